@@ -1,0 +1,113 @@
+"""Pin the CPU oracle (oracle/blsq_oracle.py) against golden vectors captured
+from the reference itself (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from _golden import load_npz, load_json, unhex, trf_inputs, dog_inputs
+from oracle import blsq_oracle as orc
+
+H = load_json("helpers.json")
+
+
+def _eq(a, b):
+    np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_helper_step_to_bound():
+    for c in H["step_size_to_bound"]:
+        t, hits = orc.step_to_bound(unhex(c["x"]), unhex(c["d"]), unhex(c["lb"]),
+                                    unhex(c["ub"]))
+        assert t == float.fromhex(c["step"])
+        _eq(hits, c["hits"])
+
+
+def test_helper_active_constraints():
+    for c in H["find_active_constraints"]:
+        a = orc.active_constraints(unhex(c["x"]), unhex(c["lb"]), unhex(c["ub"]),
+                                   rtol=float.fromhex(c["rtol"]))
+        _eq(a, c["active"])
+
+
+def test_helper_nudge_inside():
+    for c in H["make_strictly_feasible"]:
+        r = orc.nudge_inside(unhex(c["x"]), unhex(c["lb"]), unhex(c["ub"]),
+                             rstep=float.fromhex(c["rstep"]))
+        _eq(r, unhex(c["out"]))
+
+
+def test_helper_cl_scaling():
+    for c in H["scaling_vector"]:
+        v, jv = orc.cl_scaling(unhex(c["x"]), unhex(c["g"]), unhex(c["lb"]),
+                               unhex(c["ub"]))
+        _eq(v, unhex(c["v"]))
+        _eq(jv, unhex(c["jv"]))
+
+
+def test_helper_sphere_and_quadratic():
+    for c in H["intersect_trust_region"]:
+        tn, tp = orc.sphere_intersections(unhex(c["x"]), unhex(c["s"]),
+                                          float.fromhex(c["Delta"]))
+        assert tn == float.fromhex(c["t_neg"]) and tp == float.fromhex(c["t_pos"])
+    for c in H["minimize_quadratic"]:
+        t, y = orc.quad_1d_min(*(float.fromhex(c[k]) for k in "ablu"))
+        assert t == float.fromhex(c["t"]) and y == float.fromhex(c["y"])
+    with pytest.raises(ValueError):
+        orc.sphere_intersections(np.zeros(2), np.zeros(2), 1.0)
+    with pytest.raises(ValueError):
+        orc.sphere_intersections(np.array([2.0, 0]), np.ones(2), 1.0)
+
+
+TRF_CASES = load_npz("trf_small.npz") + load_npz("trf_large.npz")
+
+
+@pytest.mark.parametrize("name,ins,out", TRF_CASES, ids=[c[0] for c in TRF_CASES])
+def test_trf_tuple_matches_reference(name, ins, out):
+    P = trf_inputs(ins)
+    F, S = orc.trf_step_solve(P["J"], P["f"], P["x"], P["lb"], P["ub"],
+                              P["scale"], P["Delta"], P["alpha0"])
+    # the oracle makes the same third-party calls on the same data: exact
+    for k in ("g", "v", "jv", "d", "g_h", "diag_h", "s"):
+        _eq(getattr(F, k), out[k])
+    assert F.g_norm == float(out["g_norm"]) and F.theta == float(out["theta"])
+    _eq(np.abs(F.uf), out["abs_uf"])
+    _eq(S.p_h_tr, out["p_h_tr"])
+    assert S.alpha == float(out["alpha"]) and S.n_iter == int(out["n_iter"])
+    assert S.to_bound == float(out["to_bound"])
+    _eq(S.hits, out["hits"])
+    assert S.branch == int(out["branch"]) and S.choice == int(out["choice"])
+    k = S.steps_h.shape[0]
+    _eq(S.steps_h, out["steps_h"][:k])
+    _eq(S.qp, out["qp"][:k])
+    _eq(S.step_h, out["step_h"])
+    assert S.predicted_reduction == float(out["predicted_reduction"])
+    _eq(S.step, out["step"])
+    _eq(S.x_new, out["x_new"])
+    assert S.step_h_norm == float(out["step_h_norm"])
+    assert S.correction == float(out["correction"])
+    _eq(orc.active_constraints(S.x_new, P["lb"], P["ub"], rtol=1e-8),
+        out["active_new"])
+
+
+DOG_CASES = load_npz("dog_small.npz") + load_npz("dog_large.npz")
+
+
+@pytest.mark.parametrize("name,ins,out", DOG_CASES, ids=[c[0] for c in DOG_CASES])
+def test_dogbox_tuple_matches_reference(name, ins, out):
+    P = dog_inputs(ins)
+    F, S = orc.dogbox_step_solve(P["J"], P["f"], P["x"], P["lb"], P["ub"],
+                                 P["scale"], P["on_bound"], P["Delta"])
+    _eq(F.g, out["g"])
+    _eq(F.active.astype(np.uint8), out["active_set"])
+    assert F.g_norm == float(out["g_norm"])
+    full = np.zeros(F.n)
+    full[F.free] = F.newton
+    _eq(full, out["newton_full"])
+    full[F.free] = F.cauchy
+    _eq(full, out["cauchy_full"])
+    _eq(S.step, out["step"])
+    _eq(S.x_new, out["x_new"])
+    _eq(S.on_bound_new, out["on_bound_new"])
+    assert int(S.tr_hit) == int(out["tr_hit"])
+    assert int(S.fallback) == int(out["fallback"])
+    assert S.predicted_reduction == float(out["predicted_reduction"])
+    assert S.step_scaled_norm == float(out["step_scaled_norm"])
