@@ -1,0 +1,169 @@
+"""ctypes binding of libblsq_hip.so (include/blsq.h) — no torch, no fallback.
+
+The library is built in-tree by ``bounded-lsq_amd/csrc/Makefile`` (see
+``__graft_entry__.build``).  If it is missing, or no GPU is visible when a
+context is requested, this module raises: there is deliberately NO CPU path
+behind the product API.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libblsq_hip.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int64_p = C.POINTER(C.c_int64)
+c_int32_p = C.POINTER(C.c_int32)
+c_uint8_p = C.POINTER(C.c_uint8)
+vp = C.c_void_p
+
+# every symbol include/blsq.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "blsq_version": (C.c_int, []),
+    "blsq_device_count": (C.c_int, []),
+    "blsq_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "blsq_ctx_destroy": (C.c_int, [vp]),
+    "blsq_last_error": (C.c_char_p, [vp]),
+    "blsq_sync": (C.c_int, [vp]),
+    "blsq_dev_malloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+    "blsq_dev_free": (C.c_int, [vp, vp]),
+    "blsq_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "blsq_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "blsq_timing_enable": (C.c_int, [vp, C.c_int]),
+    "blsq_timing_reset": (C.c_int, [vp]),
+    "blsq_timing_count": (C.c_int, [vp]),
+    "blsq_timing_get": (C.c_int, [vp, C.c_int, C.POINTER(C.c_char_p), c_double_p, c_int64_p]),
+    "blsq_trf_plan_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    "blsq_trf_plan_destroy": (C.c_int, [vp]),
+    "blsq_trf_factor": (C.c_int, [vp] + [vp] * 6 + [C.c_int] + [vp] * 3),
+    "blsq_trf_step": (C.c_int, [vp, vp, vp, C.c_double] + [vp] * 11),
+    "blsq_trf_factor_dev": (C.c_int, [vp] + [vp] * 6 + [C.c_int]),
+    "blsq_trf_step_dev": (C.c_int, [vp, vp, vp, C.c_double]),
+    "blsq_trf_fetch_factor": (C.c_int, [vp] + [vp] * 5),
+    "blsq_trf_fetch_step": (C.c_int, [vp] + [vp] * 15),
+    "blsq_dogbox_plan_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    "blsq_dogbox_plan_destroy": (C.c_int, [vp]),
+    "blsq_dogbox_factor": (C.c_int, [vp] + [vp] * 6 + [C.c_int] + [vp] * 5),
+    "blsq_dogbox_step": (C.c_int, [vp] + [vp] * 9),
+    "blsq_dogbox_factor_dev": (C.c_int, [vp] + [vp] * 6 + [C.c_int, vp]),
+    "blsq_dogbox_step_dev": (C.c_int, [vp, vp]),
+    "blsq_dogbox_fetch_factor": (C.c_int, [vp] + [vp] * 7),
+    "blsq_dogbox_fetch_step": (C.c_int, [vp] + [vp] * 8),
+    "blsq_tsqr_tri_ld": (C.c_int, [C.c_int]),
+    "blsq_tsqr_plan_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    "blsq_tsqr_local_dev": (C.c_int, [vp, vp, vp, vp]),
+    "blsq_tsqr_combine_dev": (C.c_int, [vp] + [vp] * 5 + [C.c_int]),
+}
+
+_lib = None
+
+
+class BlsqError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once) and attach the declared signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BlsqError(
+            "libblsq_hip.so is not built (%s). Run `python -c 'import "
+            "__graft_entry__ as g; g.build()'` or `make -C bounded-lsq_amd/csrc`. "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(a):
+    """void* of a numpy array (or None)."""
+    if a is None:
+        return None
+    return a.ctypes.data_as(vp)
+
+
+def f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError("expected shape %r, got %r" % (tuple(shape), a.shape))
+    return a
+
+
+class Context:
+    """One device + one HIP stream (blsq_ctx).  Not thread-safe."""
+
+    def __init__(self, device_id=0):
+        self.lib = load()
+        h = vp()
+        rc = self.lib.blsq_ctx_create(int(device_id), C.byref(h))
+        if rc != 0:
+            raise BlsqError("blsq_ctx_create(device=%d) failed with code %d "
+                            "(no MI355X visible?)" % (device_id, rc))
+        self.h = h
+        self.device_id = int(device_id)
+
+    def check(self, rc, what=""):
+        if rc != 0:
+            msg = self.lib.blsq_last_error(self.h)
+            raise BlsqError("%s failed (%d): %s" % (what, rc, (msg or b"").decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.blsq_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self.check(self.lib.blsq_sync(self.h), "blsq_sync")
+
+    # ---- device memory -----------------------------------------------------
+    def malloc(self, nbytes):
+        p = vp()
+        self.check(self.lib.blsq_dev_malloc(self.h, int(nbytes), C.byref(p)), "blsq_dev_malloc")
+        return p
+
+    def free(self, p):
+        self.check(self.lib.blsq_dev_free(self.h, p), "blsq_dev_free")
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.malloc(arr.nbytes)
+        self.check(self.lib.blsq_memcpy_h2d(self.h, p, ptr(arr), arr.nbytes), "blsq_memcpy_h2d")
+        return p
+
+    def to_host(self, p, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        self.check(self.lib.blsq_memcpy_d2h(self.h, ptr(out), p, out.nbytes), "blsq_memcpy_d2h")
+        return out
+
+    # ---- timing ------------------------------------------------------------
+    def timing(self, on=True):
+        self.check(self.lib.blsq_timing_enable(self.h, 1 if on else 0), "timing_enable")
+
+    def timing_reset(self):
+        self.check(self.lib.blsq_timing_reset(self.h), "timing_reset")
+
+    def timing_read(self):
+        """-> {kernel slot name: (total_ms, launches)} (call after sync)."""
+        out = {}
+        for i in range(self.lib.blsq_timing_count(self.h)):
+            name = C.c_char_p()
+            ms = C.c_double()
+            cnt = C.c_int64()
+            self.check(self.lib.blsq_timing_get(self.h, i, C.byref(name), C.byref(ms),
+                                                C.byref(cnt)), "timing_get")
+            out[name.value.decode()] = (ms.value, cnt.value)
+        return out

@@ -1,0 +1,968 @@
+// C-ABI entry points (include/blsq.h): contexts, plans, the TSQR schedule and
+// the kernel sequence of each call.  Host-side only; kernels live in the
+// sibling .hip files.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/blsq.h"
+#include "blsq_kernels.h"
+
+using namespace blsq;
+
+namespace {
+
+constexpr int RMAX = 1088;          // max padded leaf rows: LDS panel 16 x 1090 doubles
+
+enum Slot { K_QR_LEAF = 0, K_QR_MERGE, K_PREP, K_QR_AUG, K_JACOBI, K_STEP, K_NSLOT };
+const char* kSlotNames[K_NSLOT] = {"qr_leaf", "qr_merge", "prep", "qr_aug", "jacobi_svd", "step"};
+
+inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
+inline int panel_ldp(int RP) {      // smallest LDP >= RP with LDP == 2 (mod 32)
+  int l = RP;
+  while ((l & 31) != 2) ++l;
+  return l;
+}
+
+}  // namespace
+
+struct blsq_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool timing = false;
+  double t_ms[K_NSLOT] = {0};
+  int64_t t_n[K_NSLOT] = {0};
+  struct Pending { int slot; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> pool;
+
+  int fail(hipError_t e, const char* where) {
+    err = std::string(where) + ": " + hipGetErrorString(e);
+    return (int)e;
+  }
+  int bad(int argidx, const char* what) {
+    err = std::string("invalid argument: ") + what;
+    return -argidx;
+  }
+  hipEvent_t get_event() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+  }
+  void begin(int slot) {
+    if (!timing) return;
+    Pending p{slot, get_event(), get_event()};
+    hipEventRecord(p.a, stream);
+    pending.push_back(p);
+  }
+  void end() {
+    if (!timing) return;
+    hipEventRecord(pending.back().b, stream);
+  }
+  void collect() {                  // after a stream sync
+    for (auto& p : pending) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+        t_ms[p.slot] += ms;
+        t_n[p.slot] += 1;
+      }
+      pool.push_back(p.a);
+      pool.push_back(p.b);
+    }
+    pending.clear();
+  }
+};
+
+#define HIPCHK(ctx, call)                                   \
+  do {                                                      \
+    hipError_t e__ = (call);                                \
+    if (e__ != hipSuccess) return (ctx)->fail(e__, #call);  \
+  } while (0)
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  hipError_t alloc(size_t b) {
+    bytes = b;
+    if (b == 0) return hipSuccess;
+    return hipMalloc(&p, b);
+  }
+  void release() { if (p) hipFree(p); p = nullptr; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// One level of the TSQR tree: nleaf workgroups per problem.
+struct Level {
+  int rowsA, rows_per_leaf, nleaf, RP, LDP;
+  DevBuf R;                         // [B][nleaf][NPAD*NPAD]
+};
+
+struct QrTree {
+  int B = 0, m = 0, n = 0, N = 0, NPAD = 0, NP = 0;
+  std::vector<Level> levels;        // levels.back().nleaf == 1
+  DevBuf V, T;                      // scratch shared by all QR launches of the plan
+
+  // rows: source rows per problem at level 0
+  int build(blsq_ctx* ctx, int B_, int rows, int n_, size_t extra_rp_rows) {
+    B = B_; m = rows; n = n_;
+    N = n + 1; NPAD = round_up(N, 16); NP = NPAD / 16;
+    if (NPAD > RMAX) return ctx->bad(4, "n too large (n + 1 must be <= 1088)");
+    int cur_rows = rows;
+    bool first = true;
+    size_t max_slot_rows = extra_rp_rows;   // max over launches of nslot*RP
+    size_t max_slots = (size_t)B;
+    while (true) {
+      Level L;
+      L.rowsA = cur_rows;
+      if (first) {
+        L.nleaf = std::max(1, (cur_rows + RMAX - 1) / RMAX);
+        if (L.nleaf > 1 && 2 * NPAD > RMAX)
+          return ctx->bad(4, "m > 1088 needs n + 1 <= 544 (TSQR merge capacity)");
+        L.rows_per_leaf = round_up((cur_rows + L.nleaf - 1) / L.nleaf, 16);
+        if (L.rows_per_leaf < NPAD && L.nleaf > 1) L.rows_per_leaf = NPAD;
+        L.nleaf = std::max(1, (cur_rows + L.rows_per_leaf - 1) / L.rows_per_leaf);
+      } else {
+        const int G = RMAX / NPAD;  // triangles merged per workgroup (>= 2 here)
+        L.rows_per_leaf = G * NPAD;
+        L.nleaf = (cur_rows + L.rows_per_leaf - 1) / L.rows_per_leaf;
+      }
+      L.RP = std::max(round_up(std::min(L.rows_per_leaf, std::max(cur_rows, 1)), 16), NPAD);
+      if (L.RP > RMAX) return ctx->bad(3, "leaf does not fit LDS");
+      L.LDP = panel_ldp(L.RP);
+      hipError_t e = L.R.alloc(sizeof(double) * (size_t)B * L.nleaf * NPAD * NPAD);
+      if (e != hipSuccess) return ctx->fail(e, "hipMalloc(R level)");
+      max_slot_rows = std::max(max_slot_rows, (size_t)B * L.nleaf * L.RP);
+      max_slots = std::max(max_slots, (size_t)B * L.nleaf);
+      levels.push_back(L);
+      if (L.nleaf == 1) break;
+      cur_rows = L.nleaf * NPAD;
+      first = false;
+    }
+    hipError_t e = V.alloc(sizeof(double) * max_slot_rows * NP * 16);
+    if (e != hipSuccess) return ctx->fail(e, "hipMalloc(V scratch)");
+    e = T.alloc(sizeof(double) * max_slots * NP * 256);
+    if (e != hipSuccess) return ctx->fail(e, "hipMalloc(T scratch)");
+    return 0;
+  }
+  void release() {
+    for (auto& L : levels) L.R.release();
+    V.release(); T.release();
+  }
+  const double* Rfinal() const { return levels.back().R.as<double>(); }
+
+  QrArgs base_args() const {
+    QrArgs q{};
+    q.N = N; q.NPAD = NPAD; q.NPmax = NP;
+    q.V = V.as<double>(); q.T = T.as<double>();
+    return q;
+  }
+  // [J f] -> R~  (levels 0..end); first_level lets TSQR-combine skip level 0
+  int run(blsq_ctx* ctx, const double* dJ, const double* df, int ldJ) {
+    for (size_t l = 0; l < levels.size(); ++l) {
+      const Level& L = levels[l];
+      QrArgs q = base_args();
+      if (l == 0) {
+        q.A = dJ; q.strideA = (long)m * ldJ; q.ldA = ldJ; q.rowsA = m;
+        q.F = df; q.strideF = m;
+      } else {
+        const Level& Pv = levels[l - 1];
+        q.A = Pv.R.as<double>(); q.strideA = (long)Pv.nleaf * NPAD * NPAD;
+        q.ldA = NPAD; q.rowsA = Pv.nleaf * NPAD; q.F = nullptr; q.strideF = 0;
+      }
+      q.rows_per_leaf = L.rows_per_leaf; q.RP = L.RP; q.LDP = L.LDP;
+      q.Rout = L.R.as<double>();
+      ctx->begin(l == 0 ? K_QR_LEAF : K_QR_MERGE);
+      hipError_t e = launch_qr(q, L.nleaf, B, ctx->stream);
+      ctx->end();
+      if (e != hipSuccess) return ctx->fail(e, "launch_qr");
+    }
+    return 0;
+  }
+};
+
+}  // namespace
+
+struct blsq_trf_plan {
+  blsq_ctx* ctx = nullptr;
+  int B = 0, m = 0, n = 0, ld = 0;
+  QrTree tree;
+  // TSQR (multi-rank) extras
+  int nranks = 1, m_total = 0;
+  DevBuf Rcomb;                     // [1][NPAD*NPAD] merged triangle
+  // n-space state
+  DevBuf S, X, vecs, scal2, sweeps;
+  DevBuf o_vec, o_hits, o_act, o_scal, o_info;
+  DevBuf in_J, in_f, in_vec, in_scal;   // staging for the host-pointer API
+  TrfState st{};
+  TrfStepOut out{};
+  double* d_alpha_in = nullptr;
+  int aug_RP = 0, aug_LDP = 0;
+};
+
+struct blsq_dogbox_plan {
+  blsq_ctx* ctx = nullptr;
+  int B = 0, m = 0, n = 0, ld = 0;
+  QrTree tree;
+  DevBuf S, X, vecs, ivecs, scal2, sweeps, active, onb;
+  DevBuf o_vec, o_onb, o_scal, o_info;
+  DevBuf in_J, in_f, in_vec, in_scal;
+  DogState st{};
+  DogStepOut out{};
+};
+
+// ============================================================ ctx / misc ===
+extern "C" int blsq_version(void) { return 100; }
+
+extern "C" int blsq_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int blsq_ctx_create(int device_id, blsq_ctx** out) {
+  if (!out) return -2;
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) return e != hipSuccess ? (int)e : (int)hipErrorNoDevice;
+  if (device_id < 0 || device_id >= ndev) return -1;
+  e = hipSetDevice(device_id);
+  if (e != hipSuccess) return (int)e;
+  blsq_ctx* c = new blsq_ctx();
+  c->device = device_id;
+  e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { delete c; return (int)e; }
+  *out = c;
+  return 0;
+}
+
+extern "C" int blsq_ctx_destroy(blsq_ctx* ctx) {
+  if (!ctx) return -1;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  ctx->collect();
+  for (auto e : ctx->pool) hipEventDestroy(e);
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return 0;
+}
+
+extern "C" const char* blsq_last_error(const blsq_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : "null ctx";
+}
+
+extern "C" int blsq_sync(blsq_ctx* ctx) {
+  if (!ctx) return -1;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->collect();
+  return 0;
+}
+
+extern "C" int blsq_dev_malloc(blsq_ctx* ctx, size_t bytes, void** dptr) {
+  if (!ctx) return -1;
+  if (!dptr) return ctx->bad(3, "dptr is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMalloc(dptr, bytes ? bytes : 8));
+  return 0;
+}
+extern "C" int blsq_dev_free(blsq_ctx* ctx, void* dptr) {
+  if (!ctx) return -1;
+  HIPCHK(ctx, hipFree(dptr));
+  return 0;
+}
+extern "C" int blsq_memcpy_h2d(blsq_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return -1;
+  HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+extern "C" int blsq_memcpy_d2h(blsq_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return -1;
+  HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int blsq_timing_enable(blsq_ctx* ctx, int on) {
+  if (!ctx) return -1;
+  ctx->timing = on != 0;
+  return 0;
+}
+extern "C" int blsq_timing_reset(blsq_ctx* ctx) {
+  if (!ctx) return -1;
+  for (int i = 0; i < K_NSLOT; ++i) { ctx->t_ms[i] = 0; ctx->t_n[i] = 0; }
+  return 0;
+}
+extern "C" int blsq_timing_count(const blsq_ctx*) { return K_NSLOT; }
+extern "C" int blsq_timing_get(blsq_ctx* ctx, int slot, const char** name, double* total_ms,
+                               int64_t* launches) {
+  if (!ctx) return -1;
+  if (slot < 0 || slot >= K_NSLOT) return ctx->bad(2, "slot");
+  if (name) *name = kSlotNames[slot];
+  if (total_ms) *total_ms = ctx->t_ms[slot];
+  if (launches) *launches = ctx->t_n[slot];
+  return 0;
+}
+
+// ================================================================== TRF ====
+namespace {
+
+// copy a [B][n] caller vector into the [B][ld] state layout (device to device
+// or host to device, decided by `kind`)
+int put_vec(blsq_ctx* ctx, double* dst, int ld, const double* src, int n, int B,
+            hipMemcpyKind kind) {
+  HIPCHK(ctx, hipMemcpy2DAsync(dst, sizeof(double) * ld, src, sizeof(double) * n,
+                               sizeof(double) * n, B, kind, ctx->stream));
+  return 0;
+}
+template <class T>
+int get_vec(blsq_ctx* ctx, T* dst, int n, const T* src, int ld, int B) {
+  if (!dst) return 0;
+  HIPCHK(ctx, hipMemcpy2DAsync(dst, sizeof(T) * n, src, sizeof(T) * ld, sizeof(T) * n, B,
+                               hipMemcpyDeviceToHost, ctx->stream));
+  return 0;
+}
+
+int trf_alloc_state(blsq_trf_plan* p) {
+  blsq_ctx* ctx = p->ctx;
+  const int B = p->B, ld = p->ld;
+  const size_t mat = (size_t)ld * ld;
+#define ALLOC(buf, bytes)                                               \
+  do {                                                                  \
+    hipError_t e__ = (buf).alloc(bytes);                                \
+    if (e__ != hipSuccess) return ctx->fail(e__, "hipMalloc(" #buf ")"); \
+  } while (0)
+  ALLOC(p->S, sizeof(double) * B * 2 * mat);
+  ALLOC(p->X, sizeof(double) * B * mat);
+  ALLOC(p->vecs, sizeof(double) * (size_t)B * ld * 11);
+  ALLOC(p->scal2, sizeof(double) * (size_t)B * 8);
+  ALLOC(p->sweeps, sizeof(int) * (size_t)B);
+  ALLOC(p->o_vec, sizeof(double) * (size_t)B * ld * 4);
+  ALLOC(p->o_hits, sizeof(long long) * (size_t)B * ld);
+  ALLOC(p->o_act, sizeof(long long) * (size_t)B * ld);
+  ALLOC(p->o_scal, sizeof(double) * (size_t)B * 8);
+  ALLOC(p->o_info, sizeof(int) * (size_t)B * 4);
+  ALLOC(p->in_scal, sizeof(double) * (size_t)B * 2);
+  HIPCHK(ctx, hipMemsetAsync(p->S.p, 0, p->S.bytes, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(p->vecs.p, 0, p->vecs.bytes, ctx->stream));
+  double* v = p->vecs.as<double>();
+  const size_t vs = (size_t)B * ld;
+  TrfState& st = p->st;
+  st.B = B; st.m = p->m_total; st.n = p->n; st.ld = ld;
+  st.S = p->S.as<double>(); st.X = p->X.as<double>();
+  st.x = v; st.lb = v + vs; st.ub = v + 2 * vs; st.scale = v + 3 * vs;
+  st.g = v + 4 * vs; st.v = v + 5 * vs; st.d = v + 6 * vs; st.g_h = v + 7 * vs;
+  st.diag_h = v + 8 * vs; st.s = v + 9 * vs; st.uf = v + 10 * vs;
+  double* sc = p->scal2.as<double>();
+  st.srange = sc; st.g_norm = sc + 2 * (size_t)B; st.theta = sc + 3 * (size_t)B;
+  double* ov = p->o_vec.as<double>();
+  p->out.step_h = ov; p->out.step = ov + vs; p->out.x_new = ov + 2 * vs;
+  p->out.p_h_tr = ov + 3 * vs;
+  p->out.hits = p->o_hits.as<long long>();
+  p->out.active_new = p->o_act.as<long long>();
+  p->out.scal = p->o_scal.as<double>();
+  p->out.info = p->o_info.as<int>();
+  p->aug_RP = std::max(round_up(2 * p->n, 16), ld);
+  if (p->aug_RP > RMAX) return ctx->bad(4, "n too large for the augmented system (2n <= 1088)");
+  p->aug_LDP = panel_ldp(p->aug_RP);
+  return 0;
+#undef ALLOC
+}
+
+// everything after the triangle R~ is known: prep, augmented QR, Jacobi SVD
+int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode) {
+  blsq_ctx* ctx = p->ctx;
+  p->st.Rt = Rt;
+  ctx->begin(K_PREP);
+  hipError_t e = launch_trf_prep(p->st, scale_mode, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_trf_prep");
+  QrArgs q = p->tree.base_args();
+  q.A = p->st.S; q.strideA = 2L * p->ld * p->ld; q.ldA = p->ld; q.rowsA = 2 * p->n;
+  q.F = nullptr; q.strideF = 0;
+  q.rows_per_leaf = p->aug_RP; q.RP = p->aug_RP; q.LDP = p->aug_LDP;
+  q.Rout = p->st.X;
+  ctx->begin(K_QR_AUG);
+  e = launch_qr(q, 1, p->B, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_qr(aug)");
+  JacobiArgs ja{};
+  ja.X = p->st.X; ja.strideX = (long)p->ld * p->ld; ja.ld = p->ld; ja.ncols_dev = nullptr;
+  ja.N = p->n + 1; ja.s = p->st.s; ja.uf = p->st.uf; ja.srange = p->st.srange;
+  ja.sweeps = p->sweeps.as<int>(); ja.max_sweeps = 40;
+  ctx->begin(K_JACOBI);
+  e = launch_jacobi(ja, p->B, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_jacobi");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int blsq_trf_plan_create(blsq_ctx* ctx, int B, int m, int n, blsq_trf_plan** out) {
+  if (!ctx) return -1;
+  if (!out) return ctx->bad(5, "out is NULL");
+  *out = nullptr;
+  if (B <= 0) return ctx->bad(2, "B must be positive");
+  if (m <= 0) return ctx->bad(3, "m must be positive");
+  if (n <= 0) return ctx->bad(4, "n must be positive");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  blsq_trf_plan* p = new blsq_trf_plan();
+  p->ctx = ctx; p->B = B; p->m = m; p->n = n; p->m_total = m; p->nranks = 1;
+  const int aug_rp = std::max(round_up(2 * n, 16), round_up(n + 1, 16));
+  int rc = p->tree.build(ctx, B, m, n, (size_t)B * aug_rp);
+  if (rc == 0) { p->ld = p->tree.NPAD; rc = trf_alloc_state(p); }
+  if (rc != 0) { blsq_trf_plan_destroy(p); return rc; }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  *out = p;
+  return 0;
+}
+
+extern "C" int blsq_trf_plan_destroy(blsq_trf_plan* p) {
+  if (!p) return -1;
+  hipStreamSynchronize(p->ctx->stream);
+  p->tree.release(); p->Rcomb.release();
+  p->S.release(); p->X.release(); p->vecs.release(); p->scal2.release(); p->sweeps.release();
+  p->o_vec.release(); p->o_hits.release(); p->o_act.release(); p->o_scal.release();
+  p->o_info.release(); p->in_J.release(); p->in_f.release(); p->in_vec.release();
+  p->in_scal.release();
+  delete p;
+  return 0;
+}
+
+static int trf_put_bounds(blsq_trf_plan* p, const double* x, const double* lb, const double* ub,
+                          const double* scale, hipMemcpyKind kind) {
+  blsq_ctx* ctx = p->ctx;
+  int rc;
+  if ((rc = put_vec(ctx, p->st.x, p->ld, x, p->n, p->B, kind))) return rc;
+  if ((rc = put_vec(ctx, p->st.lb, p->ld, lb, p->n, p->B, kind))) return rc;
+  if ((rc = put_vec(ctx, p->st.ub, p->ld, ub, p->n, p->B, kind))) return rc;
+  if ((rc = put_vec(ctx, p->st.scale, p->ld, scale, p->n, p->B, kind))) return rc;
+  return 0;
+}
+
+extern "C" int blsq_trf_factor_dev(blsq_trf_plan* p, const double* dJ, const double* df,
+                                   const double* dx, const double* dlb, const double* dub,
+                                   double* dscale_io, int scale_mode) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!dJ) return ctx->bad(2, "J is NULL");
+  if (!df) return ctx->bad(3, "f is NULL");
+  if (!dx || !dlb || !dub) return ctx->bad(4, "x/lb/ub is NULL");
+  if (!dscale_io) return ctx->bad(7, "scale is NULL");
+  if (scale_mode < 0 || scale_mode > 2) return ctx->bad(8, "scale_mode");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = trf_put_bounds(p, dx, dlb, dub, dscale_io, hipMemcpyDeviceToDevice);
+  if (rc) return rc;
+  if ((rc = p->tree.run(ctx, dJ, df, p->n))) return rc;
+  if ((rc = trf_after_triangle(p, p->tree.Rfinal(), scale_mode))) return rc;
+  if (scale_mode != BLSQ_SCALE_GIVEN) {
+    HIPCHK(ctx, hipMemcpy2DAsync(dscale_io, sizeof(double) * p->n, p->st.scale,
+                                 sizeof(double) * p->ld, sizeof(double) * p->n, p->B,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  return 0;
+}
+
+extern "C" int blsq_trf_step_dev(blsq_trf_plan* p, const double* dDelta, const double* dalpha_in,
+                                 double active_rtol) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!dDelta) return ctx->bad(2, "Delta is NULL");
+  if (!dalpha_in) return ctx->bad(3, "alpha is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->begin(K_STEP);
+  hipError_t e = launch_trf_step(p->st, dDelta, dalpha_in, active_rtol, p->out, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_trf_step");
+  return 0;
+}
+
+extern "C" int blsq_trf_fetch_factor(blsq_trf_plan* p, double* g, double* g_norm, double* theta,
+                                     double* scale, double* sing) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  int rc;
+  if ((rc = get_vec(ctx, g, p->n, p->st.g, p->ld, p->B))) return rc;
+  if ((rc = get_vec(ctx, scale, p->n, p->st.scale, p->ld, p->B))) return rc;
+  if ((rc = get_vec(ctx, sing, p->n, p->st.s, p->ld, p->B))) return rc;
+  if (g_norm) HIPCHK(ctx, hipMemcpyAsync(g_norm, p->st.g_norm, sizeof(double) * p->B,
+                                         hipMemcpyDeviceToHost, ctx->stream));
+  if (theta) HIPCHK(ctx, hipMemcpyAsync(theta, p->st.theta, sizeof(double) * p->B,
+                                        hipMemcpyDeviceToHost, ctx->stream));
+  return blsq_sync(ctx);
+}
+
+extern "C" int blsq_trf_fetch_step(blsq_trf_plan* p, double* alpha_out, double* step_h,
+                                   double* step, double* x_new, int64_t* hits,
+                                   int64_t* active_new, double* predicted_reduction,
+                                   double* step_h_norm, double* correction, int32_t* n_iter,
+                                   int32_t* branch, int32_t* status, double* p_h_tr,
+                                   double* to_bound, int32_t* choice) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  const int B = p->B, n = p->n, ld = p->ld;
+  int rc;
+  if ((rc = get_vec(ctx, step_h, n, p->out.step_h, ld, B))) return rc;
+  if ((rc = get_vec(ctx, step, n, p->out.step, ld, B))) return rc;
+  if ((rc = get_vec(ctx, x_new, n, p->out.x_new, ld, B))) return rc;
+  if ((rc = get_vec(ctx, p_h_tr, n, p->out.p_h_tr, ld, B))) return rc;
+  if ((rc = get_vec(ctx, (long long*)hits, n, p->out.hits, ld, B))) return rc;
+  if ((rc = get_vec(ctx, (long long*)active_new, n, p->out.active_new, ld, B))) return rc;
+  std::vector<double> sc((size_t)B * 8);
+  std::vector<int> inf((size_t)B * 4);
+  HIPCHK(ctx, hipMemcpyAsync(sc.data(), p->out.scal, sizeof(double) * sc.size(),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(inf.data(), p->out.info, sizeof(int) * inf.size(),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  if ((rc = blsq_sync(ctx))) return rc;
+  for (int b = 0; b < B; ++b) {
+    if (predicted_reduction) predicted_reduction[b] = sc[8 * b + 0];
+    if (step_h_norm) step_h_norm[b] = sc[8 * b + 1];
+    if (correction) correction[b] = sc[8 * b + 2];
+    if (alpha_out) alpha_out[b] = sc[8 * b + 3];
+    if (to_bound) to_bound[b] = sc[8 * b + 4];
+    if (n_iter) n_iter[b] = inf[4 * b + 0];
+    if (branch) branch[b] = inf[4 * b + 1];
+    if (choice) choice[b] = inf[4 * b + 2];
+    if (status) status[b] = inf[4 * b + 3];
+  }
+  return 0;
+}
+
+extern "C" int blsq_trf_factor(blsq_trf_plan* p, const double* J, const double* f,
+                               const double* x, const double* lb, const double* ub,
+                               double* scale_io, int scale_mode, double* g, double* g_norm,
+                               double* theta) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!J) return ctx->bad(2, "J is NULL");
+  if (!f) return ctx->bad(3, "f is NULL");
+  if (!x || !lb || !ub) return ctx->bad(4, "x/lb/ub is NULL");
+  if (!scale_io) return ctx->bad(7, "scale is NULL");
+  if (scale_mode < 0 || scale_mode > 2) return ctx->bad(8, "scale_mode");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t jb = sizeof(double) * (size_t)p->B * p->m * p->n;
+  const size_t fb = sizeof(double) * (size_t)p->B * p->m;
+  if (!p->in_J.p) {
+    hipError_t e = p->in_J.alloc(jb);
+    if (e != hipSuccess) return ctx->fail(e, "hipMalloc(J staging)");
+    e = p->in_f.alloc(fb);
+    if (e != hipSuccess) return ctx->fail(e, "hipMalloc(f staging)");
+  }
+  HIPCHK(ctx, hipMemcpyAsync(p->in_J.p, J, jb, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(p->in_f.p, f, fb, hipMemcpyHostToDevice, ctx->stream));
+  int rc = trf_put_bounds(p, x, lb, ub, scale_io, hipMemcpyHostToDevice);
+  if (rc) return rc;
+  if ((rc = p->tree.run(ctx, p->in_J.as<double>(), p->in_f.as<double>(), p->n))) return rc;
+  if ((rc = trf_after_triangle(p, p->tree.Rfinal(), scale_mode))) return rc;
+  return blsq_trf_fetch_factor(p, g, g_norm, theta,
+                               scale_mode != BLSQ_SCALE_GIVEN ? scale_io : nullptr, nullptr);
+}
+
+extern "C" int blsq_trf_step(blsq_trf_plan* p, const double* Delta, double* alpha_io,
+                             double active_rtol, double* step_h, double* step, double* x_new,
+                             int64_t* hits, int64_t* active_new, double* predicted_reduction,
+                             double* step_h_norm, double* correction, int32_t* n_iter,
+                             int32_t* branch, int32_t* status) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!Delta) return ctx->bad(2, "Delta is NULL");
+  if (!alpha_io) return ctx->bad(3, "alpha is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  double* dD = p->in_scal.as<double>();
+  double* dA = dD + p->B;
+  HIPCHK(ctx, hipMemcpyAsync(dD, Delta, sizeof(double) * p->B, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(dA, alpha_io, sizeof(double) * p->B, hipMemcpyHostToDevice, ctx->stream));
+  int rc = blsq_trf_step_dev(p, dD, dA, active_rtol);
+  if (rc) return rc;
+  return blsq_trf_fetch_step(p, alpha_io, step_h, step, x_new, hits, active_new,
+                             predicted_reduction, step_h_norm, correction, n_iter, branch,
+                             status, nullptr, nullptr, nullptr);
+}
+
+// ================================================================= TSQR ====
+extern "C" int blsq_tsqr_tri_ld(int n) { return round_up(n + 1, 16); }
+
+extern "C" int blsq_tsqr_plan_create(blsq_ctx* ctx, int m_local, int n, int nranks,
+                                     blsq_trf_plan** out) {
+  if (!ctx) return -1;
+  if (!out) return ctx->bad(5, "out is NULL");
+  *out = nullptr;
+  if (m_local <= 0) return ctx->bad(2, "m_local must be positive");
+  if (n <= 0) return ctx->bad(3, "n must be positive");
+  if (nranks <= 0) return ctx->bad(4, "nranks must be positive");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  blsq_trf_plan* p = new blsq_trf_plan();
+  p->ctx = ctx; p->B = 1; p->m = m_local; p->n = n; p->nranks = nranks;
+  long long mt = (long long)m_local * nranks;
+  p->m_total = mt > 2147483647LL ? 2147483647 : (int)mt;
+  const int NPAD = round_up(n + 1, 16);
+  if (nranks > 1 && 2 * NPAD > RMAX) {
+    delete p;
+    return ctx->bad(3, "TSQR needs n + 1 <= 544");
+  }
+  const int aug_rp = std::max(round_up(2 * n, 16), NPAD);
+  // scratch must also cover the combine merges: nranks triangles, G per workgroup
+  const int G = std::max(2, RMAX / NPAD);
+  const size_t comb_rows = (size_t)((nranks + G - 1) / G) * (size_t)(G * NPAD);
+  int rc = p->tree.build(ctx, 1, m_local, n, std::max((size_t)aug_rp, comb_rows));
+  if (rc == 0) { p->ld = p->tree.NPAD; rc = trf_alloc_state(p); }
+  if (rc == 0) {
+    // two ping-pong levels for the combine tree
+    hipError_t e = p->Rcomb.alloc(sizeof(double) * 2 * (size_t)((nranks + G - 1) / G + 1) *
+                                  NPAD * NPAD);
+    if (e != hipSuccess) rc = ctx->fail(e, "hipMalloc(Rcomb)");
+  }
+  if (rc != 0) { blsq_trf_plan_destroy(p); return rc; }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  *out = p;
+  return 0;
+}
+
+extern "C" int blsq_tsqr_local_dev(blsq_trf_plan* p, const double* dJ_block,
+                                   const double* df_block, double* dtri_out) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!dJ_block) return ctx->bad(2, "J block is NULL");
+  if (!df_block) return ctx->bad(3, "f block is NULL");
+  if (!dtri_out) return ctx->bad(4, "tri_out is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = p->tree.run(ctx, dJ_block, df_block, p->n);
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(dtri_out, p->tree.Rfinal(), sizeof(double) * p->ld * p->ld,
+                             hipMemcpyDeviceToDevice, ctx->stream));
+  return 0;
+}
+
+extern "C" int blsq_tsqr_combine_dev(blsq_trf_plan* p, const double* dtri_stack,
+                                     const double* dx, const double* dlb, const double* dub,
+                                     double* dscale_io, int scale_mode) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!dtri_stack) return ctx->bad(2, "tri stack is NULL");
+  if (!dx || !dlb || !dub) return ctx->bad(3, "x/lb/ub is NULL");
+  if (!dscale_io) return ctx->bad(6, "scale is NULL");
+  if (scale_mode < 0 || scale_mode > 2) return ctx->bad(7, "scale_mode");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = trf_put_bounds(p, dx, dlb, dub, dscale_io, hipMemcpyDeviceToDevice);
+  if (rc) return rc;
+  const int NPAD = p->ld;
+  const double* src = dtri_stack;
+  int ntri = p->nranks;
+  const int G = std::max(2, RMAX / NPAD);
+  double* pp[2] = {p->Rcomb.as<double>(),
+                   p->Rcomb.as<double>() + (size_t)((p->nranks + G - 1) / G + 1) * NPAD * NPAD};
+  int flip = 0;
+  while (ntri > 1) {
+    QrArgs q = p->tree.base_args();
+    q.A = src; q.strideA = 0; q.ldA = NPAD; q.rowsA = ntri * NPAD; q.F = nullptr; q.strideF = 0;
+    q.rows_per_leaf = G * NPAD;
+    const int nleaf = (ntri + G - 1) / G;
+    q.RP = std::max(round_up(std::min(q.rows_per_leaf, q.rowsA), 16), NPAD);
+    q.LDP = panel_ldp(q.RP);
+    q.Rout = pp[flip];
+    ctx->begin(K_QR_MERGE);
+    hipError_t e = launch_qr(q, nleaf, 1, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_qr(combine)");
+    src = pp[flip];
+    flip ^= 1;
+    ntri = nleaf;
+  }
+  if ((rc = trf_after_triangle(p, src, scale_mode))) return rc;
+  if (scale_mode != BLSQ_SCALE_GIVEN) {
+    HIPCHK(ctx, hipMemcpyAsync(dscale_io, p->st.scale, sizeof(double) * p->n,
+                               hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  return 0;
+}
+
+// =============================================================== dogbox ====
+namespace {
+
+int dog_alloc_state(blsq_dogbox_plan* p) {
+  blsq_ctx* ctx = p->ctx;
+  const int B = p->B, ld = p->ld;
+  const size_t mat = (size_t)ld * ld;
+  const size_t vs = (size_t)B * ld;
+#define ALLOC(buf, bytes)                                               \
+  do {                                                                  \
+    hipError_t e__ = (buf).alloc(bytes);                                \
+    if (e__ != hipSuccess) return ctx->fail(e__, "hipMalloc(" #buf ")"); \
+  } while (0)
+  ALLOC(p->S, sizeof(double) * B * mat);
+  ALLOC(p->X, sizeof(double) * B * mat);
+  ALLOC(p->vecs, sizeof(double) * vs * 9);
+  ALLOC(p->ivecs, sizeof(int) * (vs + B));
+  ALLOC(p->scal2, sizeof(double) * (size_t)B * 4);
+  ALLOC(p->sweeps, sizeof(int) * (size_t)B);
+  ALLOC(p->active, vs);
+  ALLOC(p->onb, sizeof(long long) * vs);
+  ALLOC(p->o_vec, sizeof(double) * vs * 2);
+  ALLOC(p->o_onb, sizeof(long long) * vs);
+  ALLOC(p->o_scal, sizeof(double) * (size_t)B * 4);
+  ALLOC(p->o_info, sizeof(int) * (size_t)B * 4);
+  ALLOC(p->in_scal, sizeof(double) * (size_t)B);
+  HIPCHK(ctx, hipMemsetAsync(p->S.p, 0, p->S.bytes, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(p->X.p, 0, p->X.bytes, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(p->vecs.p, 0, p->vecs.bytes, ctx->stream));
+  double* v = p->vecs.as<double>();
+  DogState& st = p->st;
+  st.B = B; st.m = p->m; st.n = p->n; st.ld = ld;
+  st.S = p->S.as<double>(); st.X = p->X.as<double>();
+  st.x = v; st.lb = v + vs; st.ub = v + 2 * vs; st.scale = v + 3 * vs; st.g = v + 4 * vs;
+  st.s = v + 5 * vs; st.uf = v + 6 * vs; st.newton = v + 7 * vs; st.cauchy = v + 8 * vs;
+  st.on_bound = p->onb.as<long long>();
+  st.free_idx = p->ivecs.as<int>(); st.ncols = p->ivecs.as<int>() + vs;
+  st.srange = p->scal2.as<double>(); st.g_norm = p->scal2.as<double>() + 2 * (size_t)B;
+  st.active = p->active.as<unsigned char>();
+  p->out.step = p->o_vec.as<double>(); p->out.x_new = p->o_vec.as<double>() + vs;
+  p->out.on_bound_new = p->o_onb.as<long long>();
+  p->out.scal = p->o_scal.as<double>(); p->out.info = p->o_info.as<int>();
+  return 0;
+#undef ALLOC
+}
+
+int dog_put(blsq_dogbox_plan* p, const double* x, const double* lb, const double* ub,
+            const double* scale, const int64_t* on_bound, hipMemcpyKind kind) {
+  blsq_ctx* ctx = p->ctx;
+  int rc;
+  if ((rc = put_vec(ctx, p->st.x, p->ld, x, p->n, p->B, kind))) return rc;
+  if ((rc = put_vec(ctx, p->st.lb, p->ld, lb, p->n, p->B, kind))) return rc;
+  if ((rc = put_vec(ctx, p->st.ub, p->ld, ub, p->n, p->B, kind))) return rc;
+  if ((rc = put_vec(ctx, p->st.scale, p->ld, scale, p->n, p->B, kind))) return rc;
+  HIPCHK(ctx, hipMemcpy2DAsync(p->st.on_bound, sizeof(long long) * p->ld, on_bound,
+                               sizeof(long long) * p->n, sizeof(long long) * p->n, p->B, kind,
+                               ctx->stream));
+  return 0;
+}
+
+int dog_after_triangle(blsq_dogbox_plan* p, int scale_mode) {
+  blsq_ctx* ctx = p->ctx;
+  p->st.Rt = p->tree.Rfinal();
+  ctx->begin(K_PREP);
+  hipError_t e = launch_dog_prep(p->st, scale_mode, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_dog_prep");
+  QrArgs q = p->tree.base_args();
+  q.A = p->st.S; q.strideA = (long)p->ld * p->ld; q.ldA = p->ld; q.rowsA = p->n;
+  q.F = nullptr; q.strideF = 0; q.ncols_dev = p->st.ncols;
+  q.rows_per_leaf = p->ld; q.RP = p->ld; q.LDP = panel_ldp(p->ld);
+  q.Rout = p->st.X;
+  ctx->begin(K_QR_AUG);
+  e = launch_qr(q, 1, p->B, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_qr(free block)");
+  JacobiArgs ja{};
+  ja.X = p->st.X; ja.strideX = (long)p->ld * p->ld; ja.ld = p->ld; ja.ncols_dev = p->st.ncols;
+  ja.N = p->n + 1; ja.s = p->st.s; ja.uf = p->st.uf; ja.srange = p->st.srange;
+  ja.sweeps = p->sweeps.as<int>(); ja.max_sweeps = 40;
+  ctx->begin(K_JACOBI);
+  e = launch_jacobi(ja, p->B, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_jacobi");
+  ctx->begin(K_STEP);
+  e = launch_dog_solve(p->st, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_dog_solve");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int blsq_dogbox_plan_create(blsq_ctx* ctx, int B, int m, int n,
+                                       blsq_dogbox_plan** out) {
+  if (!ctx) return -1;
+  if (!out) return ctx->bad(5, "out is NULL");
+  *out = nullptr;
+  if (B <= 0) return ctx->bad(2, "B must be positive");
+  if (m <= 0) return ctx->bad(3, "m must be positive");
+  if (n <= 0) return ctx->bad(4, "n must be positive");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  blsq_dogbox_plan* p = new blsq_dogbox_plan();
+  p->ctx = ctx; p->B = B; p->m = m; p->n = n;
+  int rc = p->tree.build(ctx, B, m, n, (size_t)B * round_up(n + 1, 16));
+  if (rc == 0) { p->ld = p->tree.NPAD; rc = dog_alloc_state(p); }
+  if (rc != 0) { blsq_dogbox_plan_destroy(p); return rc; }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  *out = p;
+  return 0;
+}
+
+extern "C" int blsq_dogbox_plan_destroy(blsq_dogbox_plan* p) {
+  if (!p) return -1;
+  hipStreamSynchronize(p->ctx->stream);
+  p->tree.release();
+  p->S.release(); p->X.release(); p->vecs.release(); p->ivecs.release(); p->scal2.release();
+  p->sweeps.release(); p->active.release(); p->onb.release(); p->o_vec.release();
+  p->o_onb.release(); p->o_scal.release(); p->o_info.release(); p->in_J.release();
+  p->in_f.release(); p->in_vec.release(); p->in_scal.release();
+  delete p;
+  return 0;
+}
+
+extern "C" int blsq_dogbox_factor_dev(blsq_dogbox_plan* p, const double* dJ, const double* df,
+                                      const double* dx, const double* dlb, const double* dub,
+                                      double* dscale_io, int scale_mode,
+                                      const int64_t* don_bound) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!dJ) return ctx->bad(2, "J is NULL");
+  if (!df) return ctx->bad(3, "f is NULL");
+  if (!dx || !dlb || !dub) return ctx->bad(4, "x/lb/ub is NULL");
+  if (!dscale_io) return ctx->bad(7, "scale is NULL");
+  if (scale_mode < 0 || scale_mode > 2) return ctx->bad(8, "scale_mode");
+  if (!don_bound) return ctx->bad(9, "on_bound is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = dog_put(p, dx, dlb, dub, dscale_io, don_bound, hipMemcpyDeviceToDevice);
+  if (rc) return rc;
+  if ((rc = p->tree.run(ctx, dJ, df, p->n))) return rc;
+  if ((rc = dog_after_triangle(p, scale_mode))) return rc;
+  if (scale_mode != BLSQ_SCALE_GIVEN) {
+    HIPCHK(ctx, hipMemcpy2DAsync(dscale_io, sizeof(double) * p->n, p->st.scale,
+                                 sizeof(double) * p->ld, sizeof(double) * p->n, p->B,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  return 0;
+}
+
+extern "C" int blsq_dogbox_step_dev(blsq_dogbox_plan* p, const double* dDelta) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!dDelta) return ctx->bad(2, "Delta is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->begin(K_STEP);
+  hipError_t e = launch_dog_step(p->st, dDelta, p->out, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_dog_step");
+  return 0;
+}
+
+extern "C" int blsq_dogbox_fetch_factor(blsq_dogbox_plan* p, double* g, uint8_t* active_set,
+                                        double* g_norm, int32_t* all_active, double* scale,
+                                        double* newton_full, double* cauchy_full) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  const int B = p->B, n = p->n, ld = p->ld;
+  int rc;
+  if ((rc = get_vec(ctx, g, n, p->st.g, ld, B))) return rc;
+  if ((rc = get_vec(ctx, scale, n, p->st.scale, ld, B))) return rc;
+  if ((rc = get_vec(ctx, (unsigned char*)active_set, n, p->st.active, ld, B))) return rc;
+  if (g_norm) HIPCHK(ctx, hipMemcpyAsync(g_norm, p->st.g_norm, sizeof(double) * B,
+                                         hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<int> nc(B), fidx;
+  HIPCHK(ctx, hipMemcpyAsync(nc.data(), p->st.ncols, sizeof(int) * B, hipMemcpyDeviceToHost,
+                             ctx->stream));
+  std::vector<double> nw, ca;
+  if (newton_full || cauchy_full) {
+    fidx.resize((size_t)B * ld); nw.resize((size_t)B * ld); ca.resize((size_t)B * ld);
+    HIPCHK(ctx, hipMemcpyAsync(fidx.data(), p->st.free_idx, sizeof(int) * fidx.size(),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(nw.data(), p->st.newton, sizeof(double) * nw.size(),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ca.data(), p->st.cauchy, sizeof(double) * ca.size(),
+                               hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if ((rc = blsq_sync(ctx))) return rc;
+  for (int b = 0; b < B; ++b) {
+    if (all_active) all_active[b] = (nc[b] == 0) ? 1 : 0;
+    if (newton_full || cauchy_full) {
+      for (int j = 0; j < n; ++j) {
+        if (newton_full) newton_full[(size_t)b * n + j] = 0.0;
+        if (cauchy_full) cauchy_full[(size_t)b * n + j] = 0.0;
+      }
+      for (int q = 0; q + 1 < nc[b]; ++q) {
+        const int j = fidx[(size_t)b * ld + q];
+        if (newton_full) newton_full[(size_t)b * n + j] = nw[(size_t)b * ld + q];
+        if (cauchy_full) cauchy_full[(size_t)b * n + j] = ca[(size_t)b * ld + q];
+      }
+    }
+  }
+  return 0;
+}
+
+extern "C" int blsq_dogbox_fetch_step(blsq_dogbox_plan* p, double* step, double* x_new,
+                                      int64_t* on_bound_new, uint8_t* tr_hit,
+                                      double* predicted_reduction, double* step_scaled_norm,
+                                      uint8_t* fallback, int32_t* status) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  const int B = p->B, n = p->n, ld = p->ld;
+  int rc;
+  if ((rc = get_vec(ctx, step, n, p->out.step, ld, B))) return rc;
+  if ((rc = get_vec(ctx, x_new, n, p->out.x_new, ld, B))) return rc;
+  if ((rc = get_vec(ctx, (long long*)on_bound_new, n, p->out.on_bound_new, ld, B))) return rc;
+  std::vector<double> sc((size_t)B * 4);
+  std::vector<int> inf((size_t)B * 4);
+  HIPCHK(ctx, hipMemcpyAsync(sc.data(), p->out.scal, sizeof(double) * sc.size(),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(inf.data(), p->out.info, sizeof(int) * inf.size(),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  if ((rc = blsq_sync(ctx))) return rc;
+  for (int b = 0; b < B; ++b) {
+    if (predicted_reduction) predicted_reduction[b] = sc[4 * b + 0];
+    if (step_scaled_norm) step_scaled_norm[b] = sc[4 * b + 1];
+    if (tr_hit) tr_hit[b] = (uint8_t)inf[4 * b + 0];
+    if (fallback) fallback[b] = (uint8_t)inf[4 * b + 1];
+    if (status) status[b] = inf[4 * b + 3];
+  }
+  return 0;
+}
+
+extern "C" int blsq_dogbox_factor(blsq_dogbox_plan* p, const double* J, const double* f,
+                                  const double* x, const double* lb, const double* ub,
+                                  double* scale_io, int scale_mode, const int64_t* on_bound,
+                                  double* g, uint8_t* active_set, double* g_norm,
+                                  int32_t* all_active) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!J) return ctx->bad(2, "J is NULL");
+  if (!f) return ctx->bad(3, "f is NULL");
+  if (!x || !lb || !ub) return ctx->bad(4, "x/lb/ub is NULL");
+  if (!scale_io) return ctx->bad(7, "scale is NULL");
+  if (scale_mode < 0 || scale_mode > 2) return ctx->bad(8, "scale_mode");
+  if (!on_bound) return ctx->bad(9, "on_bound is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t jb = sizeof(double) * (size_t)p->B * p->m * p->n;
+  const size_t fb = sizeof(double) * (size_t)p->B * p->m;
+  if (!p->in_J.p) {
+    hipError_t e = p->in_J.alloc(jb);
+    if (e != hipSuccess) return ctx->fail(e, "hipMalloc(J staging)");
+    e = p->in_f.alloc(fb);
+    if (e != hipSuccess) return ctx->fail(e, "hipMalloc(f staging)");
+  }
+  HIPCHK(ctx, hipMemcpyAsync(p->in_J.p, J, jb, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(p->in_f.p, f, fb, hipMemcpyHostToDevice, ctx->stream));
+  int rc = dog_put(p, x, lb, ub, scale_io, on_bound, hipMemcpyHostToDevice);
+  if (rc) return rc;
+  if ((rc = p->tree.run(ctx, p->in_J.as<double>(), p->in_f.as<double>(), p->n))) return rc;
+  if ((rc = dog_after_triangle(p, scale_mode))) return rc;
+  return blsq_dogbox_fetch_factor(p, g, active_set, g_norm, all_active,
+                                  scale_mode != BLSQ_SCALE_GIVEN ? scale_io : nullptr, nullptr,
+                                  nullptr);
+}
+
+extern "C" int blsq_dogbox_step(blsq_dogbox_plan* p, const double* Delta, double* step,
+                                double* x_new, int64_t* on_bound_new, uint8_t* tr_hit,
+                                double* predicted_reduction, double* step_scaled_norm,
+                                uint8_t* fallback, int32_t* status) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!Delta) return ctx->bad(2, "Delta is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  double* dD = p->in_scal.as<double>();
+  HIPCHK(ctx, hipMemcpyAsync(dD, Delta, sizeof(double) * p->B, hipMemcpyHostToDevice, ctx->stream));
+  int rc = blsq_dogbox_step_dev(p, dD);
+  if (rc) return rc;
+  return blsq_dogbox_fetch_step(p, step, x_new, on_bound_new, tr_hit, predicted_reduction,
+                                step_scaled_norm, fallback, status);
+}

@@ -1,0 +1,108 @@
+// Host-visible launch interfaces of the HIP kernels (internal to the library).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace blsq {
+
+// ---------------------------------------------------------------- QR ------
+struct QrArgs {
+  const double* A;        // source, row-major; problem b at A + b*strideA
+  long strideA;
+  int ldA;                // row stride of the source
+  int rowsA;              // rows of the source per problem
+  const double* F;        // optional extra (last) column, problem b at F + b*strideF
+  long strideF;
+  const int* ncols_dev;   // optional per-problem N; nullptr -> N
+  int N;                  // columns to factor (incl. the rhs column if any)
+  int rows_per_leaf;      // source rows per leaf (workgroup)
+  int RP;                 // padded leaf rows (multiple of 16, >= NPAD)
+  int LDP;                // LDS column stride of the panel (== 2 mod 32)
+  int NPAD;               // leading dimension (and row count) of each R output
+  int NPmax;              // panels reserved in the V/T scratch per slot
+  double* V;              // scratch [slot][NPmax][RP][16]
+  double* T;              // scratch [slot][NPmax][256]
+  double* Rout;           // [slot][NPAD][NPAD], slot = b*nleaf + leaf
+};
+size_t qr_lds_bytes(int LDP);
+hipError_t launch_qr(const QrArgs& q, int nleaf, int B, hipStream_t st);
+
+// ------------------------------------------------------------- Jacobi -----
+// One-sided Jacobi on the ROWS of the n x (n+1) array [R | c] (row stride ld):
+// U^T [R | c] = [S V^T | U^T c].  In place.
+struct JacobiArgs {
+  double* X;              // [B][ld*ld]
+  long strideX;
+  int ld;
+  const int* ncols_dev;   // optional per-problem N (= n+1); nullptr -> N
+  int N;
+  double* s;              // [B][ld]  singular values (unsorted)
+  double* uf;             // [B][ld]  (U^T c)_i
+  double* srange;         // [B][2]   max, min singular value
+  int* sweeps;            // [B]
+  int max_sweeps;
+};
+hipError_t launch_jacobi(const JacobiArgs& a, int B, hipStream_t st);
+
+// ---------------------------------------------------------------- TRF -----
+struct TrfState {         // all device pointers, batch-major, vector stride ld
+  int B, m, n, ld;        // ld == NPAD
+  const double* Rt;       // [B][ld*ld]   R~ = [R c; 0 rho] of [J f]
+  double* S;              // [B][2*ld*ld] stacked [R D | c ; E | 0]
+  double* X;              // [B][ld*ld]   R~_aug, then (Jacobi) rows s_i v_i^T | uf_i
+  double *x, *lb, *ub, *scale;            // [B][ld]
+  double *g, *v, *d, *g_h, *diag_h;       // [B][ld]
+  double *s, *uf;                         // [B][ld]
+  double *srange;                         // [B][2]
+  double *g_norm, *theta;                 // [B]
+};
+// jac_scaling: 0 keep `scale`; 1 scale = 1/||J col|| (0 -> 1)  (trf.py:216-219);
+//              2 scale = min(scale, 1/||J col||)               (trf.py:239-242)
+hipError_t launch_trf_prep(const TrfState& st, int jac_scaling, hipStream_t s);
+
+struct TrfStepOut {       // device pointers
+  double* step_h;         // [B][ld]
+  double* step;           // [B][ld]
+  double* x_new;          // [B][ld]
+  long long* hits;        // [B][ld]  hits of x + p (bounds.py:24-48)
+  long long* active_new;  // [B][ld]  find_active_constraints(x_new, rtol)
+  double* p_h_tr;         // [B][ld]  raw trust-region solution
+  double* scal;           // [B][8]: predicted_reduction, step_h_norm, correction,
+                          //         alpha_out, to_bound, qp0, qp1, qp2
+  int* info;              // [B][4]: n_iter, branch, choice, status
+};
+hipError_t launch_trf_step(const TrfState& st, const double* Delta,
+                           const double* alpha_in, double active_rtol,
+                           const TrfStepOut& out, hipStream_t s);
+
+// -------------------------------------------------------------- dogbox ----
+struct DogState {
+  int B, m, n, ld;
+  const double* Rt;       // [B][ld*ld]
+  double* S;              // [B][ld*ld]   R~[:, free ++ rhs], compacted columns
+  double* X;              // [B][ld*ld]   its triangle, then Jacobi rows
+  double *x, *lb, *ub, *scale;            // [B][ld]
+  long long* on_bound;    // [B][ld]
+  double *g;              // [B][ld]
+  int* free_idx;          // [B][ld]  free_idx[q] = original column of free var q
+  int* ncols;             // [B]      nfree + 1  (0 when every variable is active)
+  double *s, *uf, *srange;
+  double *newton, *cauchy;                // [B][ld], compact (free order)
+  double *g_norm;                         // [B]
+  unsigned char* active;                  // [B][ld]
+};
+hipError_t launch_dog_prep(const DogState& st, int jac_scaling, hipStream_t s);
+hipError_t launch_dog_solve(const DogState& st, hipStream_t s);
+
+struct DogStepOut {
+  double* step;           // [B][ld]  full length
+  double* x_new;          // [B][ld]
+  long long* on_bound_new;  // [B][ld]
+  double* scal;           // [B][4]: predicted_reduction, ||step/scale||_inf, -, -
+  int* info;              // [B][4]: tr_hit, fallback, all_active, status
+};
+hipError_t launch_dog_step(const DogState& st, const double* Delta,
+                           const DogStepOut& out, hipStream_t s);
+
+}  // namespace blsq

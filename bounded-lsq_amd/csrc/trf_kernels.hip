@@ -1,0 +1,457 @@
+// n-space kernels of the Trust Region Reflective step (one workgroup / problem).
+//
+// Everything the reference does between the SVD and the next fun() call
+// (bounded_lsq/trf.py:244-308) expressed on the triangle R~ = [R c] of [J f]:
+//   g = J^T f = R^T c                                  (trf.py:244)
+//   ||J[:,j]|| = ||R[:,j]||  for 'jac' scaling          (trf.py:216-219,239-242)
+//   J_h = J D  =>  (J_h a).(J_h b) = (R D a).(R D b)    (trf.py:69-73,100)
+//   svd([J D; E]) <-> svd of the triangle of [R D; E]  (trf.py:264-274)
+// The arithmetic of the bound geometry keeps the reference's elementwise
+// operation order (this file is compiled with -ffp-contract=off): masks come
+// from exact == on computed minima (bounds.py:47-48).
+#include "blsq_device.h"
+#include "blsq_kernels.h"
+
+namespace blsq {
+
+static constexpr int NS_NT = 256;
+static constexpr int NS_NW = NS_NT / WAVE;
+static constexpr double EPS = 2.220446049250313e-16;
+
+// ------------------------------------------------------------------ prep --
+__global__ __launch_bounds__(NS_NT) void trf_prep_kernel(TrfState st, int jac_scaling) {
+  __shared__ double red[32];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = st.n, ld = st.ld;
+  const double* Rt = st.Rt + (long)b * ld * ld;
+  double* S = st.S + (long)b * 2 * ld * ld;
+  const long vo = (long)b * ld;
+  double gmax = 0.0;
+  for (int j = tid; j < n; j += NS_NT) {
+    // g_j = sum_{i<=j} R[i][j] c_i ; column norm of R for 'jac' scaling
+    double gj = 0.0, nn = 0.0;
+    for (int i = 0; i <= j; ++i) {
+      const double rij = Rt[(long)i * ld + j];
+      gj = fma(rij, Rt[(long)i * ld + n], gj);
+      nn = fma(rij, rij, nn);
+    }
+    double sc = st.scale[vo + j];
+    if (jac_scaling == 1) {
+      double jn = sqrt(nn);
+      if (jn == 0.0) jn = 1.0;
+      sc = 1.0 / jn;
+    } else if (jac_scaling == 2) {
+      const double inv = 1.0 / sqrt(nn);    // 1/0 = inf keeps the old scale
+      sc = (inv < sc) ? inv : sc;
+    }
+    st.scale[vo + j] = sc;
+    // Coleman-Li scaling vector (bounds.py:106-149)
+    const double xj = st.x[vo + j], lj = st.lb[vo + j], uj = st.ub[vo + j];
+    double v = 1.0, jv = 0.0;
+    if (gj < 0.0 && is_finite(uj)) { v = uj - xj; jv = -1.0; }
+    if (gj > 0.0 && is_finite(lj)) { v = xj - lj; jv = 1.0; }
+    const double d = sqrt(v) * sc;                       // trf.py:248
+    st.g[vo + j] = gj;
+    st.v[vo + j] = v;
+    st.d[vo + j] = d;
+    st.g_h[vo + j] = d * gj;                             // trf.py:249
+    st.diag_h[vo + j] = gj * jv * (sc * sc);             // trf.py:250
+    gmax = nanmax2(gmax, fabs(gj * v));                  // trf.py:252
+  }
+  gmax = block_max(gmax, red);
+  if (tid == 0) {
+    st.g_norm[b] = gmax;
+    const double th = 1.0 - gmax;
+    st.theta[b] = (th > 0.995) ? th : 0.995;             // trf.py:277
+  }
+  __syncthreads();
+  // stacked system  [R D | c ; E | 0],  E = diag(sqrt(diag_h))   (trf.py:264-270)
+  const int N = n + 1;
+  for (int idx = tid; idx < 2 * n * N; idx += NS_NT) {
+    const int row = idx / N, col = idx - row * N;
+    double val;
+    if (row < n) {
+      if (col < n) val = (col >= row) ? Rt[(long)row * ld + col] * st.d[vo + col] : 0.0;
+      else val = Rt[(long)row * ld + n];
+    } else {
+      const int i = row - n;
+      val = (col == i) ? sqrt(st.diag_h[vo + i]) : 0.0;
+    }
+    S[(long)row * ld + col] = val;
+  }
+}
+
+hipError_t launch_trf_prep(const TrfState& st, int jac_scaling, hipStream_t s) {
+  hipLaunchKernelGGL(trf_prep_kernel, dim3(st.B), dim3(NS_NT), 0, s, st, jac_scaling);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ step --
+struct StepCtx {
+  int n, ld;
+  const double *x, *lb, *ub, *d;
+  double* red;
+};
+
+// bounds.py:24-48.  dir[] in LDS; returns min step, writes the per-element
+// steps to `steps` (LDS) so the caller can form the hit mask.
+__device__ double step_to_bound_dev(const StepCtx& c, const double* xs,
+                                    const double* dir, double* steps) {
+  double tmin = __builtin_inf();
+  for (int j = threadIdx.x; j < c.n; j += NS_NT) {
+    const double dj = dir[j];
+    double t = __builtin_inf();
+    if (dj != 0.0) {
+      const double lo = (c.lb[j] - xs[j]) / dj;
+      const double hi = (c.ub[j] - xs[j]) / dj;
+      t = nanmax2(lo, hi);
+    }
+    steps[j] = t;
+    tmin = nanmin2(tmin, t);
+  }
+  return block_min(tmin, c.red);
+}
+
+// u = R_h s  (R_h upper triangular, row-major, stride ld): one wave per row.
+__device__ void tri_matvec(const double* Rh, int n, int ld, const double* svec,
+                           double* u) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int i = w; i < n; i += NS_NW) {
+    const double* row = Rh + (long)i * ld;
+    double acc = 0.0;
+    for (int j = i + lane; j < n; j += WAVE) acc = fma(row[j], svec[j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) u[i] = acc;
+  }
+  __syncthreads();
+}
+
+__device__ double dot_dev(const double* a, const double* b, int n, double* red) {
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < n; j += NS_NT) acc += a[j] * b[j];
+  return block_sum(acc, red);
+}
+__device__ double dot3_dev(const double* a, const double* w, const double* b, int n,
+                           double* red) {      // sum (a*w)*b   (np.dot(a*w, b))
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < n; j += NS_NT) acc += (a[j] * w[j]) * b[j];
+  return block_sum(acc, red);
+}
+
+// trf.py:15-34 (minimize_quadratic)
+__device__ double quad_min_dev(double a, double b, double lo, double hi) {
+  double tbest = lo, ybest = a * (lo * lo) + b * lo;
+  const double yh = a * (hi * hi) + b * hi;
+  if (yh < ybest) { ybest = yh; tbest = hi; }
+  if (a != 0.0) {
+    const double ext = -0.5 * b / a;
+    if (lo <= ext && ext <= hi) {
+      const double ye = a * (ext * ext) + b * ext;
+      if (ye < ybest) { ybest = ye; tbest = ext; }
+    }
+  }
+  return tbest;
+}
+
+__global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const double* Delta_in,
+                                                         const double* alpha_in,
+                                                         double active_rtol, TrfStepOut out) {
+  extern __shared__ double sh[];
+  __shared__ double red[32];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = st.n, ld = st.ld, m = st.m;
+  const long vo = (long)b * ld;
+  double* ph = sh;            // p_h
+  double* rh = ph + ld;       // reflected direction / step
+  double* tmp = rh + ld;      // scratch vector (p, r, steps)
+  double* tmp2 = tmp + ld;
+  double* up = tmp2 + ld;     // R_h p_h
+  double* ur = up + ld;       // R_h r_h
+  double* ug = ur + ld;       // R_h g_h
+  double* coef = ug + ld;
+
+  const double* sv = st.s + vo;
+  const double* uf = st.uf + vo;
+  const double* X = st.X + (long)b * ld * ld;
+  const double* Rh = st.S + (long)b * 2 * ld * ld;        // top block = R D
+  const double* xg = st.x + vo;
+  const double* dg = st.d + vo;
+  const double* gh = st.g_h + vo;
+  const double* dh = st.diag_h + vo;
+  StepCtx cx{n, ld, xg, st.lb + vo, st.ub + vo, dg, red};
+  const double Delta = Delta_in[b];
+  const double alpha0 = alpha_in[b];
+  const double theta = st.theta[b];
+  int status = 0;
+
+  // ---------------- solve_lsq_trust_region (trust_region.py:56-152) --------
+  const double smax = st.srange[2 * b], smin = st.srange[2 * b + 1];
+  bool full_rank = false;
+  if (m >= n) full_rank = smin > EPS * m * smax;
+  double alpha = 0.0;
+  int n_iter = 0;
+  bool have_p = false;
+  if (full_rank) {
+    // p = -V (uf / s); rows of X are s_i v_i^T
+    for (int i = tid; i < n; i += NS_NT) coef[i] = (uf[i] / sv[i]) / sv[i];
+    __syncthreads();
+    double pn = 0.0;
+    for (int j = tid; j < n; j += NS_NT) {
+      double acc = 0.0;
+      for (int i = 0; i < n; ++i) acc = fma(X[(long)i * ld + j], coef[i], acc);
+      ph[j] = -acc;
+      pn += acc * acc;
+    }
+    pn = sqrt(block_sum(pn, red));
+    if (pn <= Delta) have_p = true;
+  }
+  if (!have_p) {
+    double s2 = 0.0;
+    for (int i = tid; i < n; i += NS_NT) { const double t = sv[i] * uf[i]; s2 += t * t; }
+    double a_hi = sqrt(block_sum(s2, red)) / Delta;
+    double a_lo = 0.0;
+    double phi = 0.0, dphi = 0.0;
+    auto secular = [&](double al) {
+      double q1 = 0.0, q2 = 0.0;
+      for (int i = tid; i < n; i += NS_NT) {
+        const double suf = sv[i] * uf[i];
+        const double den = sv[i] * sv[i] + al;
+        const double r = suf / den;
+        q1 += r * r;
+        q2 += (suf * suf) / (den * den * den);
+      }
+      q1 = block_sum(q1, red);
+      q2 = block_sum(q2, red);
+      const double pnorm = sqrt(q1);
+      phi = pnorm - Delta;
+      dphi = -q2 / pnorm;
+    };
+    if (full_rank) {
+      secular(0.0);
+      a_lo = -phi / dphi;
+    }
+    if (!full_rank && alpha0 == 0.0) {
+      const double gm = sqrt(a_lo * a_hi);
+      alpha = (0.001 * a_hi > gm) ? 0.001 * a_hi : gm;
+    } else {
+      alpha = alpha0;
+    }
+    int it = 0;
+    for (; it < 10; ++it) {
+      if (alpha < a_lo || alpha > a_hi) {
+        const double gm = sqrt(a_lo * a_hi);
+        alpha = (0.001 * a_hi > gm) ? 0.001 * a_hi : gm;
+      }
+      secular(alpha);
+      if (fabs(phi) < 0.01 * Delta) break;
+      if (phi < 0.0) a_hi = alpha;
+      const double ratio = phi / dphi;
+      const double cand = alpha - ratio;
+      a_lo = (cand > a_lo) ? cand : a_lo;       // max(alpha_lower, alpha - ratio)
+      alpha -= (phi + Delta) * ratio / Delta;
+    }
+    n_iter = (it < 10) ? it + 1 : 10;
+    for (int i = tid; i < n; i += NS_NT) coef[i] = uf[i] / (sv[i] * sv[i] + alpha);
+    __syncthreads();
+    double pn = 0.0;
+    for (int j = tid; j < n; j += NS_NT) {
+      double acc = 0.0;
+      for (int i = 0; i < n; ++i) acc = fma(X[(long)i * ld + j], coef[i], acc);
+      ph[j] = -acc;
+      pn += acc * acc;
+    }
+    pn = sqrt(block_sum(pn, red));
+    if (phi > 0.0) {
+      const double f = Delta / pn;
+      for (int j = tid; j < n; j += NS_NT) ph[j] *= f;
+    }
+  }
+  __syncthreads();
+  for (int j = tid; j < n; j += NS_NT) {
+    out.p_h_tr[vo + j] = ph[j];
+    tmp[j] = dg[j] * ph[j];                                  // p = d * p_h
+  }
+  __syncthreads();
+
+  // ---------------- feasibility of x + p (trf.py:286-292) ------------------
+  const double to_bound = step_to_bound_dev(cx, xg, tmp, tmp2);
+  for (int j = tid; j < n; j += NS_NT) {
+    const long long hit = (tmp2[j] == to_bound) ? (long long)sign_of(tmp[j]) : 0;
+    out.hits[vo + j] = hit;
+  }
+  int branch, choice = 0;
+  double qp[3] = {0.0, 0.0, 0.0};
+  const double* step_h;
+  __syncthreads();
+
+  if (to_bound >= 1.0) {
+    branch = 0;
+    const double tt = theta * to_bound;
+    const double f = (tt < 1.0) ? tt : 1.0;                  // min(theta*to_bound, 1)
+    for (int j = tid; j < n; j += NS_NT) ph[j] *= f;
+    __syncthreads();
+    tri_matvec(Rh, n, ld, ph, up);
+    const double q2 = dot_dev(up, up, n, red);
+    double dq = 0.0, lin = 0.0;
+    for (int j = tid; j < n; j += NS_NT) {
+      dq += dh[j] * (ph[j] * ph[j]);
+      lin += ph[j] * gh[j];
+    }
+    dq = block_sum(dq, red);
+    lin = block_sum(lin, red);
+    qp[0] = 0.5 * (q2 + dq) + lin;
+    step_h = ph;
+  } else {
+    branch = 1;
+    // ---- find_reflected_step (trf.py:105-156) -----------------------------
+    const double p_stride = to_bound;
+    for (int j = tid; j < n; j += NS_NT) {
+      const bool hit = (tmp2[j] == to_bound) && (tmp[j] != 0.0);
+      double rj = ph[j];
+      if (hit) rj *= -1.0;
+      rh[j] = rj;                                            // r_h
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += NS_NT) {
+      const double pj = tmp[j] * p_stride;                   // p *= p_stride
+      ph[j] = ph[j] * p_stride;                              // p_h *= p_stride
+      tmp2[j] = xg[j] + pj;                                  // x_on_bound
+      tmp[j] = dg[j] * rh[j];                                // r = d * r_h
+    }
+    __syncthreads();
+    // intersect_trust_region(p_h, r_h, Delta) (trust_region.py:11-44)
+    const double ia = dot_dev(rh, rh, n, red);
+    const double ib = dot_dev(ph, rh, n, red);
+    const double ic = dot_dev(ph, ph, n, red) - Delta * Delta;
+    double to_tr = 0.0;
+    if (ia == 0.0) status = 1;
+    else if (ic > 0.0) status = 2;
+    else {
+      const double disc = sqrt(ib * ib - ia * ic);
+      const double qq = -(ib + copysign(disc, ib));
+      const double t1 = qq / ia, t2 = ic / qq;
+      to_tr = (t1 < t2) ? t2 : t1;
+    }
+    double* steps2 = coef;
+    double to_b2 = step_to_bound_dev(cx, tmp2, tmp, steps2);
+    to_b2 *= theta;
+    const double r_hi = (to_tr < to_b2) ? to_tr : to_b2;     // min(to_bound, to_tr)
+    double r_lo;
+    if (r_hi > 0.0) r_lo = (1.0 - theta) * p_stride / r_hi;
+    else r_lo = -1.0;
+    tri_matvec(Rh, n, ld, ph, up);                           // J_h p_h (stride-scaled)
+    bool have_r = false;
+    double r_t = 0.0;
+    if (status == 0 && r_lo <= r_hi) {
+      tri_matvec(Rh, n, ld, rh, ur);
+      const double vv = dot_dev(ur, ur, n, red);
+      const double sds = dot3_dev(rh, dh, rh, n, red);
+      const double qa = 0.5 * (vv + sds);
+      double qb = dot_dev(gh, rh, n, red);
+      const double uv = dot_dev(up, ur, n, red);
+      const double s0ds = dot3_dev(ph, dh, rh, n, red);
+      qb += uv + s0ds;
+      r_t = quad_min_dev(qa, qb, r_lo, r_hi);
+      have_r = true;
+    }
+    // r_h = p_h + r_h * r_stride ;  p_h *= theta
+    for (int j = tid; j < n; j += NS_NT) {
+      const double pj = ph[j];
+      const double pt = pj * theta;
+      rh[j] = have_r ? (pj + rh[j] * r_t) : pt;
+      ph[j] = pt;
+    }
+    __syncthreads();
+    // ---- find_gradient_step (trf.py:159-170) ------------------------------
+    for (int j = tid; j < n; j += NS_NT) tmp[j] = -gh[j] * dg[j];
+    __syncthreads();
+    double to_bg = step_to_bound_dev(cx, xg, tmp, steps2);
+    to_bg *= theta;
+    const double ghn = sqrt(dot_dev(gh, gh, n, red));
+    const double to_trg = Delta / ghn;
+    double g_hi = (to_trg < to_bg) ? to_trg : to_bg;
+    for (int j = tid; j < n; j += NS_NT) tmp[j] = -gh[j];
+    __syncthreads();
+    tri_matvec(Rh, n, ld, tmp, ug);                          // J_h (-g_h)
+    const double gvv = dot_dev(ug, ug, n, red);
+    const double gsds = dot3_dev(tmp, dh, tmp, n, red);
+    const double ga = 0.5 * (gvv + gsds);
+    const double gb = dot_dev(gh, tmp, n, red);
+    const double g_t = quad_min_dev(ga, gb, 0.0, g_hi);
+    for (int j = tid; j < n; j += NS_NT) tmp[j] = -g_t * gh[j];   // c_h
+    __syncthreads();
+    // ---- evaluate_quadratic_function on [p_h, r_h, c_h] (trf.py:79-102) ----
+    // J_h p_h(final) = theta * up ;  J_h r_h = up + r_t ur ;  J_h c_h = g_t * ug
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0;
+    for (int j = tid; j < n; j += NS_NT) {
+      const double a0 = theta * up[j];
+      const double a1 = have_r ? (up[j] + r_t * ur[j]) : a0;
+      const double a2 = g_t * ug[j];
+      q0 += a0 * a0; q1 += a1 * a1; q2 += a2 * a2;
+    }
+    q0 = block_sum(q0, red); q1 = block_sum(q1, red); q2 = block_sum(q2, red);
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, l0 = 0.0, l1 = 0.0, l2 = 0.0;
+    for (int j = tid; j < n; j += NS_NT) {
+      d0 += dh[j] * (ph[j] * ph[j]);  l0 += ph[j] * gh[j];
+      d1 += dh[j] * (rh[j] * rh[j]);  l1 += rh[j] * gh[j];
+      d2 += dh[j] * (tmp[j] * tmp[j]); l2 += tmp[j] * gh[j];
+    }
+    d0 = block_sum(d0, red); d1 = block_sum(d1, red); d2 = block_sum(d2, red);
+    l0 = block_sum(l0, red); l1 = block_sum(l1, red); l2 = block_sum(l2, red);
+    qp[0] = 0.5 * (q0 + d0) + l0;
+    qp[1] = have_r ? (0.5 * (q1 + d1) + l1) : qp[0];
+    qp[2] = 0.5 * (q2 + d2) + l2;
+    choice = 0;
+    if (qp[1] < qp[choice]) choice = 1;
+    if (qp[2] < qp[choice]) choice = 2;
+    step_h = (choice == 0) ? ph : ((choice == 1) ? rh : tmp);
+  }
+
+  // ---------------- step, x_new (trf.py:301-308,318-324) -------------------
+  const double pred = -2.0 * qp[choice];
+  double sn2 = 0.0, corr = 0.0;
+  for (int j = tid; j < n; j += NS_NT) {
+    const double sh_ = step_h[j];
+    const double stp = dg[j] * sh_;
+    const double lj = cx.lb[j], uj = cx.ub[j];
+    const double xs = xg[j] + stp;
+    double xn = xs;
+    if (xs <= lj) xn = next_after(lj, uj);                   // bounds.py:91-94
+    if (xs >= uj) xn = next_after(uj, lj);                   // bounds.py:97-99
+    out.step_h[vo + j] = sh_;
+    out.step[vo + j] = stp;
+    out.x_new[vo + j] = xn;
+    sn2 += sh_ * sh_;
+    corr += (sh_ * dh[j]) * sh_;
+    // find_active_constraints(x_new, lb, ub, rtol) (bounds.py:51-76)
+    const double lower = xn - lj, upper = uj - xn;
+    long long act = 0;
+    if (lower < upper) {
+      const double thr = active_rtol * ((fabs(lj) > 1.0) ? fabs(lj) : 1.0);
+      if (lower < thr) act = -1;
+    } else {
+      const double thr = active_rtol * ((fabs(uj) > 1.0) ? fabs(uj) : 1.0);
+      if (upper < thr) act = 1;
+    }
+    out.active_new[vo + j] = act;
+  }
+  sn2 = block_sum(sn2, red);
+  corr = block_sum(corr, red);
+  if (tid == 0) {
+    double* sc = out.scal + (long)b * 8;
+    sc[0] = pred; sc[1] = sqrt(sn2); sc[2] = corr; sc[3] = alpha; sc[4] = to_bound;
+    sc[5] = qp[0]; sc[6] = qp[1]; sc[7] = qp[2];
+    int* inf = out.info + (long)b * 4;
+    inf[0] = n_iter; inf[1] = branch; inf[2] = choice; inf[3] = status;
+  }
+}
+
+hipError_t launch_trf_step(const TrfState& st, const double* Delta, const double* alpha_in,
+                           double active_rtol, const TrfStepOut& out, hipStream_t s) {
+  const size_t lds = sizeof(double) * 8 * (size_t)st.ld;
+  hipLaunchKernelGGL(trf_step_kernel, dim3(st.B), dim3(NS_NT), lds, s, st, Delta, alpha_in,
+                     active_rtol, out);
+  return hipGetLastError();
+}
+
+}  // namespace blsq

@@ -1,0 +1,158 @@
+/* blsq.h — C-ABI of the MI355X trust-region step solver (libblsq_hip.so).
+ *
+ * Drop-in boundary for ONE path of nmayorov/bounded-lsq: the per-iteration
+ * linear algebra its `trf` and `dogbox` drivers run between two fun/jac
+ * callbacks.  The reference is pure Python; what a maintainer would bind is
+ * this library through ctypes.  Each entry point cites
+ * the reference code it replaces (paths under the reference repo).
+ *
+ * Conventions
+ *   - all arrays float64, C-contiguous, batch-major: J is B x m x n exactly as
+ *     numpy hands it over, vectors are B x n (or B x m for f), masks int64;
+ *   - the caller owns every buffer passed in; outputs are caller-allocated;
+ *     the library owns device memory and the factor state inside a plan;
+ *   - return value: 0 ok; <0 invalid argument (-(index of the argument),
+ *     1-based); >0 a hipError_t.  blsq_last_error() gives the text.  Nothing
+ *     throws across the ABI.  Per-problem numerical conditions the reference
+ *     signals with ValueError (trust_region.py:28-29,34-35) are reported in
+ *     status[b] (BLSQ_STATUS_*);
+ *   - a ctx is bound to one device and one HIP stream and is NOT thread-safe;
+ *     calls taking host pointers are blocking, `_dev` calls are asynchronous
+ *     on the ctx stream (blsq_sync to wait).
+ */
+#ifndef BLSQ_H
+#define BLSQ_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct blsq_ctx blsq_ctx;
+typedef struct blsq_trf_plan blsq_trf_plan;
+typedef struct blsq_dogbox_plan blsq_dogbox_plan;
+
+enum {
+  BLSQ_STATUS_OK = 0,
+  BLSQ_STATUS_ZERO_DIRECTION = 1,  /* intersect_trust_region: "`s` is zero."  (trust_region.py:28-29) */
+  BLSQ_STATUS_OUTSIDE_TR = 2       /* "`x` is not within the trust region."  (trust_region.py:34-35) */
+};
+enum {                     /* how `scale` is treated by *_factor */
+  BLSQ_SCALE_GIVEN = 0,    /* numeric `scaling`: scale = 1/scaling, unchanged          */
+  BLSQ_SCALE_JAC_INIT = 1, /* scale = 1/||J[:,j]||, zero norm -> 1   (trf.py:216-219, dogbox.py:141-144) */
+  BLSQ_SCALE_JAC_UPDATE = 2/* scale = min(scale, 1/||J[:,j]||)        (trf.py:239-242, dogbox.py:165-168) */
+};
+
+int blsq_version(void);
+int blsq_device_count(void);
+
+int blsq_ctx_create(int device_id, blsq_ctx** out);
+int blsq_ctx_destroy(blsq_ctx* ctx);
+const char* blsq_last_error(const blsq_ctx* ctx);
+int blsq_sync(blsq_ctx* ctx);
+
+/* device memory helpers (so hosts need not bind the HIP runtime themselves) */
+int blsq_dev_malloc(blsq_ctx* ctx, size_t bytes, void** dptr);
+int blsq_dev_free(blsq_ctx* ctx, void* dptr);
+int blsq_memcpy_h2d(blsq_ctx* ctx, void* dst, const void* src, size_t bytes);
+int blsq_memcpy_d2h(blsq_ctx* ctx, void* dst, const void* src, size_t bytes);
+
+/* per-kernel device timing (HIP events on the ctx stream, for bench.py) */
+int blsq_timing_enable(blsq_ctx* ctx, int on);
+int blsq_timing_reset(blsq_ctx* ctx);
+int blsq_timing_count(const blsq_ctx* ctx);                    /* number of kernel slots */
+int blsq_timing_get(blsq_ctx* ctx, int slot, const char** name, double* total_ms,
+                    int64_t* launches);
+
+/* ------------------------------------------------------------------ TRF --
+ * blsq_trf_factor  replaces trf.py:244-277 (+ :216-219 / :239-242 for 'jac'):
+ *   g = J^T f, Coleman-Li v/d/g_h/diag_h, g_norm, theta, and the factorisation
+ *   the reference gets from svd(J_augmented) (trf.py:264-274).  Once per outer
+ *   iteration.
+ * blsq_trf_step    replaces trf.py:284-308 (+ the norm/correction terms of
+ *   :318-331 the driver needs): solve_lsq_trust_region, feasibility test,
+ *   reflected / gradient steps, model evaluation and selection, x_new.  Once
+ *   per inner iteration with a new Delta / alpha, WITHOUT refactorising.
+ */
+int blsq_trf_plan_create(blsq_ctx* ctx, int B, int m, int n, blsq_trf_plan** out);
+int blsq_trf_plan_destroy(blsq_trf_plan* plan);
+
+int blsq_trf_factor(blsq_trf_plan* plan, const double* J, const double* f, const double* x,
+                    const double* lb, const double* ub, double* scale_io, int scale_mode,
+                    double* g /*B*n*/, double* g_norm /*B*/, double* theta /*B*/);
+int blsq_trf_step(blsq_trf_plan* plan, const double* Delta /*B*/, double* alpha_io /*B*/,
+                  double active_rtol, double* step_h /*B*n*/, double* step /*B*n*/,
+                  double* x_new /*B*n*/, int64_t* hits /*B*n*/, int64_t* active_new /*B*n*/,
+                  double* predicted_reduction /*B*/, double* step_h_norm /*B*/,
+                  double* correction /*B*/, int32_t* n_iter /*B*/, int32_t* branch /*B*/,
+                  int32_t* status /*B*/);
+
+/* device-pointer variants: inputs already resident in HBM, results stay in
+ * plan-owned device buffers until fetched. */
+int blsq_trf_factor_dev(blsq_trf_plan* plan, const double* dJ, const double* df,
+                        const double* dx, const double* dlb, const double* dub,
+                        double* dscale_io, int scale_mode);
+int blsq_trf_step_dev(blsq_trf_plan* plan, const double* dDelta, const double* dalpha_in,
+                      double active_rtol);
+int blsq_trf_fetch_factor(blsq_trf_plan* plan, double* g, double* g_norm, double* theta,
+                          double* scale, double* sing /*B*n, unsorted, may be NULL*/);
+int blsq_trf_fetch_step(blsq_trf_plan* plan, double* alpha_out, double* step_h, double* step,
+                        double* x_new, int64_t* hits, int64_t* active_new,
+                        double* predicted_reduction, double* step_h_norm, double* correction,
+                        int32_t* n_iter, int32_t* branch, int32_t* status,
+                        double* p_h_tr /*may be NULL*/, double* to_bound /*may be NULL*/,
+                        int32_t* choice /*may be NULL*/);
+
+/* --------------------------------------------------------------- dogbox --
+ * blsq_dogbox_factor replaces dogbox.py:165-199: gradient, active/free split,
+ *   gtol quantity, Gauss-Newton step lstsq(J_free,-f) and the Cauchy step.
+ * blsq_dogbox_step   replaces dogbox.py:203-220 (+ :235): dogleg_step /
+ *   constrained_cauchy_step, predicted reduction (with the reference's
+ *   not-recomputed-Js quirk, :216), scatter to x_new, new on_bound.
+ */
+int blsq_dogbox_plan_create(blsq_ctx* ctx, int B, int m, int n, blsq_dogbox_plan** out);
+int blsq_dogbox_plan_destroy(blsq_dogbox_plan* plan);
+
+int blsq_dogbox_factor(blsq_dogbox_plan* plan, const double* J, const double* f,
+                       const double* x, const double* lb, const double* ub, double* scale_io,
+                       int scale_mode, const int64_t* on_bound, double* g /*B*n*/,
+                       uint8_t* active_set /*B*n*/, double* g_norm /*B*/,
+                       int32_t* all_active /*B*/);
+int blsq_dogbox_step(blsq_dogbox_plan* plan, const double* Delta /*B*/, double* step /*B*n*/,
+                     double* x_new /*B*n*/, int64_t* on_bound_new /*B*n*/, uint8_t* tr_hit /*B*/,
+                     double* predicted_reduction /*B*/, double* step_scaled_norm /*B*/,
+                     uint8_t* fallback /*B*/, int32_t* status /*B*/);
+
+int blsq_dogbox_factor_dev(blsq_dogbox_plan* plan, const double* dJ, const double* df,
+                           const double* dx, const double* dlb, const double* dub,
+                           double* dscale_io, int scale_mode, const int64_t* don_bound);
+int blsq_dogbox_step_dev(blsq_dogbox_plan* plan, const double* dDelta);
+int blsq_dogbox_fetch_factor(blsq_dogbox_plan* plan, double* g, uint8_t* active_set,
+                             double* g_norm, int32_t* all_active, double* scale,
+                             double* newton_full /*B*n, may be NULL*/,
+                             double* cauchy_full /*B*n, may be NULL*/);
+int blsq_dogbox_fetch_step(blsq_dogbox_plan* plan, double* step, double* x_new,
+                           int64_t* on_bound_new, uint8_t* tr_hit,
+                           double* predicted_reduction, double* step_scaled_norm,
+                           uint8_t* fallback, int32_t* status);
+
+/* ----------------------------------------------------------------- TSQR --
+ * Row-block partition of ONE very tall problem across ranks.
+ * Each rank factors its own row block of [J f] to an (n+1) x (n+1) triangle;
+ * the host exchanges the triangles (RCCL all-gather); every rank then merges
+ * the stack and continues with the ordinary n-space path.  `tri` buffers are
+ * dense row-major blsq_tsqr_tri_ld(n)^2 doubles.
+ */
+int blsq_tsqr_tri_ld(int n);
+int blsq_tsqr_plan_create(blsq_ctx* ctx, int m_local, int n, int nranks, blsq_trf_plan** out);
+int blsq_tsqr_local_dev(blsq_trf_plan* plan, const double* dJ_block, const double* df_block,
+                        double* dtri_out);
+int blsq_tsqr_combine_dev(blsq_trf_plan* plan, const double* dtri_stack /*nranks tris*/,
+                          const double* dx, const double* dlb, const double* dub,
+                          double* dscale_io, int scale_mode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLSQ_H */

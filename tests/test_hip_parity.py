@@ -1,0 +1,178 @@
+"""GPU parity: the HIP path, called through the C-ABI, against
+  (1) golden vectors captured from the reference (tests/golden/),
+  (2) the CPU oracle on seeded batches,
+  (3) size-independent properties at BASELINE.json's full sizes.
+Tolerances (north_star): step vector within 1e-10 relative of the reference
+CPU path; masks bit-exact."""
+import numpy as np
+import pytest
+
+from _golden import load_npz, trf_inputs, dog_inputs
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+def rel(a, b):
+    a = np.asarray(a, float); b = np.asarray(b, float)
+    den = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / (den if den > 0 else 1.0)
+
+
+@pytest.fixture(scope="module")
+def bl():
+    import bounded_lsq
+    return bounded_lsq
+
+
+TRF_CASES = load_npz("trf_small.npz") + load_npz("trf_large.npz")
+
+
+@pytest.mark.parametrize("name,ins,out", TRF_CASES, ids=[c[0] for c in TRF_CASES])
+def test_trf_golden(bl, name, ins, out):
+    P = trf_inputs(ins)
+    m, n = P["J"].shape
+    sol = bl.TrfStepSolver(1, m, n)
+    sol.factor_dev  # noqa: B018 (API exists)
+    F = sol.factor(P["J"][None], P["f"][None], P["x"][None], P["lb"][None], P["ub"][None],
+                   P["scale"][None])
+    assert rel(F.g[0], out["g"]) < 1e-12
+    assert abs(F.g_norm[0] - float(out["g_norm"])) <= 1e-12 * max(1.0, float(out["g_norm"]))
+    assert abs(F.theta[0] - float(out["theta"])) <= 1e-12
+    sol.lib.blsq_trf_step_dev  # noqa: B018
+    S = sol.step(np.array([P["Delta"]]), np.array([P["alpha0"]]))
+    D = sol.fetch_step()
+    _, sing = sol.fetch_factor(want_singular=True)
+    sref = np.asarray(out["s"], float)
+    assert rel(np.sort(sing[0])[::-1], sref) < 1e-12
+    assert int(S.n_iter[0]) == int(out["n_iter"]), "More' iteration count"
+    assert int(S.branch[0]) == int(out["branch"])
+    assert int(D.choice[0]) == int(out["choice"])
+    assert rel(D.p_h_tr[0], out["p_h_tr"]) < RTOL
+    a_ref = float(out["alpha"])
+    assert abs(S.alpha[0] - a_ref) <= 1e-9 * max(abs(a_ref), 1e-300)
+    np.testing.assert_array_equal(S.hits[0], out["hits"])           # bit-exact mask
+    assert rel(S.step_h[0], out["step_h"]) < RTOL
+    assert rel(S.step[0], out["step"]) < RTOL
+    assert rel(S.x_new[0], out["x_new"]) < RTOL
+    np.testing.assert_array_equal(S.active_new[0], out["active_new"])  # bit-exact mask
+    pr = float(out["predicted_reduction"])
+    assert abs(S.predicted_reduction[0] - pr) <= 1e-10 * abs(pr)
+    assert abs(S.step_h_norm[0] - float(out["step_h_norm"])) <= 1e-10 * float(out["step_h_norm"])
+    assert abs(S.correction[0] - float(out["correction"])) <= 1e-10 * max(
+        abs(float(out["correction"])), 1e-300)
+    # x_new must be strictly feasible (make_strictly_feasible)
+    assert np.all(S.x_new[0] > P["lb"]) and np.all(S.x_new[0] < P["ub"])
+    sol.close()
+
+
+DOG_CASES = load_npz("dog_small.npz") + load_npz("dog_large.npz")
+
+
+@pytest.mark.parametrize("name,ins,out", DOG_CASES, ids=[c[0] for c in DOG_CASES])
+def test_dogbox_golden(bl, name, ins, out):
+    P = dog_inputs(ins)
+    m, n = P["J"].shape
+    sol = bl.DogboxStepSolver(1, m, n)
+    F = sol.factor(P["J"][None], P["f"][None], P["x"][None], P["lb"][None], P["ub"][None],
+                   P["scale"][None], P["on_bound"][None])
+    assert rel(F.g[0], out["g"]) < 1e-12
+    np.testing.assert_array_equal(F.active_set[0], out["active_set"])
+    assert abs(F.g_norm[0] - float(out["g_norm"])) <= 1e-12 * max(1.0, float(out["g_norm"]))
+    _, nw, ca = sol.fetch_factor(want_steps=True)
+    assert rel(nw[0], out["newton_full"]) < RTOL
+    assert rel(ca[0], out["cauchy_full"]) < RTOL
+    S = sol.step(np.array([P["Delta"]]))
+    assert rel(S.step[0], out["step"]) < RTOL
+    assert rel(S.x_new[0], out["x_new"]) < RTOL
+    np.testing.assert_array_equal(S.on_bound_new[0], out["on_bound_new"])  # bit-exact mask
+    assert int(S.tr_hit[0]) == int(out["tr_hit"])
+    assert int(S.fallback[0]) == int(out["fallback"])
+    pr = float(out["predicted_reduction"])
+    assert abs(S.predicted_reduction[0] - pr) <= 1e-10 * abs(pr)
+    ssn = float(out["step_scaled_norm"])
+    assert abs(S.step_scaled_norm[0] - ssn) <= 1e-10 * ssn
+    sol.close()
+
+
+@pytest.mark.parametrize("B,m,n", [(16, 512, 64), (5, 200, 37), (3, 1500, 20), (2, 4096, 256)])
+def test_trf_batch_vs_oracle(bl, B, m, n):
+    from oracle import blsq_oracle as orc
+    from bounded_lsq import _synth
+    P = _synth.trf_batch(1000 + n, B, m, n)
+    Delta = np.where(np.arange(B) % 2 == 0, 10.0, 0.5)
+    sol = bl.TrfStepSolver(B, m, n)
+    sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+    S = sol.step(Delta, np.zeros(B))
+    nb = 0
+    for b in range(B):
+        _, So = orc.trf_step_solve(P["J"][b], P["f"][b], P["x"][b], P["lb"][b], P["ub"][b],
+                                   P["scale"][b], Delta[b], 0.0)
+        assert int(S.n_iter[b]) == So.n_iter and int(S.branch[b]) == So.branch
+        assert rel(S.step[b], So.step) < RTOL, (b, rel(S.step[b], So.step))
+        np.testing.assert_array_equal(S.hits[b], So.hits)
+        nb += So.branch
+    sol.close()
+
+
+@pytest.mark.parametrize("B,m,n", [(16, 512, 64), (5, 200, 37), (2, 4096, 256)])
+def test_dogbox_batch_vs_oracle(bl, B, m, n):
+    from oracle import blsq_oracle as orc
+    from bounded_lsq import _synth
+    P = _synth.dogbox_batch(2000 + n, B, m, n)
+    Delta = np.where(np.arange(B) % 2 == 0, 0.02, 0.005)
+    sol = bl.DogboxStepSolver(B, m, n)
+    sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"], P["on_bound"])
+    S = sol.step(Delta)
+    for b in range(B):
+        _, So = orc.dogbox_step_solve(P["J"][b], P["f"][b], P["x"][b], P["lb"][b], P["ub"][b],
+                                      P["scale"][b], P["on_bound"][b], Delta[b])
+        assert rel(S.step[b], So.step) < RTOL, (b, rel(S.step[b], So.step))
+        np.testing.assert_array_equal(S.on_bound_new[b], So.on_bound_new)
+        assert int(S.tr_hit[b]) == int(So.tr_hit)
+    sol.close()
+
+
+def test_jac_scaling_modes(bl):
+    """'jac' scaling (trf.py:216-219,239-242): column norms come from R."""
+    from bounded_lsq import _synth, SCALE_JAC_INIT, SCALE_JAC_UPDATE
+    B, m, n = 3, 120, 10
+    P = _synth.trf_batch(77, B, m, n)
+    P["J"][1, :, 3] = 0.0                      # zero column -> scale 1 at init
+    sol = bl.TrfStepSolver(B, m, n)
+    F = sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], np.ones((B, n)), SCALE_JAC_INIT)
+    ref = np.linalg.norm(P["J"], axis=1)
+    ref[ref == 0] = 1.0
+    np.testing.assert_allclose(F.scale, 1.0 / ref, rtol=1e-13)
+    big = np.full((B, n), 1e-3)                # min(scale, 1/norm) keeps the smaller
+    F2 = sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], big, SCALE_JAC_UPDATE)
+    with np.errstate(divide="ignore"):
+        np.testing.assert_allclose(F2.scale, np.minimum(big, 1.0 / np.linalg.norm(P["J"], axis=1)),
+                                   rtol=1e-13)
+    sol.close()
+
+
+def test_step_is_repeatable_without_refactor(bl):
+    """step() with a new Delta must not disturb the factor state (trf.py:283-285)."""
+    from bounded_lsq import _synth
+    B, m, n = 4, 300, 24
+    P = _synth.trf_batch(5, B, m, n)
+    sol = bl.TrfStepSolver(B, m, n)
+    sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+    S1 = sol.step(np.full(B, 0.7), np.zeros(B))
+    sol.step(np.full(B, 0.05), S1.alpha.copy())
+    S3 = sol.step(np.full(B, 0.7), np.zeros(B))
+    np.testing.assert_array_equal(S1.step, S3.step)
+    np.testing.assert_array_equal(S1.x_new, S3.x_new)
+    sol.close()
+
+
+def test_invalid_arguments_are_reported(bl):
+    from bounded_lsq import _abi
+    with pytest.raises(_abi.BlsqError):
+        bl.TrfStepSolver(0, 10, 2)
+    with pytest.raises(_abi.BlsqError):
+        bl.TrfStepSolver(1, 10, 2000)          # n + 1 > 1088
+    with pytest.raises(_abi.BlsqError):
+        bl.TrfStepSolver(1, 5000, 600)         # tall needs n + 1 <= 544
