@@ -111,3 +111,26 @@ def test_dogbox_tuple_matches_reference(name, ins, out):
     assert int(S.fallback) == int(out["fallback"])
     assert S.predicted_reduction == float(out["predicted_reduction"])
     assert S.step_scaled_norm == float(out["step_scaled_norm"])
+
+
+def test_rankdef_fixture_is_noise_determined():
+    """Evidence for tests/test_hip_parity.py::KNIFE_EDGE: replacing the two
+    null-space singular values of the reference's SVD (8e-16 and 0) by other
+    values of the same rounding-noise size moves the reference's own step by
+    O(1) -- so that fixture pins properties, not digits."""
+    case = [c for c in load_npz("trf_small.npz") if c[0] == "rankdef_32x8"][0]
+    P = trf_inputs(case[1])
+    F = orc.trf_factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+    assert F.s[-1] < 1e-15 and F.s[-2] < 1e-14
+    S = orc.trf_step(F, P["Delta"], P["alpha0"])
+    rng = np.random.default_rng(0)
+    worst = 0.0
+    for _ in range(5):
+        s2 = F.s.copy()
+        uf2 = F.uf.copy()
+        s2[-2:] = np.abs(rng.standard_normal(2)) * 1e-16
+        uf2[-2:] = rng.standard_normal(2)
+        S2 = orc.trf_step(F._replace(s=s2, uf=uf2), P["Delta"], P["alpha0"])
+        worst = max(worst, np.linalg.norm(S2.p_h_tr - S.p_h_tr) / np.linalg.norm(S.p_h_tr))
+        assert abs(S2.predicted_reduction - S.predicted_reduction) < 1e-3 * S.predicted_reduction
+    assert worst > 1e-2
