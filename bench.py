@@ -137,7 +137,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="problems per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="problems per GPU")
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -215,8 +215,10 @@ def main():
             worst = max(worst, float(np.linalg.norm(S.step[b] - So.step) /
                                      np.linalg.norm(So.step)))
             masks_ok = masks_ok and bool(np.array_equal(S.hits[b], So.hits))
+        sw = sol.debug_sweeps()
         parity = {"problems": min(args.check, B), "max_rel_step_err": worst,
-                  "masks_bit_exact": masks_ok}
+                  "masks_bit_exact": masks_ok,
+                  "jacobi_sweeps": [int(sw.min()), float(sw.mean()), int(sw.max())]}
 
     if rank == 0:
         timing = ctx.timing_read()

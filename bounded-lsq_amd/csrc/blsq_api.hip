@@ -501,6 +501,15 @@ extern "C" int blsq_trf_fetch_factor(blsq_trf_plan* p, double* g, double* g_norm
   return blsq_sync(ctx);
 }
 
+extern "C" int blsq_trf_debug_sweeps(blsq_trf_plan* p, int32_t* sweeps) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!sweeps) return ctx->bad(2, "sweeps is NULL");
+  HIPCHK(ctx, hipMemcpyAsync(sweeps, p->sweeps.p, sizeof(int) * p->B, hipMemcpyDeviceToHost,
+                             ctx->stream));
+  return blsq_sync(ctx);
+}
+
 extern "C" int blsq_trf_fetch_step(blsq_trf_plan* p, double* alpha_out, double* step_h,
                                    double* step, double* x_new, int64_t* hits,
                                    int64_t* active_new, double* predicted_reduction,

@@ -42,6 +42,7 @@ struct JacobiArgs {
   double* srange;         // [B][2]   max, min singular value
   int* sweeps;            // [B]
   int max_sweeps;
+  int RB;                 // rows per LDS block (set by launch_jacobi)
 };
 hipError_t launch_jacobi(const JacobiArgs& a, int B, hipStream_t st);
 

@@ -104,6 +104,9 @@ int blsq_trf_fetch_step(blsq_trf_plan* plan, double* alpha_out, double* step_h, 
                         double* p_h_tr /*may be NULL*/, double* to_bound /*may be NULL*/,
                         int32_t* choice /*may be NULL*/);
 
+/* diagnostics: Jacobi sweeps used by the last factor call, per problem */
+int blsq_trf_debug_sweeps(blsq_trf_plan* plan, int32_t* sweeps /*B*/);
+
 /* --------------------------------------------------------------- dogbox --
  * blsq_dogbox_factor replaces dogbox.py:165-199: gradient, active/free split,
  *   gtol quantity, Gauss-Newton step lstsq(J_free,-f) and the Cauchy step.
