@@ -1,0 +1,181 @@
+"""End-to-end parity of the host drivers (least_squares / trf / dogbox over the
+GPU step path) against records captured from the reference's own public
+drivers (tests/golden/e2e.json, first_iter.npz) and against the behaviours
+the reference's test-suite asserts (test_least_squares.py)."""
+import numpy as np
+import pytest
+
+from _golden import load_json, load_npz, unhex
+from _problems import ROSEN_SPECS, rosen, rosen_jac, expfit_problem, EXPFIT_X0, EXPFIT_BOX
+
+pytestmark = pytest.mark.gpu
+
+E2E = load_json("e2e.json")
+TOL = float.fromhex(E2E["tol"])
+
+
+def _problem(tag):
+    if tag.startswith("rosen"):
+        return rosen, rosen_jac
+    return expfit_problem(E2E["expfit_seed"])
+
+
+@pytest.mark.parametrize("rec", E2E["records"],
+                         ids=["%s-%s-%s" % (r["tag"], r["method"], r["scaling"])
+                              for r in E2E["records"]])
+def test_end_to_end_records(rec):
+    import bounded_lsq
+    fun, jac = _problem(rec["tag"])
+    scaling = rec["scaling"] if isinstance(rec["scaling"], str) else np.array(rec["scaling"])
+    if not isinstance(scaling, str) and scaling.size == 1:
+        scaling = float(scaling[0])
+    res = bounded_lsq.least_squares(fun, unhex(rec["x0"]), jac=jac,
+                                    bounds=(unhex(rec["lb"]), unhex(rec["ub"])),
+                                    method=rec["method"], ftol=TOL, xtol=TOL, gtol=TOL,
+                                    scaling=scaling)
+    assert res.nfev == rec["nfev"] and res.njev == rec["njev"]
+    assert res.status == rec["status"]
+    np.testing.assert_allclose(res.x, unhex(rec["x"]), rtol=1e-8, atol=1e-12)
+    np.testing.assert_allclose(res.obj_value, float.fromhex(rec["obj_value"]), rtol=1e-8,
+                               atol=1e-14)
+    np.testing.assert_array_equal(res.active_mask, rec["active_mask"])   # bit-exact mask
+    assert res.success == (rec["status"] > 0) and isinstance(res.message, str)
+
+
+FIRST = load_npz("first_iter.npz")
+
+
+@pytest.mark.parametrize("name,ins,out", FIRST, ids=[c[0] for c in FIRST])
+def test_first_inner_iteration_matches_reference_driver(name, ins, out):
+    """x passed to the 2nd fun() call == x_new of the reference's inline block."""
+    import bounded_lsq
+    from bounded_lsq import _synth
+    P = _synth.trf_problem(int(ins["seed"]), int(ins["m"]), int(ins["n"]))
+    calls = []
+
+    class Stop(Exception):
+        pass
+
+    def fun(x):
+        calls.append(x.copy())
+        if len(calls) == 2:
+            raise Stop
+        return P["f"].copy()
+
+    def jac(x, f):
+        return P["J"].copy()
+    drv = bounded_lsq.trf if name.startswith("trf") else bounded_lsq.dogbox
+    with pytest.raises(Stop):
+        drv(fun, jac, P["x"].copy(), P["lb"], P["ub"], 1e-8, 1e-8, 1e-8, None,
+            np.ones(P["x"].size))
+    np.testing.assert_array_equal(calls[0], out["x_first"])
+    dx_ref = out["x_new"] - out["x_first"]
+    dx = calls[1] - calls[0]
+    assert np.linalg.norm(dx - dx_ref) <= 1e-10 * np.linalg.norm(dx_ref)
+
+
+# ---- behaviours the reference's own tests assert (test_least_squares.py) ----
+def fun_trivial(x, a=0):
+    return (x - a) ** 2 + 5.0
+
+
+def jac_trivial(x, a=0.0):
+    return 2 * (x - a)
+
+
+def fun_rosenbrock(x):
+    return np.array([10 * (x[1] - x[0] ** 2), (1 - x[0])])
+
+
+def jac_rosenbrock(x):
+    return np.array([[-20 * x[0], 10], [-1, 0]])
+
+
+@pytest.mark.parametrize("method", ["trf", "dogbox"])
+def test_basic_and_jac_options(method):                    # :59-63, :90-95
+    from bounded_lsq import least_squares
+    for jac in ['2-point', '3-point', jac_trivial]:
+        res = least_squares(fun_trivial, 2.0, jac, method=method)
+        np.testing.assert_allclose(res.x, 0, atol=1e-4)
+        np.testing.assert_allclose(res.obj_value, 25)
+
+
+@pytest.mark.parametrize("method", ["trf", "dogbox"])
+def test_full_result(method):                              # :141-160
+    from bounded_lsq import least_squares
+    res = least_squares(fun_trivial, 2.0, method=method)
+    assert res.x.shape == (1,) and res.fun.shape == (1,) and res.jac.shape == (1, 1)
+    np.testing.assert_allclose(res.x, 0, atol=1e-4)
+    np.testing.assert_allclose(res.obj_value, 25)
+    np.testing.assert_allclose(res.fun, 5)
+    np.testing.assert_allclose(res.jac, 0, atol=1e-4)
+    np.testing.assert_allclose(res.optimality, 0, atol=1e-3)
+    np.testing.assert_array_equal(res.active_mask, 0)
+    assert res.nfev < 10 and res.njev < 10 and res.status > 0 and res.success
+
+
+@pytest.mark.parametrize("method", ["trf", "dogbox"])
+def test_args_kwargs_and_nfev(method):                     # :97-101, :112-126
+    from bounded_lsq import least_squares
+    a = 3.0
+    res = least_squares(fun_trivial, 2.0, jac_trivial, args=(a,), method=method)
+    np.testing.assert_allclose(res.x, a, rtol=1e-4)
+    res = least_squares(fun_trivial, 2.0, jac_trivial, kwargs={'a': a}, method=method)
+    np.testing.assert_allclose(res.x, a, rtol=1e-4)
+    with pytest.raises(TypeError):
+        least_squares(fun_trivial, 2.0, args=(3, 4), method=method)
+    with pytest.raises(TypeError):
+        least_squares(fun_trivial, 2.0, kwargs={'kaboom': 3}, method=method)
+    with pytest.raises(TypeError):                         # unknown option (:128-132)
+        least_squares(fun_trivial, 2.0, method=method, options={'no_such_option': 100})
+    res = least_squares(fun_trivial, 2.0, max_nfev=1, method=method)
+    assert res.nfev == 1 and res.status == 0
+
+
+@pytest.mark.parametrize("method", ["trf", "dogbox"])
+def test_rosenbrock(method):                               # :162-169
+    from bounded_lsq import least_squares
+    x0 = [-2, 1]
+    for scaling in [1.0, np.array([1.0, 5.0]), 'jac']:
+        for jac in ['2-point', '3-point', jac_rosenbrock]:
+            res = least_squares(fun_rosenbrock, x0, jac, scaling=scaling, method=method)
+            np.testing.assert_allclose(res.x, [1, 1], rtol=1e-7)
+
+
+@pytest.mark.parametrize("method", ["trf", "dogbox"])
+def test_in_bounds_and_shapes(method):                     # :222-249
+    from bounded_lsq import least_squares
+    for jac in ['2-point', '3-point', jac_trivial]:
+        res = least_squares(fun_trivial, 2.0, jac=jac, bounds=(-1.0, 3.0), method=method)
+        np.testing.assert_allclose(res.x, 0.0, atol=1e-4)
+        np.testing.assert_array_equal(res.active_mask, [0])
+        res = least_squares(fun_trivial, 2.0, jac=jac, bounds=(0.5, 3.0), method=method)
+        np.testing.assert_allclose(res.x, 0.5, atol=1e-4)
+        np.testing.assert_array_equal(res.active_mask, [-1])
+        assert 0.5 <= res.x <= 3
+
+    for bounds, expect in [((0.5, [2.0, 2.0]), [0.5, 0.5]), (([0.3, 0.2], 3.0), [0.3, 0.2]),
+                           (([-1, 0.5], [1.0, 3.0]), [0.0, 0.5])]:
+        res = least_squares(lambda x: np.asarray(x), [1.0, 1.0], bounds=bounds, method=method)
+        np.testing.assert_allclose(res.x, expect, atol=1e-5)
+
+
+@pytest.mark.parametrize("method", ["trf", "dogbox"])
+def test_rosenbrock_bounds(method):                        # :251-270
+    from bounded_lsq import least_squares
+    for x0, lb, ub in ROSEN_SPECS:
+        for scaling in [1.0, [1.0, 2.0], 'jac']:
+            for jac in ['2-point', '3-point', jac_rosenbrock]:
+                res = least_squares(fun_rosenbrock, x0, jac, (lb, ub), scaling=scaling,
+                                    method=method)
+                np.testing.assert_allclose(res.optimality, 0.0, atol=1e-5)
+
+
+def test_fun_and_jac_shape_errors():                       # :171-199
+    from bounded_lsq import least_squares
+    with pytest.raises(RuntimeError):
+        least_squares(lambda x: np.ones((2, 2)), 2.0)
+    with pytest.raises(RuntimeError):
+        least_squares(fun_trivial, 2.0, jac=lambda x: np.ones((1, 1, 1)))
+    with pytest.raises(RuntimeError):                       # m mismatch (trf.py:209-211)
+        least_squares(lambda x: np.ones(3), [2.0, 1.0], jac=lambda x: np.ones((2, 2)))
