@@ -192,3 +192,38 @@ def test_invalid_arguments_are_reported(bl):
         bl.TrfStepSolver(1, 10, 2000)          # n + 1 > 1088
     with pytest.raises(_abi.BlsqError):
         bl.TrfStepSolver(1, 5000, 600)         # tall needs n + 1 <= 544
+
+
+@pytest.mark.parametrize("m,n,nranks", [(6000, 40, 4), (3000, 128, 3), (20000, 16, 8)])
+def test_tsqr_row_blocks_single_gpu(bl, m, n, nranks):
+    """Row-block TSQR rehearsed on ONE GPU: every 'rank' factors
+    its row block, the triangles are stacked in rank order (what the RCCL
+    all-gather produces) and merged; the step must match the oracle on the
+    full problem."""
+    from oracle import blsq_oracle as orc
+    from bounded_lsq import _synth, _abi
+    from bounded_lsq._multi import TsqrTrfSolver, row_block, tri_ld
+    P = _synth.trf_problem(4242 + n, m, n)
+    ctx = bl._hip_step.default_context()
+    ld = tri_ld(n)
+    dstack = ctx.malloc(8 * nranks * ld * ld)
+    dvec = {k: ctx.to_device(P[k]) for k in ("x", "lb", "ub", "scale")}
+    sols = []
+    for r in range(nranks):
+        lo, hi = row_block(m, nranks, r)
+        sol = TsqrTrfSolver(hi - lo, n, nranks, r, ctx=ctx)
+        dJ = ctx.to_device(P["J"][lo:hi]); df = ctx.to_device(P["f"][lo:hi])
+        sol.local_triangle_dev(dJ, df, _abi.vp(dstack.value + 8 * r * ld * ld))
+        ctx.sync()
+        ctx.free(dJ); ctx.free(df)
+        sols.append(sol)
+    Delta = 0.7
+    _, So = orc.trf_step_solve(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"], Delta, 0.0)
+    for sol in sols[:2]:                        # every rank gets the same answer
+        sol.combine_dev(dstack, dvec["x"], dvec["lb"], dvec["ub"], dvec["scale"])
+        S = sol.step(np.array([Delta]), np.array([0.0]))
+        assert rel(S.step[0], So.step) < RTOL
+        np.testing.assert_array_equal(S.hits[0], So.hits)
+        assert int(S.n_iter[0]) == So.n_iter
+    for sol in sols:
+        sol.close()
