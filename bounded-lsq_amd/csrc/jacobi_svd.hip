@@ -12,28 +12,34 @@
 // accumulated; the rotations are computed from the first n entries of the two
 // rows and applied to all n+1.
 //
-// Layout / schedule (one workgroup of 512 threads per problem):
+// Layout / schedule (one workgroup of 256 threads per problem):
 //   * rows are staged through LDS in pairs of row blocks (2*RB rows x (n+1)
 //     doubles <= ~150 KB; RB = 32 for n <= 256): block A stays resident while
 //     its partners B = A+1.. are streamed through the second half (the next
 //     partner is prefetched into registers while the current pair is rotated);
-//     inside a block pair RB independent row pairs per inner round (cross
-//     pairs A_i x B_(i+r); each block's intra pairs once per sweep), so every
-//     row pair is visited exactly once per sweep;
-//   * a row pair is processed by 16 lanes (4 pairs per wave, 32 per workgroup):
-//     the dot product is reduced with a 4-step DPP xor-butterfly inside the
+//   * work unit = a 2x2 ROW TILE PAIR owned by 16 lanes (a DPP row): two rows
+//     of A and two rows of B live in REGISTERS (17 doubles per lane per row at
+//     n = 256) and receive their 4 cross rotations there, so LDS sees one
+//     load/store of a B tile per 4 rotations, and the A tile is loaded/stored
+//     once per block pair (LDS write bandwidth was the limiter of the
+//     one-pair-per-visit version).  16 tile slots per workgroup; B tiles rotate
+//     over the slots round-robin, so every row pair is visited once per sweep;
+//   * the dot product is reduced with a 4-step DPP xor-butterfly inside the
 //     16-lane row (bit-identical in all 16 lanes, no LDS crossbar);
-//   * squared row norms are cached in LDS and updated by  a -= t g, b += t g
-//     (refreshed from the data at every block load), so a pair costs ONE dot
-//     product; tan/cos/sin come from v_rcp_f64 / v_rsq_f64 + Newton steps —
-//     any t is a valid rotation, only cos^2+sin^2 = 1 needs full precision.
+//   * squared row norms are cached (registers / LDS) and updated by
+//     a -= t g, b += t g (refreshed from the data at every block load), so a
+//     pair costs ONE dot product; tan/cos/sin come from v_rcp_f64 / v_rsq_f64
+//     + Newton steps — any t is a valid rotation, only cos^2+sin^2 = 1 needs
+//     full precision.
 #include "blsq_device.h"
 #include "blsq_kernels.h"
 
 namespace blsq {
 
 static constexpr int JAC_NT = 512;
-static constexpr int JAC_SLOTS = JAC_NT / 16;     // 32 concurrent row pairs
+static constexpr int JAC_LPR = 32;                // lanes per row
+static constexpr int JAC_SLOTS = JAC_NT / JAC_LPR; // 16 concurrent tile slots
+static constexpr int JAC_NW = JAC_NT / 64;
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
@@ -51,6 +57,15 @@ __device__ __forceinline__ double row16_sum(double v) {
   return v;
 }
 
+// sum over the 32 lanes {0-31} / {32-63}: 16-lane butterfly + one xor-16 swizzle
+__device__ __forceinline__ double row32_sum(double v) {
+  v = row16_sum(v);
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F);   // bit mode: lane ^ 16
+  hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
+  return v + __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double fast_rcp(double d) {
   double r = __builtin_amdgcn_rcp(d);
   r = fma(r, fma(-d, r, 1.0), r);
@@ -64,49 +79,70 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
   return y;
 }
 
-// Rotate LDS rows p, q (stride ldx) if they are not yet orthogonal.
-// Executed by all 16 lanes of a DPP row with identical (p, q, valid).
-// EPL = elements per lane (N <= 16*EPL): both rows are held in registers, so
-// all 2*EPL LDS reads are in flight together and the rotation re-reads nothing.
+// One FAST (self-scaled) rotation between two rows held in registers.
+// The true rows are  U = du*u,  V = dv*v  (idu = 1/du, idv = 1/dv); a, b are the
+// TRUE squared norms.  With t = tan(theta):  U' = cs (U - t V),  V' = cs (V + t U)
+//   <=>  u' = u - (t dv/du) v,  v' = v + (t du/dv) u,  du' = cs du,  dv' = cs dv
+// i.e. 2 FMAs per element pair instead of 4 (the scale is applied once, when the
+// row leaves the chip).  tan comes from an f32 evaluation (any tan is a valid
+// rotation; it only has to annihilate the pair to ~1e-7, quadratic convergence
+// does the rest), cos = rsqrt(1 + tan^2) in full f64 so norms are preserved.
+// Executed by the 32 lanes of a row group; lane l holds elements l + 32k.
 template <int EPL>
-__device__ __forceinline__ int rotate_pair(double* Xs, double* sq, int ldx, int n, int N, int p,
-                                           int q, bool valid, double tol2, int l16) {
-  double* xp = Xs + p * ldx;
-  double* xq = Xs + q * ldx;
-  double a = 0.0, b = 0.0;
-  if (valid) { a = sq[p]; b = sq[q]; }
-  const bool act = valid && a > 0.0 && b > 0.0;
-  double u[EPL], v[EPL];
+__device__ __forceinline__ int rot_regs(double (&u)[EPL], double (&v)[EPL], double& a, double& b,
+                                        double& du, double& idu, double& dv, double& idv, int n,
+                                        double tol2, int l) {
+  double g0 = 0.0, g1 = 0.0;
 #pragma unroll
   for (int k = 0; k < EPL; ++k) {
-    const int e = l16 + 16 * k;
-    const bool ok = act && e < N;
-    u[k] = ok ? xp[e] : 0.0;
-    v[k] = ok ? xq[e] : 0.0;
-  }
-  double g = 0.0;
-#pragma unroll
-  for (int k = 0; k < EPL; ++k)
-    if (l16 + 16 * k < n) g = fma(u[k], v[k], g);
-  g = row16_sum(g);
-  if (!(act && g * g > tol2 * a * b)) return 0;
-  // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)),  zeta = (b - a) / (2 g)
-  const double h = b - a, ag = 2.0 * g;
-  const double den = fabs(h) + sqrt(fma(h, h, ag * ag));
-  double t = fabs(ag) * fast_rcp(den);
-  if ((h < 0.0) != (ag < 0.0)) t = -t;
-  const double cs = fast_rsqrt(fma(t, t, 1.0));
-  const double sn = cs * t;
-#pragma unroll
-  for (int k = 0; k < EPL; ++k) {
-    const int e = l16 + 16 * k;
-    if (e < N) {
-      xp[e] = cs * u[k] - sn * v[k];
-      xq[e] = sn * u[k] + cs * v[k];
+    if (l + JAC_LPR * k < n) {
+      if (k & 1) g1 = fma(u[k], v[k], g1); else g0 = fma(u[k], v[k], g0);
     }
   }
-  if (l16 == 0) { sq[p] = a - t * g; sq[q] = b + t * g; }
+  const double g = row32_sum(g0 + g1) * (du * dv);
+  if (!(a > 0.0 && b > 0.0 && g * g > tol2 * a * b)) return 0;
+  // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)),  zeta = (b - a) / (2 g)
+  const double h = b - a, ag = 2.0 * g;
+  const double big = fmax(fabs(h), fabs(ag));
+  const int ex = __builtin_amdgcn_frexp_exp(big);          // scale into f32 range
+  const float hf = (float)__builtin_amdgcn_ldexp(h, -ex);
+  const float gf = (float)__builtin_amdgcn_ldexp(ag, -ex);
+  const float rf = __builtin_amdgcn_sqrtf(fmaf(hf, hf, gf * gf));
+  float tf = fabsf(gf) * __builtin_amdgcn_rcpf(fabsf(hf) + rf);
+  if ((h < 0.0) != (ag < 0.0)) tf = -tf;
+  const double t = (double)tf;
+  const double w = fma(t, t, 1.0);
+  const double cs = fast_rsqrt(w);
+  const double ics = w * cs;                               // 1 / cs
+  const double t1 = t * dv * idu, t2 = t * du * idv;
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) {
+    const double uu = u[k];
+    u[k] = fma(-t1, v[k], uu);
+    v[k] = fma(t2, uu, v[k]);
+  }
+  du *= cs; dv *= cs; idu *= ics; idv *= ics;
+  a -= t * g;
+  b += t * g;
   return 1;
+}
+
+template <int EPL>
+__device__ __forceinline__ void row_load(double (&u)[EPL], const double* row, int N, int l) {
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) {
+    const int e = l + JAC_LPR * k;
+    const double val = row[(e < N) ? e : 0];         // unconditional load, select after
+    u[k] = (e < N) ? val : 0.0;
+  }
+}
+template <int EPL>
+__device__ __forceinline__ void row_store(const double (&u)[EPL], double* row, int N, int l) {
+#pragma unroll
+  for (int k = 0; k < EPL; ++k) {
+    const int e = l + JAC_LPR * k;
+    if (e < N) row[e] = u[k];
+  }
 }
 
 // round-robin (chess tournament) pairing of `np` (even) players, round r,
@@ -124,7 +160,7 @@ __device__ __forceinline__ void rr_pair(int np, int r, int i, int& p, int& q) {
 // while the previous block pair is being rotated).
 template <int EPL>
 struct BlockRegs {
-  static constexpr int CH = (16 * EPL + 63) / 64;
+  static constexpr int CH = (JAC_LPR * EPL + 63) / 64;
   double t[4][CH];
 };
 
@@ -133,7 +169,7 @@ __device__ __forceinline__ void block_fetch(BlockRegs<EPL>& R, const double* X, 
                                             int N, int g0, int RB, int w, int lane) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int r = w + 8 * j;
+    const int r = w + JAC_NW * j;
     const int gr = g0 + r;
     const bool rok = (r < RB) && (gr < n);
     const double* src = X + (long)(rok ? gr : 0) * ld;   // clamped: loads are unconditional
@@ -150,7 +186,7 @@ __device__ __forceinline__ void block_commit(const BlockRegs<EPL>& R, double* Xs
                                              int s0, int RB, int w, int lane) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int r = w + 8 * j;
+    const int r = w + JAC_NW * j;
     if (r < RB) {
       double* dst = Xs + (s0 + r) * ldx;
 #pragma unroll
@@ -163,22 +199,23 @@ __device__ __forceinline__ void block_commit(const BlockRegs<EPL>& R, double* Xs
 }
 template <int EPL>
 __device__ __forceinline__ void block_store(double* X, int ld, int n, int N, int g0,
-                                            const double* Xs, int ldx, int s0, int RB, int w,
-                                            int lane) {
+                                            const double* Xs, const double* dsc, int ldx, int s0,
+                                            int RB, int w, int lane) {
   double t[4][BlockRegs<EPL>::CH];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int r = w + 8 * j;
+    const int r = w + JAC_NW * j;
     const double* src = Xs + (s0 + (r < RB ? r : 0)) * ldx;
+    const double sc = dsc[s0 + (r < RB ? r : 0)];          // fold the fast-rotation scale in
 #pragma unroll
     for (int c = 0; c < BlockRegs<EPL>::CH; ++c) {
       const int e = lane + 64 * c;
-      t[j][c] = src[(e < N) ? e : 0];
+      t[j][c] = src[(e < N) ? e : 0] * sc;
     }
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int r = w + 8 * j;
+    const int r = w + JAC_NW * j;
     const int gr = g0 + r;
     if (r < RB && gr < n) {
       double* dst = X + (long)gr * ld;
@@ -190,22 +227,26 @@ __device__ __forceinline__ void block_store(double* X, int ld, int n, int N, int
     }
   }
 }
-// squared norms (first n entries) of LDS rows [s0, s0+cnt): one row per 16 lanes
+// squared norms (first n entries) of LDS rows [s0, s0+cnt), one row per 32 lanes;
+// also resets the fast-rotation scales of those rows to 1
 template <int EPL>
-__device__ __forceinline__ void block_norms(const double* Xs, double* sq, int ldx, int n, int s0,
-                                            int cnt, int slot, int l16) {
+__device__ __forceinline__ void block_norms(double* Xs, double* sq, double* dsc, double* idsc,
+                                            int ldx, int n, int N, int s0, int cnt, int slot,
+                                            int l, bool apply) {
   for (int r0 = 0; r0 < cnt; r0 += JAC_SLOTS) {
     const int r = r0 + slot;
-    const double* src = Xs + (s0 + (r < cnt ? r : 0)) * ldx;
+    double* src = Xs + (s0 + (r < cnt ? r : 0)) * ldx;
+    const double sc = apply ? dsc[s0 + (r < cnt ? r : 0)] : 1.0;
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
-      const int e = l16 + 16 * k;
-      const double v = src[(e < n) ? e : 0];
+      const int e = l + JAC_LPR * k;
+      const double v = src[(e < N) ? e : 0] * sc;
+      if (apply && r < cnt && e < N) src[e] = v;       // fold the scale into the data
       if (e < n) acc = fma(v, v, acc);
     }
-    acc = row16_sum(acc);
-    if (r < cnt && l16 == 0) sq[s0 + r] = acc;
+    acc = row32_sum(acc);
+    if (r < cnt && l == 0) { sq[s0 + r] = acc; dsc[s0 + r] = 1.0; idsc[s0 + r] = 1.0; }
   }
 }
 
@@ -215,7 +256,7 @@ __global__ __launch_bounds__(JAC_NT) void jacobi_rows_kernel(JacobiArgs a) {
   __shared__ double red[32];
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int slot = tid >> 4, l16 = tid & 15;
+  const int slot = tid / JAC_LPR, l = tid % JAC_LPR;
   const int N = a.ncols_dev ? a.ncols_dev[b] : a.N;
   const int n = N - 1;
   double* X = a.X + (long)b * a.strideX;
@@ -227,25 +268,127 @@ __global__ __launch_bounds__(JAC_NT) void jacobi_rows_kernel(JacobiArgs a) {
   const int RB = a.RB;                       // rows per block (even, <= 32)
   const int ldx = N;                         // LDS row stride
   double* Xs = lds;                          // [2*RB][ldx]: slots [0,RB) = A, [RB,2RB) = B
-  double* sq = Xs + 2 * RB * ldx;            // [2*RB]
+  double* sq = Xs + 2 * RB * ldx;            // [2*RB] true squared norms
+  double* dsc = sq + 2 * RB;                 // [2*RB] fast-rotation scale of each LDS row
+  double* idsc = dsc + 2 * RB;               // [2*RB] its inverse
   const double tol = sqrt((double)n) * 2.220446049250313e-16;
   const double tol2 = tol * tol;
   const int nb = (n + RB - 1) / RB;          // row blocks (last may be partial: zero rows)
-  const int half = RB / 2;
+  const int NT2 = RB / 2;                    // 2-row tiles per block (<= 16 = JAC_SLOTS)
   BlockRegs<EPL> pre;
 
-  // intra-block round-robin; blocks in LDS at offsets offA (slots < half) and offB
+  struct RowSt { double a, d, id; };
+  auto st_load = [&](int row, bool valid) -> RowSt {
+    RowSt r;
+    r.a = valid ? sq[row] : 0.0;
+    r.d = valid ? dsc[row] : 1.0;
+    r.id = valid ? idsc[row] : 1.0;
+    return r;
+  };
+  auto st_store = [&](int row, const RowSt& r) { sq[row] = r.a; dsc[row] = r.d; idsc[row] = r.id; };
+
+  // all pairs between the two 2-row tiles at LDS rows (ta, ta+1) and (tb, tb+1);
+  // `within` adds the pair inside each tile (done once per sweep per tile).
+  auto tile_pair = [&](int ta, int tb, bool valid, bool within) -> int {
+    double u0[EPL], u1[EPL], v0[EPL], v1[EPL];
+    const int ra = valid ? ta : 0, rb = valid ? tb : 0;
+    row_load<EPL>(u0, Xs + ra * ldx, N, l);
+    row_load<EPL>(u1, Xs + (ra + 1) * ldx, N, l);
+    row_load<EPL>(v0, Xs + rb * ldx, N, l);
+    row_load<EPL>(v1, Xs + (rb + 1) * ldx, N, l);
+    RowSt A0 = st_load(ra, valid), A1 = st_load(ra + 1, valid);
+    RowSt B0 = st_load(rb, valid), B1 = st_load(rb + 1, valid);
+    int rot = 0;
+    if (within) {
+      rot |= rot_regs<EPL>(u0, u1, A0.a, A1.a, A0.d, A0.id, A1.d, A1.id, n, tol2, l);
+      rot |= rot_regs<EPL>(v0, v1, B0.a, B1.a, B0.d, B0.id, B1.d, B1.id, n, tol2, l);
+    }
+    rot |= rot_regs<EPL>(u0, v0, A0.a, B0.a, A0.d, A0.id, B0.d, B0.id, n, tol2, l);
+    rot |= rot_regs<EPL>(u1, v1, A1.a, B1.a, A1.d, A1.id, B1.d, B1.id, n, tol2, l);
+    rot |= rot_regs<EPL>(u0, v1, A0.a, B1.a, A0.d, A0.id, B1.d, B1.id, n, tol2, l);
+    rot |= rot_regs<EPL>(u1, v0, A1.a, B0.a, A1.d, A1.id, B0.d, B0.id, n, tol2, l);
+    if (valid && rot) {
+      row_store<EPL>(u0, Xs + ra * ldx, N, l);
+      row_store<EPL>(u1, Xs + (ra + 1) * ldx, N, l);
+      row_store<EPL>(v0, Xs + rb * ldx, N, l);
+      row_store<EPL>(v1, Xs + (rb + 1) * ldx, N, l);
+      if (l == 0) { st_store(ra, A0); st_store(ra + 1, A1); st_store(rb, B0); st_store(rb + 1, B1); }
+    }
+    return rot;
+  };
+
+  // intra-block sweep of the blocks at LDS row offsets 0 (A) and RB (B):
+  // round-robin over the NT2 tiles of each block; the first half of the slots
+  // serves A, the second half B.  Round 0 also rotates the pair inside every tile.
   auto intra = [&](bool doA, bool doB) -> int {
     int rot = 0;
-    for (int r = 0; r < RB - 1; ++r) {
-      const bool inA = slot < half;
-      const bool valid = (slot < RB) && (inA ? doA : doB);
+    if (NT2 < 2) {                           // RB == 2: a block is a single tile
+      const bool valid = (slot == 0 && doA) || (slot == 1 && doB);
+      double u0[EPL], u1[EPL];
+      const int r0 = (slot == 1) ? RB : 0;
+      row_load<EPL>(u0, Xs + r0 * ldx, N, l);
+      row_load<EPL>(u1, Xs + (r0 + 1) * ldx, N, l);
+      RowSt A0 = st_load(r0, valid), A1 = st_load(r0 + 1, valid);
+      rot = rot_regs<EPL>(u0, u1, A0.a, A1.a, A0.d, A0.id, A1.d, A1.id, n, tol2, l);
+      if (valid && rot) {
+        row_store<EPL>(u0, Xs + r0 * ldx, N, l);
+        row_store<EPL>(u1, Xs + (r0 + 1) * ldx, N, l);
+        if (l == 0) { st_store(r0, A0); st_store(r0 + 1, A1); }
+      }
+      __syncthreads();
+      return rot;
+    }
+    const int np2 = NT2 + (NT2 & 1);         // even number of players
+    for (int r = 0; r < np2 - 1; ++r) {
+      const bool inA = slot < np2 / 2;
+      const int li = inA ? slot : slot - np2 / 2;
+      bool valid = (li < np2 / 2) && (slot < np2) && (inA ? doA : doB);
       int p = 0, q = 0;
-      if (valid) { rr_pair(RB, r, inA ? slot : slot - half, p, q); if (!inA) { p += RB; q += RB; } }
-      rot |= rotate_pair<EPL>(Xs, sq, ldx, n, N, p, q, valid, tol2, l16);
+      rr_pair(np2, r, li < np2 / 2 ? li : 0, p, q);
+      if (p >= NT2 || q >= NT2) valid = false;     // dummy tile (odd NT2)
+      const int off = inA ? 0 : RB;
+      rot |= tile_pair(off + 2 * p, off + 2 * q, valid, r == 0);
       __syncthreads();
     }
     return rot;
+  };
+
+  // cross phase between the block at rows [0,RB) and the block at [RB,2RB):
+  // slot s keeps A tile s in registers; B tile (s + r) mod NT2 visits it in round r.
+  auto cross = [&]() -> int {
+    const bool valid = slot < NT2;
+    const int ra = valid ? 2 * slot : 0;
+    double u0[EPL], u1[EPL];
+    row_load<EPL>(u0, Xs + ra * ldx, N, l);
+    row_load<EPL>(u1, Xs + (ra + 1) * ldx, N, l);
+    RowSt A0 = st_load(ra, valid), A1 = st_load(ra + 1, valid);
+    int rotA = 0;
+    for (int r = 0; r < NT2; ++r) {
+      const int rb = valid ? RB + 2 * ((slot + r) % NT2) : RB;
+      double v0[EPL], v1[EPL];
+      row_load<EPL>(v0, Xs + rb * ldx, N, l);
+      row_load<EPL>(v1, Xs + (rb + 1) * ldx, N, l);
+      RowSt B0 = st_load(rb, valid), B1 = st_load(rb + 1, valid);
+      int rr = 0;
+      rr |= rot_regs<EPL>(u0, v0, A0.a, B0.a, A0.d, A0.id, B0.d, B0.id, n, tol2, l);
+      rr |= rot_regs<EPL>(u1, v1, A1.a, B1.a, A1.d, A1.id, B1.d, B1.id, n, tol2, l);
+      rr |= rot_regs<EPL>(u0, v1, A0.a, B1.a, A0.d, A0.id, B1.d, B1.id, n, tol2, l);
+      rr |= rot_regs<EPL>(u1, v0, A1.a, B0.a, A1.d, A1.id, B0.d, B0.id, n, tol2, l);
+      if (valid && rr) {
+        row_store<EPL>(v0, Xs + rb * ldx, N, l);
+        row_store<EPL>(v1, Xs + (rb + 1) * ldx, N, l);
+        if (l == 0) { st_store(rb, B0); st_store(rb + 1, B1); }
+      }
+      rotA |= rr;
+      __syncthreads();
+    }
+    if (valid && rotA) {
+      row_store<EPL>(u0, Xs + ra * ldx, N, l);
+      row_store<EPL>(u1, Xs + (ra + 1) * ldx, N, l);
+      if (l == 0) { st_store(ra, A0); st_store(ra + 1, A1); }
+    }
+    __syncthreads();
+    return rotA;
   };
 
   int sweep = 0;
@@ -257,22 +400,16 @@ __global__ __launch_bounds__(JAC_NT) void jacobi_rows_kernel(JacobiArgs a) {
     block_commit<EPL>(pre, Xs, ldx, N, RB, RB, w, lane);
     __syncthreads();
     for (; sweep < a.max_sweeps;) {
-      block_norms<EPL>(Xs, sq, ldx, n, 0, 2 * RB, slot, l16);
+      // (re)compute the true norms; from the 2nd sweep on first fold the scales in
+      block_norms<EPL>(Xs, sq, dsc, idsc, ldx, n, N, 0, 2 * RB, slot, l, sweep > 0);
       __syncthreads();
       int rotated = intra(true, nb == 2);
-      if (nb == 2) {
-        for (int r = 0; r < RB; ++r) {
-          const bool valid = slot < RB;
-          rotated |= rotate_pair<EPL>(Xs, sq, ldx, n, N, valid ? slot : 0,
-                                      valid ? RB + ((slot + r) % RB) : 0, valid, tol2, l16);
-          __syncthreads();
-        }
-      }
+      if (nb == 2) rotated |= cross();
       ++sweep;
       if (!block_or(rotated, red)) break;
     }
-    block_store<EPL>(X, ld, n, N, 0, Xs, ldx, 0, RB, w, lane);
-    block_store<EPL>(X, ld, n, N, RB, Xs, ldx, RB, RB, w, lane);
+    block_store<EPL>(X, ld, n, N, 0, Xs, dsc, ldx, 0, RB, w, lane);
+    block_store<EPL>(X, ld, n, N, RB, Xs, dsc, ldx, RB, RB, w, lane);
   } else {
     // ---- block-cyclic sweeps: A resident, partners B streamed (prefetched) --
     for (; sweep < a.max_sweeps;) {
@@ -280,27 +417,20 @@ __global__ __launch_bounds__(JAC_NT) void jacobi_rows_kernel(JacobiArgs a) {
       for (int A = 0; A + 1 < nb; ++A) {
         block_fetch<EPL>(pre, X, ld, n, N, A * RB, RB, w, lane);
         block_commit<EPL>(pre, Xs, ldx, N, 0, RB, w, lane);
-        block_fetch<EPL>(pre, X, ld, n, N, (A + 1) * RB, RB, w, lane);   // first partner
         for (int Bk = A + 1; Bk < nb; ++Bk) {
+          block_fetch<EPL>(pre, X, ld, n, N, Bk * RB, RB, w, lane);
           block_commit<EPL>(pre, Xs, ldx, N, RB, RB, w, lane);
           __syncthreads();
-          if (Bk == A + 1) block_norms<EPL>(Xs, sq, ldx, n, 0, RB, slot, l16);
-          block_norms<EPL>(Xs, sq, ldx, n, RB, RB, slot, l16);
+          if (Bk == A + 1) block_norms<EPL>(Xs, sq, dsc, idsc, ldx, n, N, 0, RB, slot, l, false);
+          block_norms<EPL>(Xs, sq, dsc, idsc, ldx, n, N, RB, RB, slot, l, false);
           __syncthreads();
-          if (Bk + 1 < nb)                                 // prefetch the next partner
-            block_fetch<EPL>(pre, X, ld, n, N, (Bk + 1) * RB, RB, w, lane);
           if (Bk == A + 1) rotated |= intra(A == 0, true);  // each block once per sweep
-          for (int r = 0; r < RB; ++r) {                    // cross pairs A_i x B_(i+r)
-            const bool valid = slot < RB;
-            rotated |= rotate_pair<EPL>(Xs, sq, ldx, n, N, valid ? slot : 0,
-                                        valid ? RB + ((slot + r) % RB) : 0, valid, tol2, l16);
-            __syncthreads();
-          }
-          block_store<EPL>(X, ld, n, N, Bk * RB, Xs, ldx, RB, RB, w, lane);
+          rotated |= cross();
+          block_store<EPL>(X, ld, n, N, Bk * RB, Xs, dsc, ldx, RB, RB, w, lane);
           __threadfence_block();
           __syncthreads();
         }
-        block_store<EPL>(X, ld, n, N, A * RB, Xs, ldx, 0, RB, w, lane);
+        block_store<EPL>(X, ld, n, N, A * RB, Xs, dsc, ldx, 0, RB, w, lane);
         __threadfence_block();
         __syncthreads();
       }
@@ -312,7 +442,7 @@ __global__ __launch_bounds__(JAC_NT) void jacobi_rows_kernel(JacobiArgs a) {
   __syncthreads();
 
   double smax = 0.0, smin = __builtin_inf();
-  for (int i = w; i < n; i += JAC_NT / WAVE) {
+  for (int i = w; i < n; i += JAC_NW) {
     const double* xi = X + (long)i * ld;
     double aa = 0.0;
     for (int e = lane; e < n; e += WAVE) { const double u = xi[e]; aa = fma(u, u, aa); }
@@ -356,14 +486,14 @@ static hipError_t launch_jacobi_t(const JacobiArgs& a, int B, size_t lds, hipStr
 hipError_t launch_jacobi(const JacobiArgs& a_in, int B, hipStream_t st) {
   JacobiArgs a = a_in;
   a.RB = jacobi_block_rows(a.N);
-  const size_t lds = sizeof(double) * ((size_t)2 * a.RB * a.N + 2 * a.RB);
-  const int epl = (a.N + 15) / 16;
-  if (epl <= 2) return launch_jacobi_t<2>(a, B, lds, st);
+  const size_t lds = sizeof(double) * ((size_t)2 * a.RB * a.N + 6 * a.RB);
+  const int epl = (a.N + JAC_LPR - 1) / JAC_LPR;
+  if (epl <= 1) return launch_jacobi_t<1>(a, B, lds, st);
+  if (epl <= 3) return launch_jacobi_t<3>(a, B, lds, st);
   if (epl <= 5) return launch_jacobi_t<5>(a, B, lds, st);
   if (epl <= 9) return launch_jacobi_t<9>(a, B, lds, st);
   if (epl <= 17) return launch_jacobi_t<17>(a, B, lds, st);
-  if (epl <= 34) return launch_jacobi_t<34>(a, B, lds, st);
-  return launch_jacobi_t<68>(a, B, lds, st);
+  return launch_jacobi_t<34>(a, B, lds, st);
 }
 
 }  // namespace blsq
