@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libblsq_hip.so")
+LIB_PATH = os.environ.get("BLSQ_LIB", os.path.join(_HERE, "libblsq_hip.so"))
 
 c_double_p = C.POINTER(C.c_double)
 c_int64_p = C.POINTER(C.c_int64)
@@ -43,6 +43,7 @@ SIGNATURES = {
     "blsq_trf_step_dev": (C.c_int, [vp, vp, vp, C.c_double]),
     "blsq_trf_fetch_factor": (C.c_int, [vp] + [vp] * 5),
     "blsq_trf_fetch_step": (C.c_int, [vp] + [vp] * 15),
+    "blsq_debug_qr_stamps": (C.c_int, [vp]),
     "blsq_trf_debug_sweeps": (C.c_int, [vp, vp]),
     "blsq_dogbox_plan_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "blsq_dogbox_plan_destroy": (C.c_int, [vp]),

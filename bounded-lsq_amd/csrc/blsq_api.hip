@@ -176,6 +176,7 @@ struct QrTree {
         const Level& Pv = levels[l - 1];
         q.A = Pv.R.as<double>(); q.strideA = (long)Pv.nleaf * NPAD * NPAD;
         q.ldA = NPAD; q.rowsA = Pv.nleaf * NPAD; q.F = nullptr; q.strideF = 0;
+        q.stack_rows = NPAD;
       }
       q.rows_per_leaf = L.rows_per_leaf; q.RP = L.RP; q.LDP = L.LDP;
       q.Rout = L.R.as<double>();
@@ -390,6 +391,7 @@ int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode) {
   q.F = nullptr; q.strideF = 0;
   q.rows_per_leaf = p->aug_RP; q.RP = p->aug_RP; q.LDP = p->aug_LDP;
   q.Rout = p->st.X;
+  q.stack_rows = p->n;                 // [R D; E]: two upper-triangular blocks of n rows
   ctx->begin(K_QR_AUG);
   e = launch_qr(q, 1, p->B, ctx->stream);
   ctx->end();
@@ -499,6 +501,11 @@ extern "C" int blsq_trf_fetch_factor(blsq_trf_plan* p, double* g, double* g_norm
   if (theta) HIPCHK(ctx, hipMemcpyAsync(theta, p->st.theta, sizeof(double) * p->B,
                                         hipMemcpyDeviceToHost, ctx->stream));
   return blsq_sync(ctx);
+}
+
+extern "C" int blsq_debug_qr_stamps(void* dbuf) {
+  set_qr_debug_buffer(reinterpret_cast<double*>(dbuf));
+  return 0;
 }
 
 extern "C" int blsq_trf_debug_sweeps(blsq_trf_plan* p, int32_t* sweeps) {
@@ -674,6 +681,7 @@ extern "C" int blsq_tsqr_combine_dev(blsq_trf_plan* p, const double* dtri_stack,
   while (ntri > 1) {
     QrArgs q = p->tree.base_args();
     q.A = src; q.strideA = 0; q.ldA = NPAD; q.rowsA = ntri * NPAD; q.F = nullptr; q.strideF = 0;
+    q.stack_rows = NPAD;
     q.rows_per_leaf = G * NPAD;
     const int nleaf = (ntri + G - 1) / G;
     q.RP = std::max(round_up(std::min(q.rows_per_leaf, q.rowsA), 16), NPAD);

@@ -13,12 +13,86 @@ constexpr int TILE = 16;          // f64 MFMA tile edge (v_mfma_f64_16x16x4_f64)
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
-// ---- wave reductions (all 64 lanes end with the result) ------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+// ---- DPP helpers ----------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of a DPP row; every lane gets the bit-identical total
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]   (xor 1)
+  v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]   (xor 2)
+  v += dpp_mov<0x141>(v);     // row_half_mirror       (other quad of the 8)
+  v += dpp_mov<0x140>(v);     // row_mirror            (other half of the 16)
   return v;
 }
+__device__ __forceinline__ double read_lane(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+// ---- wave reductions (all 64 lanes end with the result) ------------------
+// DPP butterfly inside each 16-lane row, then the 4 row totals through SGPRs:
+// no LDS crossbar (ds_bpermute), fixed order (deterministic).
+__device__ __forceinline__ double wave_sum(double v) {
+  v = row16_sum(v);
+  return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
+}
+// Reduce SIXTEEN per-lane values across the wave at once (transposed butterfly:
+// at every step a lane hands the half it does not keep to its partner, so the
+// 16 totals cost 8+4+2+1 exchanges instead of 16 x 4).  On return v[0] of lane l
+// holds the wave total of the value with index wave_sum16_index(l); all 64 lanes
+// are valid.  Must be called in wave-uniform control flow.  Fixed order.
+__device__ __forceinline__ int wave_sum16_index(int lane) {
+  return ((lane & 1) << 3) | ((lane & 2) << 1) | ((lane & 4) >> 1) | ((lane & 8) >> 3);
+}
+__device__ __forceinline__ void wave_sum16(double (&v)[16]) {
+  const int lane = threadIdx.x & 63;
+  const bool k0 = (lane & 1) == 0, k1 = (lane & 2) == 0, k2 = (lane & 4) == 0,
+             k3 = (lane & 8) == 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {                       // partner = lane ^ 1
+    const double send = k0 ? v[8 + i] : v[i];
+    const double keep = k0 ? v[i] : v[8 + i];
+    v[i] = keep + dpp_mov<0xB1>(send);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {                       // partner = lane ^ 2
+    const double send = k1 ? v[4 + i] : v[i];
+    const double keep = k1 ? v[i] : v[4 + i];
+    v[i] = keep + dpp_mov<0x4E>(send);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {                       // partner = lane ^ 4
+    const double send = k2 ? v[2 + i] : v[i];
+    const double keep = k2 ? v[i] : v[2 + i];
+    const double up = dpp_mov<0x104>(send);           // row_shl:4  (from lane + 4)
+    const double dn = dpp_mov<0x114>(send);           // row_shr:4  (from lane - 4)
+    v[i] = keep + (k2 ? up : dn);
+  }
+  {                                                   // partner = lane ^ 8
+    const double send = k3 ? v[1] : v[0];
+    const double keep = k3 ? v[0] : v[1];
+    const double up = dpp_mov<0x108>(send);           // row_shl:8
+    const double dn = dpp_mov<0x118>(send);           // row_shr:8
+    v[0] = keep + (k3 ? up : dn);
+  }
+  {                                                   // rows: lane ^ 16, then lane ^ 32
+    double t = v[0];
+    int lo = __builtin_amdgcn_ds_swizzle(__double2loint(t), 0x401F);
+    int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(t), 0x401F);
+    t += __hiloint2double(hi, lo);
+    const int addr = (lane ^ 32) << 2;
+    lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(t));
+    hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(t));
+    v[0] = t + __hiloint2double(hi, lo);
+  }
+}
+
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));

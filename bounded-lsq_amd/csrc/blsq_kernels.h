@@ -24,9 +24,12 @@ struct QrArgs {
   double* V;              // scratch [slot][NPmax][RP][16]
   double* T;              // scratch [slot][NPmax][256]
   double* Rout;           // [slot][NPAD][NPAD], slot = b*nleaf + leaf
+  double* dbg;            // diagnostic stamps (nullptr in the product)
+  int stack_rows;         // >0: source is a stack of upper-triangular blocks of this many rows
 };
 size_t qr_lds_bytes(int LDP);
 hipError_t launch_qr(const QrArgs& q, int nleaf, int B, hipStream_t st);
+void set_qr_debug_buffer(double* p);
 
 // ------------------------------------------------------------- Jacobi -----
 // One-sided Jacobi on the ROWS of the n x (n+1) array [R | c] (row stride ld):

@@ -41,22 +41,6 @@ static constexpr int JAC_LPR = 32;                // lanes per row
 static constexpr int JAC_SLOTS = JAC_NT / JAC_LPR; // 16 concurrent tile slots
 static constexpr int JAC_NW = JAC_NT / 64;
 
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
-  return __hiloint2double(hi, lo);
-}
-// sum over the 16 lanes of a DPP row; every lane gets the bit-identical total
-__device__ __forceinline__ double row16_sum(double v) {
-  v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]   (xor 1)
-  v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]   (xor 2)
-  v += dpp_mov<0x141>(v);     // row_half_mirror       (other quad of the 8)
-  v += dpp_mov<0x140>(v);     // row_mirror            (other half of the 16)
-  return v;
-}
-
 // sum over the 32 lanes {0-31} / {32-63}: 16-lane butterfly + one xor-16 swizzle
 __device__ __forceinline__ double row32_sum(double v) {
   v = row16_sum(v);

@@ -27,6 +27,18 @@
 
 namespace blsq {
 
+// Diagnostic build only (-DBLSQ_QR_STAMPS): thread 0 of each workgroup sums the
+// cycles of each phase into q.dbg[slot*8 + phase].  Never enabled in the product.
+#ifdef BLSQ_QR_STAMPS
+#define STAMP_DECL unsigned long long st_acc[8] = {0,0,0,0,0,0,0,0}; unsigned long long st_t = __builtin_readcyclecounter();
+#define STAMP(i) { unsigned long long now_ = __builtin_readcyclecounter(); st_acc[i] += now_ - st_t; st_t = now_; }
+#define STAMP_OUT if (tid == 0 && q.dbg) { for (int i_ = 0; i_ < 8; ++i_) q.dbg[slot * 8 + i_] = (double)st_acc[i_]; }
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_OUT
+#endif
+
 static constexpr int QR_NT = 512;
 static constexpr int QR_NW = QR_NT / WAVE;
 
@@ -34,7 +46,23 @@ __device__ __forceinline__ v4d mfma_f64(double a, double b, v4d c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// Stacked-triangle inputs (TSQR merges, [R D; E]): the source is a stack of
+// upper-triangular blocks of `sr` rows, so block reflector j is zero outside
+// tile j of the first block and the rows i <= 16j+15 of every later block.
+// sr == 0: dense source, every tile >= j is live.  (wave-uniform)
+__device__ __forceinline__ bool tile_active(int t, int j, int sr) {
+  if (sr <= 0) return true;
+  const int rlo = t * TILE, rhi = rlo + TILE - 1;
+  const int glo = rlo / sr, ghi = rhi / sr;
+  if (glo != ghi) return true;              // straddles a block boundary (holds row 0 of a block)
+  if (glo == 0) return t == j;
+  return (rlo - glo * sr) <= j * TILE + TILE - 1;
+}
+
+// MAXT = tile slots per wave (ceil(RP/16/8)); tile of slot i is t0 + 8 i.
+template <int MAXT>
 __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
+  constexpr int NR = (MAXT * QR_NW * TILE + QR_NT - 1) / QR_NT;   // rows per thread
   extern __shared__ double lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -64,43 +92,95 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
   if (nrows < 0) nrows = 0;
   const double* A = q.A + (long)b * q.strideA + (long)r0 * q.ldA;
   const double* F = q.F ? q.F + (long)b * q.strideF + r0 : nullptr;
-  double* V = q.V + slot * (long)q.NPmax * RP * 16;
+  double* V = q.V + slot * (long)q.NPmax * RP * 16;     // tiles [t][row][col]
   double* T = q.T + slot * (long)q.NPmax * 256;
 
   const int lr = lane >> 4;                 // 0..3
   const int lc = lane & 15;                 // 0..15
+  double ident[4];                          // B-operand slices of the 16x16 identity
+#pragma unroll
+  for (int s = 0; s < 4; ++s) ident[s] = (lc == 4 * s + lr) ? 1.0 : 0.0;
 
+  STAMP_DECL
   for (int k = 0; k < NP; ++k) {
     // ---- 1. stage panel k of the source into LDS (single HBM read) --------
-    for (int idx = tid; idx < RP * 16; idx += QR_NT) {
-      const int row = idx >> 4, c = idx & 15;
-      const int col = k * TILE + c;
-      double val = 0.0;
-      if (row < nrows) {
-        if (col < nA) val = A[(long)row * q.ldA + col];
-        else if (col == nA && F) val = F[row];
+    // Loads are unconditional (clamped addresses, select afterwards) and 8 are in
+    // flight per thread: a guarded load would serialise into branch+load+wait.
+    {
+      const int total = RP * 16;
+      const bool fpanel = (F != nullptr) && (nA >= k * TILE) && (nA < k * TILE + TILE);
+      const int rmax = nrows > 0 ? nrows - 1 : 0;
+      for (int i0 = 0; i0 < total; i0 += 8 * QR_NT) {
+        double tmp[8], tf[8];
+#pragma unroll
+        for (int uu = 0; uu < 8; ++uu) {
+          const int idx = i0 + uu * QR_NT + tid;
+          const int row = idx >> 4, c = idx & 15;
+          const int col = k * TILE + c;
+          const int rc = row < rmax ? row : rmax;
+          const int cc = col < nA ? col : (nA > 0 ? nA - 1 : 0);
+          tmp[uu] = (nrows > 0 && nA > 0) ? A[(long)rc * q.ldA + cc] : 0.0;
+          tf[uu] = fpanel ? F[rc] : 0.0;
+        }
+#pragma unroll
+        for (int uu = 0; uu < 8; ++uu) {
+          const int idx = i0 + uu * QR_NT + tid;
+          const int row = idx >> 4, c = idx & 15;
+          const int col = k * TILE + c;
+          double val = 0.0;
+          if (row < nrows) {
+            if (col < nA) val = tmp[uu];
+            else if (col == nA && F) val = tf[uu];
+          }
+          if (idx < total) P[c * LDP + row] = val;
+        }
       }
-      P[c * LDP + row] = val;
     }
     __syncthreads();
+    STAMP(0)
 
     // ---- 2. apply block reflectors 0..k-1:  P -= V_j (T_j^T (V_j^T P)) ----
+    // HBM traffic is what bounds this phase (the V panels of a leaf do not fit
+    // L2/MALL), so every V_j tile is read ONCE (contiguous 512 B per k-step, all
+    // loads of a wave issued before the first MFMA).  The second GEMM needs the
+    // transposed operand layout; it is produced on chip by 4 MFMAs against the
+    // identity: feeding the loaded registers as A = V^T gives D = V^T in C layout
+    // (row = lane/16 + 4 reg), which IS the A-operand layout of V for k-step
+    // `reg`.  Multiplying by exact 0/1 is exact.
     for (int j = 0; j < k; ++j) {
       const double* Vj = V + (long)j * RP * 16;
       const double* Tj = T + j * 256;
-      int t0 = j + ((w - j) % QR_NW + QR_NW) % QR_NW;   // first own tile >= j
-      v4d acc = {0.0, 0.0, 0.0, 0.0};
-      for (int t = t0; t < ntile; t += QR_NW) {
-        const double* vt = Vj + (long)t * 256;
-        const double* pt = P + lc * LDP + t * TILE + lr;
+      const int t0 = j + ((w - j) % QR_NW + QR_NW) % QR_NW;   // first own tile >= j
+      const int tlast = ntile - 1;
+      double va[MAXT][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-          acc = mfma_f64(vt[64 * s + lane], pt[4 * s], acc);
+      for (int i = 0; i < MAXT; ++i) {
+        const int t = t0 + QR_NW * i;
+        const double* vt = Vj + (long)(t < ntile ? t : tlast) * 256;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) va[i][s] = vt[64 * s + lane];
+      }
+      v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) {
+        const int t = t0 + QR_NW * i;
+        if (t < ntile && tile_active(t, j, q.stack_rows)) {
+          const double* pt = P + lc * LDP + t * TILE + lr;
+          v4d tr = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            acc = mfma_f64(va[i][s], pt[4 * s], acc);
+            tr = mfma_f64(va[i][s], ident[s], tr);        // on-chip transpose
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) va[i][s] = tr[s];
+        }
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) Wred[w * 256 + g * 64 + lane] = acc[g];
       __syncthreads();
       v4d W = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
       for (int ww = 0; ww < QR_NW; ++ww) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) W[g] += Wred[ww * 256 + g * 64 + lane];
@@ -108,26 +188,37 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
       v4d W2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int s = 0; s < 4; ++s) W2 = mfma_f64(Tj[64 * s + lane], W[s], W2);
-      for (int t = t0; t < ntile; t += QR_NW) {
-        const double* vt = Vj + (long)t * 256 + lc * 16 + lr;
-        double* pt = P + lc * LDP + t * TILE + lr;
-        v4d C;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) C[g] = pt[4 * g];
+      for (int i = 0; i < MAXT; ++i) {
+        const int t = t0 + QR_NW * i;
+        if (t < ntile && tile_active(t, j, q.stack_rows)) {
+          double* pt = P + lc * LDP + t * TILE + lr;
+          v4d C;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) C = mfma_f64(-vt[4 * s], W2[s], C);
+          for (int g = 0; g < 4; ++g) C[g] = pt[4 * g];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) pt[4 * g] = C[g];
+          for (int s = 0; s < 4; ++s) C = mfma_f64(-va[i][s], W2[s], C);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) pt[4 * g] = C[g];
+        }
       }
       __syncthreads();                      // Wred is reused by the next j
     }
 
+    STAMP(1)
     // ---- 3. Householder-factor rows >= 16k of the panel in LDS ------------
-    // Each thread owns rows tid, tid+512, tid+1024 (RP <= 1088).  Per column:
-    // one fused reduction (sum x^2 and the <=15 dot products x.P[c']) through
-    // wave shuffles + one LDS exchange + ONE barrier.
+    // Each thread owns rows tid + 512 i, i < NR (RP <= 512 NR).  Per column: one
+    // fused reduction (sum x^2 and the <=15 dot products x.P[c']) through
+    // DPP/readlane wave sums + one LDS exchange + ONE barrier.  The LDS loads of a
+    // column step are unconditional (clamped) and issued together, and the loaded
+    // panel values are reused from registers for the rank-1 update.
     const int base = k * TILE;
-    const int row0 = tid, row1 = tid + QR_NT, row2 = tid + 2 * QR_NT;
+    int rowi[NR], rci[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      rowi[r] = tid + r * QR_NT;
+      rci[r] = rowi[r] < RP ? rowi[r] : RP - 1;
+    }
 #pragma unroll 1
     for (int c = 0; c < TILE; ++c) {
       const int p = base + c;               // pivot row == global column
@@ -135,34 +226,55 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
         if (tid == 0) taus[c] = 0.0;
         continue;
       }
-      const double* pc = P + c * LDP;
-      const bool in0 = row0 > p && row0 < RP, in1 = row1 > p && row1 < RP,
-                 in2 = row2 > p && row2 < RP;
-      const double x0 = in0 ? pc[row0] : 0.0;
-      const double x1 = in1 ? pc[row1] : 0.0;
-      const double x2 = in2 ? pc[row2] : 0.0;
+      bool inr[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) inr[r] = rowi[r] > p && rowi[r] < RP;
+      const bool owner = (tid == (p % QR_NT));
+      // y[r][i] = P[column c+i (clamped to 15)][row r]; i >= 16-c is discarded later
+      double y[NR][TILE];
+#pragma unroll
+      for (int i = 0; i < TILE; ++i) {
+        const int ci = (c + i < TILE) ? c + i : TILE - 1;
+        const double* pi = P + ci * LDP;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) y[r][i] = pi[rci[r]];
+      }
+      double x[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) x[r] = inr[r] ? y[r][0] : 0.0;
       double* ex = xch + (c & 1) * (QR_NW * 16 + 16);
       {
-        const double sred = wave_sum(x0 * x0 + x1 * x1 + x2 * x2);
-        if (lane == 0) ex[w * 16] = sred;
+        double part[TILE];
+#pragma unroll
+        for (int i = 0; i < TILE; ++i) {
+          double acc = 0.0;
+#pragma unroll
+          for (int r = 0; r < NR; ++r) acc = fma(x[r], (i == 0) ? x[r] : y[r][i], acc);
+          part[i] = acc;
+        }
+        wave_sum16(part);                    // all 16 totals in one transposed butterfly
+        if (lane < TILE) ex[w * 16 + wave_sum16_index(lane)] = part[0];
       }
-      for (int i = 1; c + i < TILE; ++i) {
-        const double* pi = P + (c + i) * LDP;
-        double acc = 0.0;
-        if (in0) acc += x0 * pi[row0];
-        if (in1) acc += x1 * pi[row1];
-        if (in2) acc += x2 * pi[row2];
-        acc = wave_sum(acc);
-        if (lane == 0) ex[w * 16 + i] = acc;
+      if (owner) {                          // publish the (old) pivot row: it was last
+        // written by THIS thread (previous column's update), others must not read P here
+#pragma unroll
+        for (int i = 0; i < TILE; ++i) {
+          const int ci = (c + i < TILE) ? c + i : TILE - 1;
+          ex[QR_NW * 16 + i] = P[ci * LDP + p];
+        }
       }
-      const bool owner = (tid == (p % QR_NT));
-      if (owner) {                          // publish the (old) pivot row
-        for (int i = 0; c + i < TILE; ++i) ex[QR_NW * 16 + i] = P[(c + i) * LDP + p];
-      }
+      STAMP(6)
       __syncthreads();
-      double xn2 = 0.0;
-      for (int ww = 0; ww < QR_NW; ++ww) xn2 += ex[ww * 16];
-      const double alpha = ex[QR_NW * 16];
+      STAMP(7)
+      // lane i (mod 16) sums the 8 wave partials of value i and reads pivot value i:
+      // 9 LDS reads per wave instead of 135 broadcast reads per thread; the results
+      // travel to all lanes through v_readlane (SGPRs).
+      double totl = 0.0;
+#pragma unroll
+      for (int ww = 0; ww < QR_NW; ++ww) totl += ex[ww * 16 + lc];
+      const double pvl = ex[QR_NW * 16 + lc];
+      const double xn2 = read_lane(totl, 0);
+      const double alpha = read_lane(pvl, 0);
       double beta, tau, scal;
       if (xn2 == 0.0) {
         beta = alpha; tau = 0.0; scal = 0.0;
@@ -171,26 +283,32 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
         tau = (beta - alpha) / beta;
         scal = 1.0 / (alpha - beta);
       }
-      const double v0 = scal * x0, v1 = scal * x1, v2 = scal * x2;
+      const double wvl = tau * (pvl + scal * totl);      // lane i holds w_i
+      double vv[NR];
       double* pcw = P + c * LDP;
-      if (in0) pcw[row0] = v0;
-      if (in1) pcw[row1] = v1;
-      if (in2) pcw[row2] = v2;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        vv[r] = scal * x[r];
+        if (inr[r]) pcw[rowi[r]] = vv[r];
+      }
       if (owner) pcw[p] = beta;
-      for (int i = 1; c + i < TILE; ++i) {
-        double tot = 0.0;
-        for (int ww = 0; ww < QR_NW; ++ww) tot += ex[ww * 16 + i];
-        const double wv = tau * (ex[QR_NW * 16 + i] + scal * tot);
-        double* pi = P + (c + i) * LDP;
-        if (in0) pi[row0] -= v0 * wv;
-        if (in1) pi[row1] -= v1 * wv;
-        if (in2) pi[row2] -= v2 * wv;
-        if (owner) pi[p] -= wv;
+#pragma unroll
+      for (int i = 1; i < TILE; ++i) {
+        if (c + i < TILE) {                  // uniform
+          const double wv = read_lane(wvl, i);
+          const double pvi = read_lane(pvl, i);
+          double* pi = P + (c + i) * LDP;
+#pragma unroll
+          for (int r = 0; r < NR; ++r)
+            if (inr[r]) pi[rowi[r]] = y[r][i] - vv[r] * wv;
+          if (owner) pi[p] = pvi - wv;
+        }
       }
       if (tid == 0) taus[c] = tau;
     }
     __syncthreads();
 
+    STAMP(2)
     // ---- 4. emit the R block column (rows 0..NPAD-1 of these 16 columns) --
     for (int idx = tid; idx < NPAD * 16; idx += QR_NT) {
       const int row = idx >> 4, c = idx & 15;
@@ -201,6 +319,7 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
         Rout[(long)row * NPAD + col] = val;
       }
     }
+    STAMP(3)
     if (k == NP - 1) break;                 // no later panel needs V_k / T_k
     __syncthreads();
 
@@ -219,6 +338,7 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
       int t0 = k + ((w - k) % QR_NW + QR_NW) % QR_NW;
       v4d acc = {0.0, 0.0, 0.0, 0.0};
       for (int t = t0; t < ntile; t += QR_NW) {
+        if (!tile_active(t, k, q.stack_rows)) continue;
         const double* pt = P + lc * LDP + t * TILE + lr;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -253,6 +373,7 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
         for (int c = 0; c < TILE; ++c) Tk[i * 16 + c] = Ts[c];
       }
     }
+    STAMP(4)
     // ---- 7. spill V_k (tile-contiguous: [row][16]) for later panels -------
     {
       double* Vk = V + (long)k * RP * 16;
@@ -263,7 +384,9 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
     }
     __threadfence_block();
     __syncthreads();
+    STAMP(5)
   }
+  STAMP_OUT
 }
 
 size_t qr_lds_bytes(int LDP) {
@@ -271,18 +394,33 @@ size_t qr_lds_bytes(int LDP) {
                                    2 * (QR_NW * 16 + 16) + 16);
 }
 
-hipError_t launch_qr(const QrArgs& q, int nleaf, int B, hipStream_t st) {
-  const size_t lds = qr_lds_bytes(q.LDP);
+template <int MAXT>
+static hipError_t launch_qr_t(const QrArgs& q, int nleaf, int B, size_t lds, hipStream_t st) {
   static size_t configured = 0;
   if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute((const void*)qr_panel_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)qr_panel_kernel<MAXT>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     configured = lds;
   }
-  hipLaunchKernelGGL(qr_panel_kernel, dim3(nleaf, B), dim3(QR_NT), lds, st, q);
+  hipLaunchKernelGGL(qr_panel_kernel<MAXT>, dim3(nleaf, B), dim3(QR_NT), lds, st, q);
   return hipGetLastError();
+}
+
+static double* g_qr_dbg = nullptr;
+void set_qr_debug_buffer(double* p) { g_qr_dbg = p; }
+
+hipError_t launch_qr(const QrArgs& q_in, int nleaf, int B, hipStream_t st) {
+  QrArgs q = q_in;
+  q.dbg = g_qr_dbg;
+  if (g_qr_dbg) g_qr_dbg += (size_t)nleaf * B * 8;   // successive launches append
+  const size_t lds = qr_lds_bytes(q.LDP);
+  const int slots = (q.RP / TILE + QR_NW - 1) / QR_NW;
+  if (slots <= 2) return launch_qr_t<2>(q, nleaf, B, lds, st);
+  if (slots <= 4) return launch_qr_t<4>(q, nleaf, B, lds, st);
+  if (slots <= 6) return launch_qr_t<6>(q, nleaf, B, lds, st);
+  if (slots <= 8) return launch_qr_t<8>(q, nleaf, B, lds, st);
+  return launch_qr_t<9>(q, nleaf, B, lds, st);
 }
 
 }  // namespace blsq

@@ -104,6 +104,10 @@ int blsq_trf_fetch_step(blsq_trf_plan* plan, double* alpha_out, double* step_h, 
                         double* p_h_tr /*may be NULL*/, double* to_bound /*may be NULL*/,
                         int32_t* choice /*may be NULL*/);
 
+/* diagnostics: in-kernel phase stamps of the QR kernel (only a -DBLSQ_QR_STAMPS
+ * build writes them): 8 doubles per workgroup into the given device buffer */
+int blsq_debug_qr_stamps(void* dbuf);
+
 /* diagnostics: Jacobi sweeps used by the last factor call, per problem */
 int blsq_trf_debug_sweeps(blsq_trf_plan* plan, int32_t* sweeps /*B*/);
 
