@@ -17,8 +17,9 @@ __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+  // all rows/banks enabled and every source lane valid: no `old` value needed
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
   return __hiloint2double(hi, lo);
 }
 // sum over the 16 lanes of a DPP row; every lane gets the bit-identical total

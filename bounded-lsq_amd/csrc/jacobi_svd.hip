@@ -85,6 +85,9 @@ __device__ __forceinline__ int rot_regs(double (&u)[EPL], double (&v)[EPL], doub
   }
   const double g = row32_sum(g0 + g1) * (du * dv);
   if (!(a > 0.0 && b > 0.0 && g * g > tol2 * a * b)) return 0;
+  // cos^2 > 1e-16 (|cos| > 1e-8): after this rotation the pair is NOT yet guaranteed to be
+  // below tolerance at the next visit, so another sweep is needed (bit 1 of the result)
+  const int big_cos = (g * g > 1e-16 * a * b) ? 2 : 0;
   // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)),  zeta = (b - a) / (2 g)
   const double h = b - a, ag = 2.0 * g;
   const double big = fmax(fabs(h), fabs(ag));
@@ -108,7 +111,7 @@ __device__ __forceinline__ int rot_regs(double (&u)[EPL], double (&v)[EPL], doub
   du *= cs; dv *= cs; idu *= ics; idv *= ics;
   a -= t * g;
   b += t * g;
-  return 1;
+  return 1 | big_cos;
 }
 
 template <int EPL>
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(JAC_NT) void jacobi_rows_kernel(JacobiArgs a) {
       int rotated = intra(true, nb == 2);
       if (nb == 2) rotated |= cross();
       ++sweep;
-      if (!block_or(rotated, red)) break;
+      if (!block_or(rotated & 2, red)) break;   // quadratic convergence: what was rotated is done
     }
     block_store<EPL>(X, ld, n, N, 0, Xs, dsc, ldx, 0, RB, w, lane);
     block_store<EPL>(X, ld, n, N, RB, Xs, dsc, ldx, RB, RB, w, lane);
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(JAC_NT) void jacobi_rows_kernel(JacobiArgs a) {
         __syncthreads();
       }
       ++sweep;
-      if (!block_or(rotated, red)) break;
+      if (!block_or(rotated & 2, red)) break;
     }
   }
   __threadfence_block();
