@@ -71,19 +71,21 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 // row leaves the chip).  tan comes from an f32 evaluation (any tan is a valid
 // rotation; it only has to annihilate the pair to ~1e-7, quadratic convergence
 // does the rest), cos = rsqrt(1 + tan^2) in full f64 so norms are preserved.
-// Executed by the 32 lanes of a row group; lane l holds elements l + 32k.
+// Executed by the 32 lanes of a row group; lane l holds elements l + 32k.  Rows
+// are zero-padded to 32*EPL entries, so nothing here is guarded; the carried
+// right-hand-side entries (cu, cv) ride along as scalars.
+struct RowSt { double a, d, id, c; };     // true norm^2, scale, 1/scale, carried entry
+
 template <int EPL>
-__device__ __forceinline__ int rot_regs(double (&u)[EPL], double (&v)[EPL], double& a, double& b,
-                                        double& du, double& idu, double& dv, double& idv, int n,
-                                        double tol2, int l) {
+__device__ __forceinline__ int rot_regs(double (&u)[EPL], double (&v)[EPL], RowSt& U, RowSt& V,
+                                        double tol2) {
   double g0 = 0.0, g1 = 0.0;
 #pragma unroll
   for (int k = 0; k < EPL; ++k) {
-    if (l + JAC_LPR * k < n) {
-      if (k & 1) g1 = fma(u[k], v[k], g1); else g0 = fma(u[k], v[k], g0);
-    }
+    if (k & 1) g1 = fma(u[k], v[k], g1); else g0 = fma(u[k], v[k], g0);
   }
-  const double g = row32_sum(g0 + g1) * (du * dv);
+  const double g = row32_sum(g0 + g1) * (U.d * V.d);
+  const double a = U.a, b = V.a;
   if (!(a > 0.0 && b > 0.0 && g * g > tol2 * a * b)) return 0;
   // cos^2 > 1e-16 (|cos| > 1e-8): after this rotation the pair is NOT yet guaranteed to be
   // below tolerance at the next visit, so another sweep is needed (bit 1 of the result)
@@ -101,35 +103,31 @@ __device__ __forceinline__ int rot_regs(double (&u)[EPL], double (&v)[EPL], doub
   const double w = fma(t, t, 1.0);
   const double cs = fast_rsqrt(w);
   const double ics = w * cs;                               // 1 / cs
-  const double t1 = t * dv * idu, t2 = t * du * idv;
+  const double t1 = t * V.d * U.id, t2 = t * U.d * V.id;
 #pragma unroll
   for (int k = 0; k < EPL; ++k) {
     const double uu = u[k];
     u[k] = fma(-t1, v[k], uu);
     v[k] = fma(t2, uu, v[k]);
   }
-  du *= cs; dv *= cs; idu *= ics; idv *= ics;
-  a -= t * g;
-  b += t * g;
+  const double cu = U.c;
+  U.c = fma(-t1, V.c, cu);
+  V.c = fma(t2, cu, V.c);
+  U.d *= cs; V.d *= cs; U.id *= ics; V.id *= ics;
+  U.a = a - t * g;
+  V.a = b + t * g;
   return 1 | big_cos;
 }
 
 template <int EPL>
-__device__ __forceinline__ void row_load(double (&u)[EPL], const double* row, int N, int l) {
+__device__ __forceinline__ void row_load(double (&u)[EPL], const double* row, int l) {
 #pragma unroll
-  for (int k = 0; k < EPL; ++k) {
-    const int e = l + JAC_LPR * k;
-    const double val = row[(e < N) ? e : 0];         // unconditional load, select after
-    u[k] = (e < N) ? val : 0.0;
-  }
+  for (int k = 0; k < EPL; ++k) u[k] = row[l + JAC_LPR * k];
 }
 template <int EPL>
-__device__ __forceinline__ void row_store(const double (&u)[EPL], double* row, int N, int l) {
+__device__ __forceinline__ void row_store(const double (&u)[EPL], double* row, int l) {
 #pragma unroll
-  for (int k = 0; k < EPL; ++k) {
-    const int e = l + JAC_LPR * k;
-    if (e < N) row[e] = u[k];
-  }
+  for (int k = 0; k < EPL; ++k) row[l + JAC_LPR * k] = u[k];
 }
 
 // round-robin (chess tournament) pairing of `np` (even) players, round r,
@@ -141,19 +139,20 @@ __device__ __forceinline__ void rr_pair(int np, int r, int i, int& p, int& q) {
 }
 
 // ---- block transfers -------------------------------------------------------
+// LDS row layout: stride LDX = 32*EPL doubles, entries [0,n) = the row of R,
+// [n, LDX) = 0; the carried entry (global column n) lives in cz[row].
 // A block is RB (<= 32) rows; wave w moves rows w, w+8, w+16, w+24 of it, lanes
-// stride the row.  All loads of a block are issued before the first use, so a
-// block costs one memory round trip (and can be prefetched into registers
-// while the previous block pair is being rotated).
+// stride the row.  All loads of a block are issued before the first use.
 template <int EPL>
 struct BlockRegs {
   static constexpr int CH = (JAC_LPR * EPL + 63) / 64;
   double t[4][CH];
+  double c[4];
 };
 
 template <int EPL>
 __device__ __forceinline__ void block_fetch(BlockRegs<EPL>& R, const double* X, int ld, int n,
-                                            int N, int g0, int RB, int w, int lane) {
+                                            int g0, int RB, int w, int lane) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int r = w + JAC_NW * j;
@@ -163,42 +162,50 @@ __device__ __forceinline__ void block_fetch(BlockRegs<EPL>& R, const double* X, 
 #pragma unroll
     for (int c = 0; c < BlockRegs<EPL>::CH; ++c) {
       const int e = lane + 64 * c;
-      const double val = src[(e < N) ? e : 0];
-      R.t[j][c] = (rok && e < N) ? val : 0.0;
+      const double val = src[(e < n) ? e : 0];
+      R.t[j][c] = (rok && e < n) ? val : 0.0;
     }
+    const double cval = src[n];
+    R.c[j] = rok ? cval : 0.0;
   }
 }
 template <int EPL>
-__device__ __forceinline__ void block_commit(const BlockRegs<EPL>& R, double* Xs, int ldx, int N,
+__device__ __forceinline__ void block_commit(const BlockRegs<EPL>& R, double* Xs, double* cz,
                                              int s0, int RB, int w, int lane) {
+  constexpr int LDX = JAC_LPR * EPL;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int r = w + JAC_NW * j;
     if (r < RB) {
-      double* dst = Xs + (s0 + r) * ldx;
+      double* dst = Xs + (s0 + r) * LDX;
 #pragma unroll
       for (int c = 0; c < BlockRegs<EPL>::CH; ++c) {
         const int e = lane + 64 * c;
-        if (e < N) dst[e] = R.t[j][c];
+        if (e < LDX) dst[e] = R.t[j][c];
       }
+      if (lane == 0) cz[s0 + r] = R.c[j];
     }
   }
 }
 template <int EPL>
-__device__ __forceinline__ void block_store(double* X, int ld, int n, int N, int g0,
-                                            const double* Xs, const double* dsc, int ldx, int s0,
-                                            int RB, int w, int lane) {
+__device__ __forceinline__ void block_store(double* X, int ld, int n, int g0, const double* Xs,
+                                            const double* cz, const double* dsc, int s0, int RB,
+                                            int w, int lane) {
+  constexpr int LDX = JAC_LPR * EPL;
   double t[4][BlockRegs<EPL>::CH];
+  double tc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int r = w + JAC_NW * j;
-    const double* src = Xs + (s0 + (r < RB ? r : 0)) * ldx;
-    const double sc = dsc[s0 + (r < RB ? r : 0)];          // fold the fast-rotation scale in
+    const int rr = s0 + (r < RB ? r : 0);
+    const double* src = Xs + rr * LDX;
+    const double sc = dsc[rr];                     // fold the fast-rotation scale in
 #pragma unroll
     for (int c = 0; c < BlockRegs<EPL>::CH; ++c) {
       const int e = lane + 64 * c;
-      t[j][c] = src[(e < N) ? e : 0] * sc;
+      t[j][c] = src[(e < LDX) ? e : 0] * sc;
     }
+    tc[j] = cz[rr] * sc;
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -209,31 +216,36 @@ __device__ __forceinline__ void block_store(double* X, int ld, int n, int N, int
 #pragma unroll
       for (int c = 0; c < BlockRegs<EPL>::CH; ++c) {
         const int e = lane + 64 * c;
-        if (e < N) dst[e] = t[j][c];
+        if (e < n) dst[e] = t[j][c];
       }
+      if (lane == 0) dst[n] = tc[j];
     }
   }
 }
-// squared norms (first n entries) of LDS rows [s0, s0+cnt), one row per 32 lanes;
-// also resets the fast-rotation scales of those rows to 1
+// squared norms of LDS rows [s0, s0+cnt), one row per 32 lanes; resets the
+// fast-rotation scales to 1 (after optionally folding them into the data)
 template <int EPL>
-__device__ __forceinline__ void block_norms(double* Xs, double* sq, double* dsc, double* idsc,
-                                            int ldx, int n, int N, int s0, int cnt, int slot,
-                                            int l, bool apply) {
+__device__ __forceinline__ void block_norms(double* Xs, double* cz, double* sq, double* dsc,
+                                            double* idsc, int s0, int cnt, int slot, int l,
+                                            bool apply) {
+  constexpr int LDX = JAC_LPR * EPL;
   for (int r0 = 0; r0 < cnt; r0 += JAC_SLOTS) {
     const int r = r0 + slot;
-    double* src = Xs + (s0 + (r < cnt ? r : 0)) * ldx;
-    const double sc = apply ? dsc[s0 + (r < cnt ? r : 0)] : 1.0;
+    const int rr = s0 + (r < cnt ? r : 0);
+    double* src = Xs + rr * LDX;
+    const double sc = apply ? dsc[rr] : 1.0;
     double acc = 0.0;
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
-      const int e = l + JAC_LPR * k;
-      const double v = src[(e < N) ? e : 0] * sc;
-      if (apply && r < cnt && e < N) src[e] = v;       // fold the scale into the data
-      if (e < n) acc = fma(v, v, acc);
+      const double v = src[l + JAC_LPR * k] * sc;
+      if (apply && r < cnt) src[l + JAC_LPR * k] = v;
+      acc = fma(v, v, acc);
     }
     acc = row32_sum(acc);
-    if (r < cnt && l == 0) { sq[s0 + r] = acc; dsc[s0 + r] = 1.0; idsc[s0 + r] = 1.0; }
+    if (r < cnt && l == 0) {
+      sq[rr] = acc; dsc[rr] = 1.0; idsc[rr] = 1.0;
+      if (apply) cz[rr] *= sc;
+    }
   }
 }
 
@@ -253,52 +265,55 @@ __global__ __launch_bounds__(JAC_NT) void jacobi_rows_kernel(JacobiArgs a) {
     return;
   }
   const int RB = a.RB;                       // rows per block (even, <= 32)
-  const int ldx = N;                         // LDS row stride
-  double* Xs = lds;                          // [2*RB][ldx]: slots [0,RB) = A, [RB,2RB) = B
-  double* sq = Xs + 2 * RB * ldx;            // [2*RB] true squared norms
-  double* dsc = sq + 2 * RB;                 // [2*RB] fast-rotation scale of each LDS row
-  double* idsc = dsc + 2 * RB;               // [2*RB] its inverse
+  constexpr int LDX = JAC_LPR * EPL;         // LDS row stride (zero padded)
+  const int NROW = 2 * RB + 2;               // + a dummy zero tile for idle slots
+  double* Xs = lds;                          // [NROW][LDX]: [0,RB) = A, [RB,2RB) = B
+  double* sq = Xs + NROW * LDX;              // [NROW] true squared norms
+  double* dsc = sq + NROW;                   // [NROW] fast-rotation scale of each LDS row
+  double* idsc = dsc + NROW;                 // [NROW] its inverse
+  double* cz = idsc + NROW;                  // [NROW] carried entry (column n of the row)
   const double tol = sqrt((double)n) * 2.220446049250313e-16;
   const double tol2 = tol * tol;
   const int nb = (n + RB - 1) / RB;          // row blocks (last may be partial: zero rows)
   const int NT2 = RB / 2;                    // 2-row tiles per block (<= 16 = JAC_SLOTS)
+  const int DUMMY = 2 * RB;                  // rows 2RB, 2RB+1: zeros, norm 0 -> never rotated
   BlockRegs<EPL> pre;
+  for (int e = tid; e < 2 * LDX; e += JAC_NT) Xs[DUMMY * LDX + e] = 0.0;
+  if (tid < 2) { sq[DUMMY + tid] = 0.0; dsc[DUMMY + tid] = 1.0; idsc[DUMMY + tid] = 1.0; cz[DUMMY + tid] = 0.0; }
 
-  struct RowSt { double a, d, id; };
-  auto st_load = [&](int row, bool valid) -> RowSt {
+  auto st_load = [&](int row) -> RowSt {
     RowSt r;
-    r.a = valid ? sq[row] : 0.0;
-    r.d = valid ? dsc[row] : 1.0;
-    r.id = valid ? idsc[row] : 1.0;
+    r.a = sq[row]; r.d = dsc[row]; r.id = idsc[row]; r.c = cz[row];
     return r;
   };
-  auto st_store = [&](int row, const RowSt& r) { sq[row] = r.a; dsc[row] = r.d; idsc[row] = r.id; };
+  auto st_store = [&](int row, const RowSt& r) {
+    sq[row] = r.a; dsc[row] = r.d; idsc[row] = r.id; cz[row] = r.c;
+  };
 
-  // all pairs between the two 2-row tiles at LDS rows (ta, ta+1) and (tb, tb+1);
+  // all pairs between the two 2-row tiles at LDS rows (ra, ra+1) and (rb, rb+1);
   // `within` adds the pair inside each tile (done once per sweep per tile).
-  auto tile_pair = [&](int ta, int tb, bool valid, bool within) -> int {
+  // Idle slots pass the dummy tile for both (zero norms: nothing happens).
+  auto tile_pair = [&](int ra, int rb, bool within) -> int {
     double u0[EPL], u1[EPL], v0[EPL], v1[EPL];
-    const int ra = valid ? ta : 0, rb = valid ? tb : 0;
-    row_load<EPL>(u0, Xs + ra * ldx, N, l);
-    row_load<EPL>(u1, Xs + (ra + 1) * ldx, N, l);
-    row_load<EPL>(v0, Xs + rb * ldx, N, l);
-    row_load<EPL>(v1, Xs + (rb + 1) * ldx, N, l);
-    RowSt A0 = st_load(ra, valid), A1 = st_load(ra + 1, valid);
-    RowSt B0 = st_load(rb, valid), B1 = st_load(rb + 1, valid);
+    row_load<EPL>(u0, Xs + ra * LDX, l);
+    row_load<EPL>(u1, Xs + (ra + 1) * LDX, l);
+    row_load<EPL>(v0, Xs + rb * LDX, l);
+    row_load<EPL>(v1, Xs + (rb + 1) * LDX, l);
+    RowSt A0 = st_load(ra), A1 = st_load(ra + 1), B0 = st_load(rb), B1 = st_load(rb + 1);
     int rot = 0;
     if (within) {
-      rot |= rot_regs<EPL>(u0, u1, A0.a, A1.a, A0.d, A0.id, A1.d, A1.id, n, tol2, l);
-      rot |= rot_regs<EPL>(v0, v1, B0.a, B1.a, B0.d, B0.id, B1.d, B1.id, n, tol2, l);
+      rot |= rot_regs<EPL>(u0, u1, A0, A1, tol2);
+      rot |= rot_regs<EPL>(v0, v1, B0, B1, tol2);
     }
-    rot |= rot_regs<EPL>(u0, v0, A0.a, B0.a, A0.d, A0.id, B0.d, B0.id, n, tol2, l);
-    rot |= rot_regs<EPL>(u1, v1, A1.a, B1.a, A1.d, A1.id, B1.d, B1.id, n, tol2, l);
-    rot |= rot_regs<EPL>(u0, v1, A0.a, B1.a, A0.d, A0.id, B1.d, B1.id, n, tol2, l);
-    rot |= rot_regs<EPL>(u1, v0, A1.a, B0.a, A1.d, A1.id, B0.d, B0.id, n, tol2, l);
-    if (valid && rot) {
-      row_store<EPL>(u0, Xs + ra * ldx, N, l);
-      row_store<EPL>(u1, Xs + (ra + 1) * ldx, N, l);
-      row_store<EPL>(v0, Xs + rb * ldx, N, l);
-      row_store<EPL>(v1, Xs + (rb + 1) * ldx, N, l);
+    rot |= rot_regs<EPL>(u0, v0, A0, B0, tol2);
+    rot |= rot_regs<EPL>(u1, v1, A1, B1, tol2);
+    rot |= rot_regs<EPL>(u0, v1, A0, B1, tol2);
+    rot |= rot_regs<EPL>(u1, v0, A1, B0, tol2);
+    if (rot) {
+      row_store<EPL>(u0, Xs + ra * LDX, l);
+      row_store<EPL>(u1, Xs + (ra + 1) * LDX, l);
+      row_store<EPL>(v0, Xs + rb * LDX, l);
+      row_store<EPL>(v1, Xs + (rb + 1) * LDX, l);
       if (l == 0) { st_store(ra, A0); st_store(ra + 1, A1); st_store(rb, B0); st_store(rb + 1, B1); }
     }
     return rot;
@@ -312,14 +327,14 @@ __global__ __launch_bounds__(JAC_NT) void jacobi_rows_kernel(JacobiArgs a) {
     if (NT2 < 2) {                           // RB == 2: a block is a single tile
       const bool valid = (slot == 0 && doA) || (slot == 1 && doB);
       double u0[EPL], u1[EPL];
-      const int r0 = (slot == 1) ? RB : 0;
-      row_load<EPL>(u0, Xs + r0 * ldx, N, l);
-      row_load<EPL>(u1, Xs + (r0 + 1) * ldx, N, l);
-      RowSt A0 = st_load(r0, valid), A1 = st_load(r0 + 1, valid);
-      rot = rot_regs<EPL>(u0, u1, A0.a, A1.a, A0.d, A0.id, A1.d, A1.id, n, tol2, l);
-      if (valid && rot) {
-        row_store<EPL>(u0, Xs + r0 * ldx, N, l);
-        row_store<EPL>(u1, Xs + (r0 + 1) * ldx, N, l);
+      const int r0 = valid ? ((slot == 1) ? RB : 0) : DUMMY;
+      row_load<EPL>(u0, Xs + r0 * LDX, l);
+      row_load<EPL>(u1, Xs + (r0 + 1) * LDX, l);
+      RowSt A0 = st_load(r0), A1 = st_load(r0 + 1);
+      rot = rot_regs<EPL>(u0, u1, A0, A1, tol2);
+      if (rot) {
+        row_store<EPL>(u0, Xs + r0 * LDX, l);
+        row_store<EPL>(u1, Xs + (r0 + 1) * LDX, l);
         if (l == 0) { st_store(r0, A0); st_store(r0 + 1, A1); }
       }
       __syncthreads();
@@ -334,7 +349,7 @@ __global__ __launch_bounds__(JAC_NT) void jacobi_rows_kernel(JacobiArgs a) {
       rr_pair(np2, r, li < np2 / 2 ? li : 0, p, q);
       if (p >= NT2 || q >= NT2) valid = false;     // dummy tile (odd NT2)
       const int off = inA ? 0 : RB;
-      rot |= tile_pair(off + 2 * p, off + 2 * q, valid, r == 0);
+      rot |= tile_pair(valid ? off + 2 * p : DUMMY, valid ? off + 2 * q : DUMMY, r == 0);
       __syncthreads();
     }
     return rot;
@@ -344,34 +359,36 @@ __global__ __launch_bounds__(JAC_NT) void jacobi_rows_kernel(JacobiArgs a) {
   // slot s keeps A tile s in registers; B tile (s + r) mod NT2 visits it in round r.
   auto cross = [&]() -> int {
     const bool valid = slot < NT2;
-    const int ra = valid ? 2 * slot : 0;
+    const int ra = valid ? 2 * slot : DUMMY;
     double u0[EPL], u1[EPL];
-    row_load<EPL>(u0, Xs + ra * ldx, N, l);
-    row_load<EPL>(u1, Xs + (ra + 1) * ldx, N, l);
-    RowSt A0 = st_load(ra, valid), A1 = st_load(ra + 1, valid);
+    row_load<EPL>(u0, Xs + ra * LDX, l);
+    row_load<EPL>(u1, Xs + (ra + 1) * LDX, l);
+    RowSt A0 = st_load(ra), A1 = st_load(ra + 1);
     int rotA = 0;
+    int tb = slot;                           // B tile index, advances by one per round
     for (int r = 0; r < NT2; ++r) {
-      const int rb = valid ? RB + 2 * ((slot + r) % NT2) : RB;
+      const int rb = valid ? RB + 2 * tb : DUMMY;
+      tb = (tb + 1 == NT2) ? 0 : tb + 1;
       double v0[EPL], v1[EPL];
-      row_load<EPL>(v0, Xs + rb * ldx, N, l);
-      row_load<EPL>(v1, Xs + (rb + 1) * ldx, N, l);
-      RowSt B0 = st_load(rb, valid), B1 = st_load(rb + 1, valid);
+      row_load<EPL>(v0, Xs + rb * LDX, l);
+      row_load<EPL>(v1, Xs + (rb + 1) * LDX, l);
+      RowSt B0 = st_load(rb), B1 = st_load(rb + 1);
       int rr = 0;
-      rr |= rot_regs<EPL>(u0, v0, A0.a, B0.a, A0.d, A0.id, B0.d, B0.id, n, tol2, l);
-      rr |= rot_regs<EPL>(u1, v1, A1.a, B1.a, A1.d, A1.id, B1.d, B1.id, n, tol2, l);
-      rr |= rot_regs<EPL>(u0, v1, A0.a, B1.a, A0.d, A0.id, B1.d, B1.id, n, tol2, l);
-      rr |= rot_regs<EPL>(u1, v0, A1.a, B0.a, A1.d, A1.id, B0.d, B0.id, n, tol2, l);
-      if (valid && rr) {
-        row_store<EPL>(v0, Xs + rb * ldx, N, l);
-        row_store<EPL>(v1, Xs + (rb + 1) * ldx, N, l);
+      rr |= rot_regs<EPL>(u0, v0, A0, B0, tol2);
+      rr |= rot_regs<EPL>(u1, v1, A1, B1, tol2);
+      rr |= rot_regs<EPL>(u0, v1, A0, B1, tol2);
+      rr |= rot_regs<EPL>(u1, v0, A1, B0, tol2);
+      if (rr) {
+        row_store<EPL>(v0, Xs + rb * LDX, l);
+        row_store<EPL>(v1, Xs + (rb + 1) * LDX, l);
         if (l == 0) { st_store(rb, B0); st_store(rb + 1, B1); }
       }
       rotA |= rr;
       __syncthreads();
     }
-    if (valid && rotA) {
-      row_store<EPL>(u0, Xs + ra * ldx, N, l);
-      row_store<EPL>(u1, Xs + (ra + 1) * ldx, N, l);
+    if (rotA) {
+      row_store<EPL>(u0, Xs + ra * LDX, l);
+      row_store<EPL>(u1, Xs + (ra + 1) * LDX, l);
       if (l == 0) { st_store(ra, A0); st_store(ra + 1, A1); }
     }
     __syncthreads();
@@ -381,43 +398,43 @@ __global__ __launch_bounds__(JAC_NT) void jacobi_rows_kernel(JacobiArgs a) {
   int sweep = 0;
   if (nb <= 2) {
     // ---- everything fits: load once, full sweeps in LDS ---------------------
-    block_fetch<EPL>(pre, X, ld, n, N, 0, RB, w, lane);
-    block_commit<EPL>(pre, Xs, ldx, N, 0, RB, w, lane);
-    block_fetch<EPL>(pre, X, ld, n, N, RB, RB, w, lane);
-    block_commit<EPL>(pre, Xs, ldx, N, RB, RB, w, lane);
+    block_fetch<EPL>(pre, X, ld, n, 0, RB, w, lane);
+    block_commit<EPL>(pre, Xs, cz, 0, RB, w, lane);
+    block_fetch<EPL>(pre, X, ld, n, RB, RB, w, lane);
+    block_commit<EPL>(pre, Xs, cz, RB, RB, w, lane);
     __syncthreads();
     for (; sweep < a.max_sweeps;) {
       // (re)compute the true norms; from the 2nd sweep on first fold the scales in
-      block_norms<EPL>(Xs, sq, dsc, idsc, ldx, n, N, 0, 2 * RB, slot, l, sweep > 0);
+      block_norms<EPL>(Xs, cz, sq, dsc, idsc, 0, 2 * RB, slot, l, sweep > 0);
       __syncthreads();
       int rotated = intra(true, nb == 2);
       if (nb == 2) rotated |= cross();
       ++sweep;
       if (!block_or(rotated & 2, red)) break;   // quadratic convergence: what was rotated is done
     }
-    block_store<EPL>(X, ld, n, N, 0, Xs, dsc, ldx, 0, RB, w, lane);
-    block_store<EPL>(X, ld, n, N, RB, Xs, dsc, ldx, RB, RB, w, lane);
+    block_store<EPL>(X, ld, n, 0, Xs, cz, dsc, 0, RB, w, lane);
+    block_store<EPL>(X, ld, n, RB, Xs, cz, dsc, RB, RB, w, lane);
   } else {
-    // ---- block-cyclic sweeps: A resident, partners B streamed (prefetched) --
+    // ---- block-cyclic sweeps: A resident, partners B streamed ---------------
     for (; sweep < a.max_sweeps;) {
       int rotated = 0;
       for (int A = 0; A + 1 < nb; ++A) {
-        block_fetch<EPL>(pre, X, ld, n, N, A * RB, RB, w, lane);
-        block_commit<EPL>(pre, Xs, ldx, N, 0, RB, w, lane);
+        block_fetch<EPL>(pre, X, ld, n, A * RB, RB, w, lane);
+        block_commit<EPL>(pre, Xs, cz, 0, RB, w, lane);
         for (int Bk = A + 1; Bk < nb; ++Bk) {
-          block_fetch<EPL>(pre, X, ld, n, N, Bk * RB, RB, w, lane);
-          block_commit<EPL>(pre, Xs, ldx, N, RB, RB, w, lane);
+          block_fetch<EPL>(pre, X, ld, n, Bk * RB, RB, w, lane);
+          block_commit<EPL>(pre, Xs, cz, RB, RB, w, lane);
           __syncthreads();
-          if (Bk == A + 1) block_norms<EPL>(Xs, sq, dsc, idsc, ldx, n, N, 0, RB, slot, l, false);
-          block_norms<EPL>(Xs, sq, dsc, idsc, ldx, n, N, RB, RB, slot, l, false);
+          if (Bk == A + 1) block_norms<EPL>(Xs, cz, sq, dsc, idsc, 0, RB, slot, l, false);
+          block_norms<EPL>(Xs, cz, sq, dsc, idsc, RB, RB, slot, l, false);
           __syncthreads();
           if (Bk == A + 1) rotated |= intra(A == 0, true);  // each block once per sweep
           rotated |= cross();
-          block_store<EPL>(X, ld, n, N, Bk * RB, Xs, dsc, ldx, RB, RB, w, lane);
+          block_store<EPL>(X, ld, n, Bk * RB, Xs, cz, dsc, RB, RB, w, lane);
           __threadfence_block();
           __syncthreads();
         }
-        block_store<EPL>(X, ld, n, N, A * RB, Xs, dsc, ldx, 0, RB, w, lane);
+        block_store<EPL>(X, ld, n, A * RB, Xs, cz, dsc, 0, RB, w, lane);
         __threadfence_block();
         __syncthreads();
       }
@@ -448,9 +465,9 @@ __global__ __launch_bounds__(JAC_NT) void jacobi_rows_kernel(JacobiArgs a) {
   }
 }
 
-// rows per LDS block for row length N (even, <= 32, 2*RB*N doubles <= ~150 KB)
-int jacobi_block_rows(int N) {
-  int rb = (int)((150 * 1024) / (16 * (size_t)N));
+// rows per LDS block for LDS row stride ldx doubles (even, <= 32; 2*RB+2 rows <= ~156 KB)
+int jacobi_block_rows(int ldx) {
+  int rb = (int)(((156 * 1024) / (8 * (size_t)ldx) - 2) / 2);
   if (rb > 32) rb = 32;
   rb &= ~1;
   if (rb < 2) rb = 2;
@@ -470,17 +487,23 @@ static hipError_t launch_jacobi_t(const JacobiArgs& a, int B, size_t lds, hipStr
   return hipGetLastError();
 }
 
-hipError_t launch_jacobi(const JacobiArgs& a_in, int B, hipStream_t st) {
-  JacobiArgs a = a_in;
-  a.RB = jacobi_block_rows(a.N);
-  const size_t lds = sizeof(double) * ((size_t)2 * a.RB * a.N + 6 * a.RB);
-  const int epl = (a.N + JAC_LPR - 1) / JAC_LPR;
-  if (epl <= 1) return launch_jacobi_t<1>(a, B, lds, st);
-  if (epl <= 3) return launch_jacobi_t<3>(a, B, lds, st);
-  if (epl <= 5) return launch_jacobi_t<5>(a, B, lds, st);
-  if (epl <= 9) return launch_jacobi_t<9>(a, B, lds, st);
-  if (epl <= 17) return launch_jacobi_t<17>(a, B, lds, st);
-  return launch_jacobi_t<34>(a, B, lds, st);
+template <int EPL>
+static hipError_t launch_jacobi_e(JacobiArgs a, int B, hipStream_t st) {
+  const int ldx = JAC_LPR * EPL;
+  a.RB = jacobi_block_rows(ldx);
+  const size_t nrow = 2 * (size_t)a.RB + 2;
+  const size_t lds = sizeof(double) * (nrow * ldx + 4 * nrow);
+  return launch_jacobi_t<EPL>(a, B, lds, st);
+}
+
+hipError_t launch_jacobi(const JacobiArgs& a, int B, hipStream_t st) {
+  const int epl = (a.N - 1 + JAC_LPR - 1) / JAC_LPR;      // row length n = N - 1
+  if (epl <= 1) return launch_jacobi_e<1>(a, B, st);
+  if (epl <= 2) return launch_jacobi_e<2>(a, B, st);
+  if (epl <= 4) return launch_jacobi_e<4>(a, B, st);
+  if (epl <= 8) return launch_jacobi_e<8>(a, B, st);
+  if (epl <= 17) return launch_jacobi_e<17>(a, B, st);
+  return launch_jacobi_e<34>(a, B, st);
 }
 
 }  // namespace blsq
