@@ -40,6 +40,26 @@ def alg_flops_trf(m, n):    # R-SVD count + GEMV terms
     return 2 * (m + n) * n * n + 11 * n ** 3 + 6 * (m + n) * n
 
 
+def measured_traffic(kernel, m, n, B):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary
+    (profiles/hbm_traffic_latest.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes,
+    gfx950 correction per MI355X_MICROARCH.md) when it was collected for this exact
+    workload; None otherwise (bench.py itself cannot collect PMC counters)."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
+    try:
+        with open(path) as fh:
+            t = json.load(fh)
+        cfg = t.get("config", {})
+        if (cfg.get("m"), cfg.get("n"), cfg.get("batch")) != (m, n, B):
+            return None
+        for name, v in t["kernels"].items():
+            if kernel.split("_")[0] in name:
+                return v["hbm_bytes"]
+    except Exception:
+        pass
+    return None
+
+
 def make_deltas(B):
     """Half 'reflective' (Delta=10: Gauss-Newton step, reflection branch) and
     half 'feasible' (Delta=0.5: More' iterations) as SURVEY.md 8(d) asks."""
@@ -159,14 +179,19 @@ def main():
         cpu = cpu_baseline(P, Delta)              # before any GPU initialisation (fork)
 
     dist = None
+    backend = os.environ.get("BLSQ_DIST_BACKEND", "nccl")     # "gloo": rehearsal on one GPU
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from bounded_lsq import TrfStepSolver, _abi
-    ctx = _abi.Context(local_rank)
+    ndev = max(1, _abi.load().blsq_device_count())
+    ctx = _abi.Context(local_rank % ndev)
     sol = TrfStepSolver(B, m, n, ctx=ctx)
     d = {k: ctx.to_device(P[k]) for k in ("J", "f", "x", "lb", "ub", "scale")}
     dDelta = ctx.to_device(Delta)
@@ -180,9 +205,11 @@ def main():
         ctx.sync()
         if dist is not None:
             import torch
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         one_step()
@@ -198,7 +225,8 @@ def main():
     ctx.timing(False)
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -245,7 +273,8 @@ def main():
                        "m": m, "n": n, "batch_per_gpu": B, "sharding": "by problem, no collective"},
             "roofline": {
                 "bound": "mfma", "achieved": achieved_tf, "peak": PEAK_FP64_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved_tf / PEAK_FP64_TFLOPS, "traffic": None,
+                "unit": "TFLOP/s", "frac": achieved_tf / PEAK_FP64_TFLOPS,
+                "traffic": measured_traffic(dom, m, n, B),
                 "kernel": dom, "kernel_ms_per_step": per_step_ms[dom],
                 "alg_flops_per_solve": alg_flops_trf(m, n),
                 "alg_bytes_per_solve": alg_bytes_trf(m, n),
