@@ -36,8 +36,8 @@
 
 namespace blsq {
 
-static constexpr int JAC_NT = 512;
-static constexpr int JAC_LPR = 32;                // lanes per row
+static constexpr int JAC_NT = 256;
+static constexpr int JAC_LPR = 16;                // lanes per row (4 row pairs per wave-instruction)
 static constexpr int JAC_SLOTS = JAC_NT / JAC_LPR; // 16 concurrent tile slots
 static constexpr int JAC_NW = JAC_NT / 64;
 
@@ -48,6 +48,11 @@ __device__ __forceinline__ double row32_sum(double v) {
   lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F);   // bit mode: lane ^ 16
   hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
   return v + __hiloint2double(hi, lo);
+}
+
+// sum over the JAC_LPR lanes that share a row
+__device__ __forceinline__ double row_sum(double v) {
+  return (JAC_LPR == 16) ? row16_sum(v) : row32_sum(v);
 }
 
 __device__ __forceinline__ double fast_rcp(double d) {
@@ -84,7 +89,7 @@ __device__ __forceinline__ int rot_regs(double (&u)[EPL], double (&v)[EPL], RowS
   for (int k = 0; k < EPL; ++k) {
     if (k & 1) g1 = fma(u[k], v[k], g1); else g0 = fma(u[k], v[k], g0);
   }
-  const double g = row32_sum(g0 + g1) * (U.d * V.d);
+  const double g = row_sum(g0 + g1) * (U.d * V.d);
   const double a = U.a, b = V.a;
   if (!(a > 0.0 && b > 0.0 && g * g > tol2 * a * b)) return 0;
   // cos^2 > 1e-16 (|cos| > 1e-8): after this rotation the pair is NOT yet guaranteed to be
@@ -146,15 +151,16 @@ __device__ __forceinline__ void rr_pair(int np, int r, int i, int& p, int& q) {
 template <int EPL>
 struct BlockRegs {
   static constexpr int CH = (JAC_LPR * EPL + 63) / 64;
-  double t[4][CH];
-  double c[4];
+  static constexpr int RPW = 32 / JAC_NW;      // rows of a 32-row block per wave
+  double t[RPW][CH];
+  double c[RPW];
 };
 
 template <int EPL>
 __device__ __forceinline__ void block_fetch(BlockRegs<EPL>& R, const double* X, int ld, int n,
                                             int g0, int RB, int w, int lane) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < BlockRegs<EPL>::RPW; ++j) {
     const int r = w + JAC_NW * j;
     const int gr = g0 + r;
     const bool rok = (r < RB) && (gr < n);
@@ -174,7 +180,7 @@ __device__ __forceinline__ void block_commit(const BlockRegs<EPL>& R, double* Xs
                                              int s0, int RB, int w, int lane) {
   constexpr int LDX = JAC_LPR * EPL;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < BlockRegs<EPL>::RPW; ++j) {
     const int r = w + JAC_NW * j;
     if (r < RB) {
       double* dst = Xs + (s0 + r) * LDX;
@@ -192,10 +198,10 @@ __device__ __forceinline__ void block_store(double* X, int ld, int n, int g0, co
                                             const double* cz, const double* dsc, int s0, int RB,
                                             int w, int lane) {
   constexpr int LDX = JAC_LPR * EPL;
-  double t[4][BlockRegs<EPL>::CH];
-  double tc[4];
+  double t[BlockRegs<EPL>::RPW][BlockRegs<EPL>::CH];
+  double tc[BlockRegs<EPL>::RPW];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < BlockRegs<EPL>::RPW; ++j) {
     const int r = w + JAC_NW * j;
     const int rr = s0 + (r < RB ? r : 0);
     const double* src = Xs + rr * LDX;
@@ -208,7 +214,7 @@ __device__ __forceinline__ void block_store(double* X, int ld, int n, int g0, co
     tc[j] = cz[rr] * sc;
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < BlockRegs<EPL>::RPW; ++j) {
     const int r = w + JAC_NW * j;
     const int gr = g0 + r;
     if (r < RB && gr < n) {
@@ -241,7 +247,7 @@ __device__ __forceinline__ void block_norms(double* Xs, double* cz, double* sq, 
       if (apply && r < cnt) src[l + JAC_LPR * k] = v;
       acc = fma(v, v, acc);
     }
-    acc = row32_sum(acc);
+    acc = row_sum(acc);
     if (r < cnt && l == 0) {
       sq[rr] = acc; dsc[rr] = 1.0; idsc[rr] = 1.0;
       if (apply) cz[rr] *= sc;
@@ -502,8 +508,9 @@ hipError_t launch_jacobi(const JacobiArgs& a, int B, hipStream_t st) {
   if (epl <= 2) return launch_jacobi_e<2>(a, B, st);
   if (epl <= 4) return launch_jacobi_e<4>(a, B, st);
   if (epl <= 8) return launch_jacobi_e<8>(a, B, st);
-  if (epl <= 17) return launch_jacobi_e<17>(a, B, st);
-  return launch_jacobi_e<34>(a, B, st);
+  if (epl <= 16) return launch_jacobi_e<16>(a, B, st);
+  if (epl <= 34) return launch_jacobi_e<34>(a, B, st);
+  return launch_jacobi_e<68>(a, B, st);
 }
 
 }  // namespace blsq
