@@ -83,9 +83,14 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
 
   const long slot = (long)b * gridDim.x + leaf;
   double* Rout = q.Rout + slot * (long)NPAD * NPAD;
-  if (N <= 0) return;                       // uniform per workgroup
-  const int NP = (N + TILE - 1) / TILE;
-  const int nA = q.F ? N - 1 : N;           // columns taken from A
+  if (N <= 1) return;                       // uniform per workgroup
+  // The LAST logical column is always the right-hand side (f, or column N-1 of a
+  // stacked source).  It is not factored: every thread keeps its rows of it in
+  // registers and applies each block reflector to it right after the panel is
+  // done (O(16 m) VALU work per panel instead of a 16-column MFMA panel pass).
+  const int nc = N - 1;                     // columns to factor
+  const int NP = (nc + TILE - 1) / TILE;
+  const int nA = nc;                        // columns taken from A
   const int r0 = leaf * q.rows_per_leaf;
   int nrows = q.rowsA - r0;
   if (nrows > q.rows_per_leaf) nrows = q.rows_per_leaf;
@@ -101,6 +106,17 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) ident[s] = (lc == 4 * s + lr) ? 1.0 : 0.0;
 
+  // right-hand side rows owned by this thread (rows tid + 512 r)
+  double fr[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int row = tid + r * QR_NT;
+    const int rc = (nrows > 0) ? (row < nrows ? row : nrows - 1) : 0;
+    double val = 0.0;
+    if (nrows > 0) val = F ? F[rc] : A[(long)rc * q.ldA + nc];
+    fr[r] = (row < nrows) ? val : 0.0;
+  }
+
   STAMP_DECL
   for (int k = 0; k < NP; ++k) {
     // ---- 1. stage panel k of the source into LDS (single HBM read) --------
@@ -108,10 +124,9 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
     // flight per thread: a guarded load would serialise into branch+load+wait.
     {
       const int total = RP * 16;
-      const bool fpanel = (F != nullptr) && (nA >= k * TILE) && (nA < k * TILE + TILE);
       const int rmax = nrows > 0 ? nrows - 1 : 0;
       for (int i0 = 0; i0 < total; i0 += 8 * QR_NT) {
-        double tmp[8], tf[8];
+        double tmp[8];
 #pragma unroll
         for (int uu = 0; uu < 8; ++uu) {
           const int idx = i0 + uu * QR_NT + tid;
@@ -120,18 +135,13 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
           const int rc = row < rmax ? row : rmax;
           const int cc = col < nA ? col : (nA > 0 ? nA - 1 : 0);
           tmp[uu] = (nrows > 0 && nA > 0) ? A[(long)rc * q.ldA + cc] : 0.0;
-          tf[uu] = fpanel ? F[rc] : 0.0;
         }
 #pragma unroll
         for (int uu = 0; uu < 8; ++uu) {
           const int idx = i0 + uu * QR_NT + tid;
           const int row = idx >> 4, c = idx & 15;
           const int col = k * TILE + c;
-          double val = 0.0;
-          if (row < nrows) {
-            if (col < nA) val = tmp[uu];
-            else if (col == nA && F) val = tf[uu];
-          }
+          const double val = (row < nrows && col < nA) ? tmp[uu] : 0.0;
           if (idx < total) P[c * LDP + row] = val;
         }
       }
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
 #pragma unroll 1
     for (int c = 0; c < TILE; ++c) {
       const int p = base + c;               // pivot row == global column
-      if (!(p < N && p < RP)) {             // padding column: H = I (uniform)
+      if (!(p < nc && p < RP)) {            // padding column: H = I (uniform)
         if (tid == 0) taus[c] = 0.0;
         continue;
       }
@@ -320,7 +330,6 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
       }
     }
     STAMP(3)
-    if (k == NP - 1) break;                 // no later panel needs V_k / T_k
     __syncthreads();
 
     // ---- 5. make V_k explicit (unit lower trapezoid, zeros above) ---------
@@ -375,7 +384,7 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
     }
     STAMP(4)
     // ---- 7. spill V_k (tile-contiguous: [row][16]) for later panels -------
-    {
+    if (k < NP - 1) {
       double* Vk = V + (long)k * RP * 16;
       for (int idx = tid; idx < RP * 16; idx += QR_NT) {
         const int row = idx >> 4, c = idx & 15;
@@ -385,6 +394,52 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
     __threadfence_block();
     __syncthreads();
     STAMP(5)
+
+    // ---- 8. right-hand side:  f -= V_k (T_k^T (V_k^T f))  ------------------
+    {
+      double vk[NR][TILE];
+#pragma unroll
+      for (int c = 0; c < TILE; ++c) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const double val = P[c * LDP + rci[r]];
+          vk[r][c] = (rowi[r] < RP) ? val : 0.0;      // rows past the leaf must stay inert
+        }
+      }
+      double part[TILE];
+#pragma unroll
+      for (int c = 0; c < TILE; ++c) {
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc = fma(vk[r][c], fr[r], acc);
+        part[c] = acc;
+      }
+      wave_sum16(part);
+      double* ex = xch;
+      if (lane < TILE) ex[w * 16 + wave_sum16_index(lane)] = part[0];
+      __syncthreads();
+      double wl = 0.0;                       // lane i (mod 16): (V_k^T f)_i
+#pragma unroll
+      for (int ww = 0; ww < QR_NW; ++ww) wl += ex[ww * 16 + lc];
+      const double* Ts = Wred;               // T_k rows, left there by step 6
+      double zl = 0.0;                       // lane c: (T_k^T w)_c = sum_i T[i][c] w_i
+#pragma unroll
+      for (int i = 0; i < TILE; ++i) zl = fma(Ts[i * TILE + lc], read_lane(wl, i), zl);
+#pragma unroll
+      for (int c = 0; c < TILE; ++c) {
+        const double zc = read_lane(zl, c);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) fr[r] = fma(-vk[r][c], zc, fr[r]);
+      }
+      __syncthreads();                       // ex / Wred / P are rewritten by the next panel
+    }
+    STAMP(5)
+  }
+  // rhs column of the triangle: c = (Q^T f)[0:nc]; rows >= nc are not needed downstream
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int row = tid + r * QR_NT;
+    if (row < NPAD) Rout[(long)row * NPAD + nc] = (row < nc && row < RP) ? fr[r] : 0.0;
   }
   STAMP_OUT
 }

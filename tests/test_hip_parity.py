@@ -112,7 +112,9 @@ def test_dogbox_golden(bl, name, ins, out):
     sol.close()
 
 
-@pytest.mark.parametrize("B,m,n", [(16, 512, 64), (5, 200, 37), (3, 1500, 20), (2, 4096, 256)])
+@pytest.mark.parametrize("B,m,n", [(16, 512, 64), (5, 200, 37), (3, 1500, 20), (2, 4096, 256),
+                                   (2, 2500, 50), (3, 1100, 17), (4, 700, 100), (2, 5000, 33),
+                                   (2, 3000, 200), (6, 90, 5), (2, 1089, 16)])
 def test_trf_batch_vs_oracle(bl, B, m, n):
     from oracle import blsq_oracle as orc
     from bounded_lsq import _synth
@@ -132,7 +134,8 @@ def test_trf_batch_vs_oracle(bl, B, m, n):
     sol.close()
 
 
-@pytest.mark.parametrize("B,m,n", [(16, 512, 64), (5, 200, 37), (2, 4096, 256)])
+@pytest.mark.parametrize("B,m,n", [(16, 512, 64), (5, 200, 37), (2, 4096, 256), (3, 1500, 20),
+                                   (2, 2500, 50), (4, 700, 100), (6, 90, 5)])
 def test_dogbox_batch_vs_oracle(bl, B, m, n):
     from oracle import blsq_oracle as orc
     from bounded_lsq import _synth
