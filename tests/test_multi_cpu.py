@@ -63,9 +63,13 @@ open(os.path.join(%(out)r, "rank%%d.ok" %% rank), "w").write("ok")
 def test_triangle_allgather_gloo_world2(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT, "out": str(tmp_path)})
+    import socket
+    with socket.socket() as sk:                    # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
