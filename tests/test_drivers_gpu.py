@@ -179,3 +179,67 @@ def test_fun_and_jac_shape_errors():                       # :171-199
         least_squares(fun_trivial, 2.0, jac=lambda x: np.ones((1, 1, 1)))
     with pytest.raises(RuntimeError):                       # m mismatch (trf.py:209-211)
         least_squares(lambda x: np.ones(3), [2.0, 1.0], jac=lambda x: np.ones((2, 2)))
+
+
+# ---- batched front-end: every problem must match its own sequential solve -------
+def _expfit_batch(B, m=40):
+    t = np.linspace(0, 4, m)
+    ys = []
+    for b in range(B):
+        rng = np.random.default_rng(100 + b)
+        truth = np.array([2.0 + 0.1 * b, -0.7 + 0.02 * b, 0.5, 0.3 + 0.01 * b])
+        y = truth[0] * np.exp(truth[1] * t) + truth[2] * np.cos(truth[3] * t)
+        ys.append(y + 0.01 * rng.standard_normal(m))
+    Y = np.array(ys)
+
+    def fun(P):
+        P = np.atleast_2d(P)
+        return (P[:, 0:1] * np.exp(P[:, 1:2] * t) + P[:, 2:3] * np.cos(P[:, 3:4] * t)) - Y[:P.shape[0]]
+
+    def jac(P):
+        P = np.atleast_2d(P)
+        e = np.exp(P[:, 1:2] * t)
+        return np.stack([e, P[:, 0:1] * t * e, np.cos(P[:, 3:4] * t),
+                         -P[:, 2:3] * t * np.sin(P[:, 3:4] * t)], axis=2)
+    return fun, jac, Y, t
+
+
+@pytest.mark.parametrize("method", ["trf", "dogbox"])
+@pytest.mark.parametrize("scaling", [1.0, "jac"])
+@pytest.mark.parametrize("bounded", [False, True])
+def test_least_squares_batch_matches_sequential(method, scaling, bounded):
+    from bounded_lsq import least_squares, least_squares_batch
+    B = 10
+    fun, jac, Y, t = _expfit_batch(B)
+    X0 = np.tile(np.array([1.0, -0.1, 1.0, 1.0]), (B, 1))
+    X0[:, 0] += 0.05 * np.arange(B)
+    bounds = (np.array([0.0, -2.0, 0.0, 0.0]), np.array([1.8, 0.0, 3.0, 2.0])) if bounded \
+        else (-np.inf, np.inf)
+    res = least_squares_batch(fun, X0, jac, bounds=bounds, method=method, scaling=scaling)
+    assert len(res) == B
+    for b in range(B):
+        def fun_b(p, b=b):
+            return p[0] * np.exp(p[1] * t) + p[2] * np.cos(p[3] * t) - Y[b]
+
+        def jac_b(p, b=b):
+            e = np.exp(p[1] * t)
+            return np.stack([e, p[0] * t * e, np.cos(p[3] * t), -p[2] * t * np.sin(p[3] * t)], 1)
+        ref = least_squares(fun_b, X0[b], jac_b, bounds=bounds, method=method, scaling=scaling)
+        r = res[b]
+        assert (r.nfev, r.njev, r.status) == (ref.nfev, ref.njev, ref.status), b
+        np.testing.assert_allclose(r.x, ref.x, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(r.obj_value, ref.obj_value, rtol=1e-9)
+        np.testing.assert_array_equal(r.active_mask, ref.active_mask)
+        assert r.success == ref.success and r.message == ref.message
+
+
+def test_least_squares_batch_validation():
+    from bounded_lsq import least_squares_batch
+    with pytest.raises(ValueError):
+        least_squares_batch(lambda X: X, np.zeros(3), lambda X: X)             # x0 not (B, n)
+    with pytest.raises(ValueError):
+        least_squares_batch(lambda X: X, np.zeros((2, 2)), lambda X: X, method='lm')
+    with pytest.raises(ValueError):
+        least_squares_batch(lambda X: X, np.zeros((2, 2)), lambda X: X, bounds=(1.0, 0.0))
+    with pytest.raises(ValueError):
+        least_squares_batch(lambda X: X, np.full((2, 2), 5.0), lambda X: X, bounds=(0.0, 1.0))
