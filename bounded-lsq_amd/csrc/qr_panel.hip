@@ -216,105 +216,109 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
     }
 
     STAMP(1)
-    // ---- 3. Householder-factor rows >= 16k of the panel in LDS ------------
-    // Each thread owns rows tid + 512 i, i < NR (RP <= 512 NR).  Per column: one
-    // fused reduction (sum x^2 and the <=15 dot products x.P[c']) through
-    // DPP/readlane wave sums + one LDS exchange + ONE barrier.  The LDS loads of a
-    // column step are unconditional (clamped) and issued together, and the loaded
-    // panel values are reused from registers for the rank-1 update.
+    // ---- 3. Householder-factor rows >= 16k of the panel --------------------
+    // Each thread owns rows tid + 512 i, i < NR (RP <= 512 NR) and keeps ITS rows of
+    // all 16 panel columns in registers for the whole factorisation (one LDS read
+    // before, one LDS write after; the column loop is fully unrolled so the
+    // register file is indexed statically).  Per column: one fused reduction (sum
+    // x^2 and the <=15 dot products x.P[c']) through a transposed DPP butterfly +
+    // one LDS exchange + ONE barrier; totals are summed lane-parallel and broadcast
+    // with v_readlane.
     const int base = k * TILE;
     int rowi[NR], rci[NR];
+    double pr[NR][TILE];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       rowi[r] = tid + r * QR_NT;
       rci[r] = rowi[r] < RP ? rowi[r] : RP - 1;
     }
-#pragma unroll 1
+#pragma unroll
+    for (int c = 0; c < TILE; ++c) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) pr[r][c] = P[c * LDP + rci[r]];
+    }
+#pragma unroll
     for (int c = 0; c < TILE; ++c) {
       const int p = base + c;               // pivot row == global column
       if (!(p < nc && p < RP)) {            // padding column: H = I (uniform)
         if (tid == 0) taus[c] = 0.0;
-        continue;
-      }
-      bool inr[NR];
-#pragma unroll
-      for (int r = 0; r < NR; ++r) inr[r] = rowi[r] > p && rowi[r] < RP;
-      const bool owner = (tid == (p % QR_NT));
-      // y[r][i] = P[column c+i (clamped to 15)][row r]; i >= 16-c is discarded later
-      double y[NR][TILE];
-#pragma unroll
-      for (int i = 0; i < TILE; ++i) {
-        const int ci = (c + i < TILE) ? c + i : TILE - 1;
-        const double* pi = P + ci * LDP;
-#pragma unroll
-        for (int r = 0; r < NR; ++r) y[r][i] = pi[rci[r]];
-      }
-      double x[NR];
-#pragma unroll
-      for (int r = 0; r < NR; ++r) x[r] = inr[r] ? y[r][0] : 0.0;
-      double* ex = xch + (c & 1) * (QR_NW * 16 + 16);
-      {
-        double part[TILE];
-#pragma unroll
-        for (int i = 0; i < TILE; ++i) {
-          double acc = 0.0;
-#pragma unroll
-          for (int r = 0; r < NR; ++r) acc = fma(x[r], (i == 0) ? x[r] : y[r][i], acc);
-          part[i] = acc;
-        }
-        wave_sum16(part);                    // all 16 totals in one transposed butterfly
-        if (lane < TILE) ex[w * 16 + wave_sum16_index(lane)] = part[0];
-      }
-      if (owner) {                          // publish the (old) pivot row: it was last
-        // written by THIS thread (previous column's update), others must not read P here
-#pragma unroll
-        for (int i = 0; i < TILE; ++i) {
-          const int ci = (c + i < TILE) ? c + i : TILE - 1;
-          ex[QR_NW * 16 + i] = P[ci * LDP + p];
-        }
-      }
-      STAMP(6)
-      __syncthreads();
-      STAMP(7)
-      // lane i (mod 16) sums the 8 wave partials of value i and reads pivot value i:
-      // 9 LDS reads per wave instead of 135 broadcast reads per thread; the results
-      // travel to all lanes through v_readlane (SGPRs).
-      double totl = 0.0;
-#pragma unroll
-      for (int ww = 0; ww < QR_NW; ++ww) totl += ex[ww * 16 + lc];
-      const double pvl = ex[QR_NW * 16 + lc];
-      const double xn2 = read_lane(totl, 0);
-      const double alpha = read_lane(pvl, 0);
-      double beta, tau, scal;
-      if (xn2 == 0.0) {
-        beta = alpha; tau = 0.0; scal = 0.0;
       } else {
-        beta = -copysign(sqrt(alpha * alpha + xn2), alpha);
-        tau = (beta - alpha) / beta;
-        scal = 1.0 / (alpha - beta);
-      }
-      const double wvl = tau * (pvl + scal * totl);      // lane i holds w_i
-      double vv[NR];
-      double* pcw = P + c * LDP;
+        bool inr[NR], own[NR];
+        double x[NR];
 #pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        vv[r] = scal * x[r];
-        if (inr[r]) pcw[rowi[r]] = vv[r];
-      }
-      if (owner) pcw[p] = beta;
-#pragma unroll
-      for (int i = 1; i < TILE; ++i) {
-        if (c + i < TILE) {                  // uniform
-          const double wv = read_lane(wvl, i);
-          const double pvi = read_lane(pvl, i);
-          double* pi = P + (c + i) * LDP;
-#pragma unroll
-          for (int r = 0; r < NR; ++r)
-            if (inr[r]) pi[rowi[r]] = y[r][i] - vv[r] * wv;
-          if (owner) pi[p] = pvi - wv;
+        for (int r = 0; r < NR; ++r) {
+          inr[r] = rowi[r] > p && rowi[r] < RP;
+          own[r] = rowi[r] == p;
+          x[r] = inr[r] ? pr[r][c] : 0.0;
         }
+        double* ex = xch + (c & 1) * (QR_NW * 16 + 16);
+        {
+          double part[TILE];
+#pragma unroll
+          for (int i = 0; i < TILE; ++i) {
+            double acc = 0.0;
+            if (c + i < TILE) {
+#pragma unroll
+              for (int r = 0; r < NR; ++r)
+                acc = fma(x[r], (i == 0) ? x[r] : pr[r][(c + i < TILE) ? c + i : 0], acc);
+            }
+            part[i] = acc;
+          }
+          wave_sum16(part);                  // all 16 totals in one transposed butterfly
+          if (lane < TILE) ex[w * 16 + wave_sum16_index(lane)] = part[0];
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          if (own[r]) {                      // the pivot row's owner publishes it
+#pragma unroll
+            for (int i = 0; i < TILE; ++i)
+              ex[QR_NW * 16 + i] = pr[r][(c + i < TILE) ? c + i : TILE - 1];
+          }
+        }
+        STAMP(6)
+        __syncthreads();
+        STAMP(7)
+        double totl = 0.0;                   // lane i (mod 16): total of value i
+#pragma unroll
+        for (int ww = 0; ww < QR_NW; ++ww) totl += ex[ww * 16 + lc];
+        const double pvl = ex[QR_NW * 16 + lc];
+        const double xn2 = read_lane(totl, 0);
+        const double alpha = read_lane(pvl, 0);
+        double beta, tau, scal;
+        if (xn2 == 0.0) {
+          beta = alpha; tau = 0.0; scal = 0.0;
+        } else {
+          beta = -copysign(sqrt(alpha * alpha + xn2), alpha);
+          tau = (beta - alpha) / beta;
+          scal = 1.0 / (alpha - beta);
+        }
+        const double wvl = tau * (pvl + scal * totl);      // lane i holds w_i
+        double vv[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          vv[r] = scal * x[r];
+          if (inr[r]) pr[r][c] = vv[r];
+          if (own[r]) pr[r][c] = beta;
+        }
+#pragma unroll
+        for (int i = 1; i < TILE; ++i) {
+          if (c + i < TILE) {
+            const double wv = read_lane(wvl, i);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+              if (inr[r]) pr[r][c + i] = fma(-vv[r], wv, pr[r][c + i]);
+              if (own[r]) pr[r][c + i] -= wv;
+            }
+          }
+        }
+        if (tid == 0) taus[c] = tau;
       }
-      if (tid == 0) taus[c] = tau;
+    }
+#pragma unroll
+    for (int c = 0; c < TILE; ++c) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+        if (rowi[r] < RP) P[c * LDP + rowi[r]] = pr[r][c];
     }
     __syncthreads();
 
