@@ -373,17 +373,24 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
       }
       __syncthreads();
       if (tid < TILE) {
-        // thread i owns row i of T:  T[i][c] = -tau_c * sum_{q=i}^{c-1} T[i][q] G[q][c]
+        // thread i owns row i of T:  T[i][c] = -tau_c * sum_{q=i}^{c-1} T[i][q] G[q][c].
+        // Fully unrolled: the row lives in registers and the (static) G / tau reads are
+        // independent of the recurrence, so they pipeline instead of serialising.
         const int i = tid;
-        double* Ts = Wred + i * TILE;         // Wred is idle until the next panel
+        double Trow[TILE];
+#pragma unroll
         for (int c = 0; c < TILE; ++c) {
           const double tc = taus[c];
           double sacc = 0.0;
-          for (int qq = i; qq < c; ++qq) sacc += Ts[qq] * Gs[qq * 16 + c];
-          Ts[c] = (i == c) ? tc : ((i < c) ? -tc * sacc : 0.0);
+#pragma unroll
+          for (int qq = 0; qq < TILE; ++qq)
+            if (qq < c) sacc = fma(Trow[qq], Gs[qq * 16 + c], sacc);
+          Trow[c] = (i == c) ? tc : ((i < c) ? -tc * sacc : 0.0);
         }
+        double* Ts = Wred + i * TILE;         // Wred is idle until the next panel; step 8 reads T here
         double* Tk = T + k * 256;
-        for (int c = 0; c < TILE; ++c) Tk[i * 16 + c] = Ts[c];
+#pragma unroll
+        for (int c = 0; c < TILE; ++c) { Ts[c] = Trow[c]; Tk[i * 16 + c] = Trow[c]; }
       }
     }
     STAMP(4)
