@@ -246,7 +246,8 @@ def main():
         sw = sol.debug_sweeps()
         parity = {"problems": min(args.check, B), "max_rel_step_err": worst,
                   "masks_bit_exact": masks_ok,
-                  "jacobi_sweeps": [int(sw.min()), float(sw.mean()), int(sw.max())]}
+                  "jacobi_sweeps": [int(sw.min()), float(sw.mean()), int(sw.max())],
+                  "svd_free_fraction": float(sol.debug_fast().mean())}
 
     if rank == 0:
         timing = ctx.timing_read()

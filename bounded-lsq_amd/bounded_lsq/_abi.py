@@ -44,6 +44,7 @@ SIGNATURES = {
     "blsq_trf_fetch_factor": (C.c_int, [vp] + [vp] * 5),
     "blsq_trf_fetch_step": (C.c_int, [vp] + [vp] * 15),
     "blsq_debug_qr_stamps": (C.c_int, [vp]),
+    "blsq_trf_debug_fast": (C.c_int, [vp, vp]),
     "blsq_trf_debug_sweeps": (C.c_int, [vp, vp]),
     "blsq_dogbox_plan_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "blsq_dogbox_plan_destroy": (C.c_int, [vp]),

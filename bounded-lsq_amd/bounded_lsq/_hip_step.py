@@ -118,6 +118,11 @@ class TrfStepSolver:
         out = TrfFactorOut(g, g_norm, theta, scale)
         return (out, sing) if want_singular else out
 
+    def debug_fast(self):
+        fl = np.empty(self.B, np.int32)
+        self.ctx.check(self.lib.blsq_trf_debug_fast(self.h, ptr(fl)), "blsq_trf_debug_fast")
+        return fl
+
     def debug_sweeps(self):
         sw = np.empty(self.B, np.int32)
         self.ctx.check(self.lib.blsq_trf_debug_sweeps(self.h, ptr(sw)), "blsq_trf_debug_sweeps")

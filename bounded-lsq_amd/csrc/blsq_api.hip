@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -18,8 +19,10 @@ namespace {
 
 constexpr int RMAX = 1088;          // max padded leaf rows: LDS panel 16 x 1090 doubles
 
-enum Slot { K_QR_LEAF = 0, K_QR_MERGE, K_PREP, K_QR_AUG, K_JACOBI, K_STEP, K_NSLOT };
-const char* kSlotNames[K_NSLOT] = {"qr_leaf", "qr_merge", "prep", "qr_aug", "jacobi_svd", "step"};
+enum Slot { K_QR_LEAF = 0, K_QR_MERGE, K_PREP, K_QR_AUG, K_JACOBI, K_STEP, K_LM_GATE, K_LM_QR, K_LM_SOLVE,
+            K_NSLOT };
+const char* kSlotNames[K_NSLOT] = {"qr_leaf", "qr_merge", "prep", "qr_aug", "jacobi_svd", "step",
+                                   "lm_gate", "lm_qr", "lm_solve"};
 
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
 inline int panel_ldp(int RP) {      // smallest LDP >= RP with LDP == 2 (mod 32)
@@ -206,6 +209,10 @@ struct blsq_trf_plan {
   TrfStepOut out{};
   double* d_alpha_in = nullptr;
   int aug_RP = 0, aug_LDP = 0;
+  // SVD-free trust-region path (lm_kernels.hip)
+  DevBuf lm_S2, lm_Xa, lm_ints, lm_sc, lm_ph;
+  LmState lm{};
+  int lm_enable = 1;
 };
 
 struct blsq_dogbox_plan {
@@ -371,6 +378,24 @@ int trf_alloc_state(blsq_trf_plan* p) {
   p->out.active_new = p->o_act.as<long long>();
   p->out.scal = p->o_scal.as<double>();
   p->out.info = p->o_info.as<int>();
+  ALLOC(p->lm_S2, sizeof(double) * B * 2 * mat);
+  ALLOC(p->lm_Xa, sizeof(double) * B * mat);
+  ALLOC(p->lm_ints, sizeof(int) * ((size_t)B * 7 + 4));
+  ALLOC(p->lm_sc, sizeof(double) * (size_t)B * 16);
+  ALLOC(p->lm_ph, sizeof(double) * vs);
+  HIPCHK(ctx, hipMemsetAsync(p->lm_S2.p, 0, p->lm_S2.bytes, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(p->lm_ints.p, 0, p->lm_ints.bytes, ctx->stream));
+  {
+    LmState& lm = p->lm;
+    lm.B = B; lm.m = p->m_total; lm.n = p->n; lm.ld = ld;
+    lm.Raug = p->X.as<double>(); lm.S2 = p->lm_S2.as<double>(); lm.Xa = p->lm_Xa.as<double>();
+    int* ii = p->lm_ints.as<int>();
+    lm.fast = ii; lm.ncols_jac = ii + B; lm.ncols_lm = ii + 2 * (size_t)B; lm.st = ii + 3 * (size_t)B;
+    lm.active_count = ii + 7 * (size_t)B;
+    lm.sc = p->lm_sc.as<double>(); lm.ph = p->lm_ph.as<double>();
+    const char* env = getenv("BLSQ_NO_SVDFREE");
+    p->lm_enable = (env && env[0] == '1') ? 0 : 1;
+  }
   p->aug_RP = std::max(round_up(2 * p->n, 16), ld);
   if (p->aug_RP > RMAX) return ctx->bad(4, "n too large for the augmented system (2n <= 1088)");
   p->aug_LDP = panel_ldp(p->aug_RP);
@@ -396,14 +421,59 @@ int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode) {
   e = launch_qr(q, 1, p->B, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_qr(aug)");
+  // rank gate: clearly full-rank problems skip the SVD (lm_kernels.hip)
+  ctx->begin(K_LM_GATE);
+  e = launch_lm_gate(p->lm, p->lm_enable, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_lm_gate");
   JacobiArgs ja{};
-  ja.X = p->st.X; ja.strideX = (long)p->ld * p->ld; ja.ld = p->ld; ja.ncols_dev = nullptr;
+  ja.X = p->st.X; ja.strideX = (long)p->ld * p->ld; ja.ld = p->ld; ja.ncols_dev = p->lm.ncols_jac;
   ja.N = p->n + 1; ja.s = p->st.s; ja.uf = p->st.uf; ja.srange = p->st.srange;
   ja.sweeps = p->sweeps.as<int>(); ja.max_sweeps = 40;
   ctx->begin(K_JACOBI);
   e = launch_jacobi(ja, p->B, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_jacobi");
+  return 0;
+}
+
+// Safeguarded Newton iteration of the SVD-free problems: lock-step rounds of
+// (stacked QR of [R_aug; sqrt(alpha) I]) + (two triangular solves + update).
+int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_in) {
+  blsq_ctx* ctx = p->ctx;
+  int active = 0;
+  HIPCHK(ctx, hipMemsetAsync(p->lm.active_count, 0, sizeof(int), ctx->stream));
+  ctx->begin(K_LM_SOLVE);
+  hipError_t e = launch_lm_start(p->lm, dDelta, dalpha_in, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_lm_start");
+  HIPCHK(ctx, hipMemcpyAsync(&active, p->lm.active_count, sizeof(int), hipMemcpyDeviceToHost,
+                             ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int round = 0; round < 12 && active > 0; ++round) {
+    HIPCHK(ctx, hipMemsetAsync(p->lm.active_count, 0, sizeof(int), ctx->stream));
+    ctx->begin(K_LM_SOLVE);
+    e = launch_lm_prep(p->lm, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_lm_prep");
+    QrArgs q = p->tree.base_args();
+    q.A = p->lm.S2; q.strideA = 2L * p->ld * p->ld; q.ldA = p->ld; q.rowsA = 2 * p->n;
+    q.F = nullptr; q.strideF = 0; q.ncols_dev = p->lm.ncols_lm;
+    q.rows_per_leaf = p->aug_RP; q.RP = p->aug_RP; q.LDP = p->aug_LDP;
+    q.Rout = p->lm.Xa;
+    q.stack_rows = p->n;
+    ctx->begin(K_LM_QR);
+    e = launch_qr(q, 1, p->B, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_qr(lm)");
+    ctx->begin(K_LM_SOLVE);
+    e = launch_lm_update(p->lm, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_lm_update");
+    HIPCHK(ctx, hipMemcpyAsync(&active, p->lm.active_count, sizeof(int), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
   return 0;
 }
 
@@ -436,6 +506,8 @@ extern "C" int blsq_trf_plan_destroy(blsq_trf_plan* p) {
   p->o_vec.release(); p->o_hits.release(); p->o_act.release(); p->o_scal.release();
   p->o_info.release(); p->in_J.release(); p->in_f.release(); p->in_vec.release();
   p->in_scal.release();
+  p->lm_S2.release(); p->lm_Xa.release(); p->lm_ints.release(); p->lm_sc.release();
+  p->lm_ph.release();
   delete p;
   return 0;
 }
@@ -481,8 +553,11 @@ extern "C" int blsq_trf_step_dev(blsq_trf_plan* p, const double* dDelta, const d
   if (!dDelta) return ctx->bad(2, "Delta is NULL");
   if (!dalpha_in) return ctx->bad(3, "alpha is NULL");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = trf_lm_rounds(p, dDelta, dalpha_in);
+  if (rc) return rc;
   ctx->begin(K_STEP);
-  hipError_t e = launch_trf_step(p->st, dDelta, dalpha_in, active_rtol, p->out, ctx->stream);
+  hipError_t e = launch_trf_step(p->st, &p->lm, dDelta, dalpha_in, active_rtol, p->out,
+                                 ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_trf_step");
   return 0;
@@ -506,6 +581,15 @@ extern "C" int blsq_trf_fetch_factor(blsq_trf_plan* p, double* g, double* g_norm
 extern "C" int blsq_debug_qr_stamps(void* dbuf) {
   set_qr_debug_buffer(reinterpret_cast<double*>(dbuf));
   return 0;
+}
+
+extern "C" int blsq_trf_debug_fast(blsq_trf_plan* p, int32_t* fast) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!fast) return ctx->bad(2, "fast is NULL");
+  HIPCHK(ctx, hipMemcpyAsync(fast, p->lm.fast, sizeof(int) * p->B, hipMemcpyDeviceToHost,
+                             ctx->stream));
+  return blsq_sync(ctx);
 }
 
 extern "C" int blsq_trf_debug_sweeps(blsq_trf_plan* p, int32_t* sweeps) {

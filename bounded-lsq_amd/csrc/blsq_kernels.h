@@ -76,9 +76,30 @@ struct TrfStepOut {       // device pointers
                           //         alpha_out, to_bound, qp0, qp1, qp2
   int* info;              // [B][4]: n_iter, branch, choice, status
 };
-hipError_t launch_trf_step(const TrfState& st, const double* Delta,
+struct LmState;
+hipError_t launch_trf_step(const TrfState& st, const LmState* lm, const double* Delta,
                            const double* alpha_in, double active_rtol,
                            const TrfStepOut& out, hipStream_t s);
+
+// ------------------------------------------------ SVD-free TR sub-problem ----
+struct LmState {
+  int B, m, n, ld;
+  const double* Raug;     // [B][ld*ld]  augmented triangle | c_aug (TrfState.X before Jacobi)
+  double* S2;             // [B][2*ld*ld] stacked [R_aug | c ; sqrt(alpha) I | 0]
+  double* Xa;             // [B][ld*ld]  its triangle R_alpha | c_alpha
+  int* fast;              // [B] 1: problem uses the SVD-free path
+  int* ncols_jac;         // [B] N or 0: launch mask of the Jacobi kernel
+  int* ncols_lm;          // [B] N or 0: launch mask of the per-iteration QR
+  double* sc;             // [B][16] alpha, lo, hi, phi, dphi, Delta, smax_est, smin_est
+  int* st;                // [B][4]  it, phase, n_iter
+  double* ph;             // [B][ld] p_h of the SVD-free path
+  int* active_count;      // [1] problems that need another evaluation
+};
+hipError_t launch_lm_gate(const LmState& lm, int enable, hipStream_t s);
+hipError_t launch_lm_start(const LmState& lm, const double* Delta, const double* alpha_in,
+                           hipStream_t s);
+hipError_t launch_lm_prep(const LmState& lm, hipStream_t s);
+hipError_t launch_lm_update(const LmState& lm, hipStream_t s);
 
 // -------------------------------------------------------------- dogbox ----
 struct DogState {

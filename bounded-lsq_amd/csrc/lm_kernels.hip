@@ -1,0 +1,269 @@
+// SVD-free evaluation of the trust-region sub-problem for full-rank factors.
+//
+// solve_lsq_trust_region (bounded_lsq/trust_region.py:56-152) works in the SVD
+// basis of the augmented Jacobian, but every quantity it uses is a function of
+// A^T A + alpha I only (A = [J D; E], A^T A = R_aug^T R_aug):
+//     p(alpha)    = -(A^T A + alpha I)^{-1} A^T b          (:115, :148)
+//     phi(alpha)  = ||p|| - Delta                           (:51)
+//     phi'(alpha) = -p^T (A^T A + alpha I)^{-1} p / ||p||   (:52: sum suf^2/denom^3)
+//     alpha_upper = ||suf|| / Delta = ||A^T b|| / Delta     (:119)
+// With  [R_aug; sqrt(alpha) I] = Q_a [R_a; 0]  (the same structured stacked QR as the
+// Coleman-Li augmentation; rhs [c_aug; 0] -> c_a) :  p = -R_a^{-1} c_a  and
+// p^T (..)^{-1} p = ||R_a^{-T} p||^2 — two triangular solves.  The safeguarded
+// Newton iteration itself (brackets, restart rule, |phi| < 0.01 Delta stop, 10
+// iterations, stale-phi rescale) is restated unchanged.
+//
+// The reference takes this branch only when `full_rank` (s_min > eps m s_max,
+// :108-112); here a problem uses the SVD-free path only if a CONSERVATIVE gate
+// holds (power / inverse-power estimates of s_max, s_min with a 1e3 margin);
+// everything else — rank-deficient, wide (m < n), badly conditioned — goes through
+// the Jacobi SVD exactly as before.  Batched problems advance in lock-step rounds
+// (one stacked QR per Newton iteration), finished ones drop out.
+#include "blsq_device.h"
+#include "blsq_kernels.h"
+#include "tri_ops.h"
+
+namespace blsq {
+
+static constexpr double LM_EPS = 2.220446049250313e-16;
+static constexpr double LM_GATE_MARGIN = 1.0e3;
+
+enum { LM_IDLE = 0, LM_EVAL = 1, LM_FINAL = 2 };
+// sc[] slots
+enum { SC_ALPHA = 0, SC_LO, SC_HI, SC_PHI, SC_DPHI, SC_DELTA, SC_SMAX, SC_SMIN };
+// st[] slots
+enum { ST_IT = 0, ST_PHASE, ST_NITER };
+
+// ------------------------------------------------------------------- gate --
+__global__ __launch_bounds__(TRI_NT) void lm_gate_kernel(LmState lm, int enable) {
+  extern __shared__ double sh[];
+  __shared__ double red[32];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = lm.n, ld = lm.ld, N = n + 1;
+  const double* R = lm.Raug + (long)b * ld * ld;
+  double* v = sh;
+  double* u = v + ld;
+  double* invd = u + ld;
+  int ok = (enable != 0) && (lm.m >= n);
+  // diagonal: finite and non-zero
+  int bad = 0;
+  for (int i = tid; i < n; i += TRI_NT) {
+    const double dgi = R[(long)i * ld + i];
+    if (!(is_finite(dgi)) || dgi == 0.0) bad = 1;
+  }
+  if (block_or(bad, red)) ok = 0;
+  double smax = 0.0, smin = 0.0;
+  if (ok) {                                             // uniform
+    tri_invdiag(R, n, ld, invd);
+    const double s0 = 1.0 / sqrt((double)n);
+    for (int i = tid; i < n; i += TRI_NT) v[i] = (i & 1) ? -s0 : s0;
+    __syncthreads();
+    // s_max: power iteration on R^T R (a lower bound on s_max)
+    for (int it = 0; it < 4; ++it) {
+      tri_mv(R, n, ld, v, u);
+      tri_mtv(R, n, ld, u, v);
+      const double nv = sqrt(tri_dot(v, v, n, red));
+      smax = sqrt(nv);
+      const double inv = (nv > 0.0) ? 1.0 / nv : 0.0;
+      for (int i = tid; i < n; i += TRI_NT) v[i] *= inv;
+      __syncthreads();
+    }
+    // s_min: inverse power iteration on (R^T R)^{-1} (an upper bound on s_min)
+    for (int i = tid; i < n; i += TRI_NT) v[i] = (i % 3 == 0) ? s0 : -0.5 * s0;
+    __syncthreads();
+    for (int it = 0; it < 4; ++it) {
+      tri_solve_upper_t(R, n, ld, invd, v);
+      tri_solve_upper(R, n, ld, invd, v);
+      const double nv = sqrt(tri_dot(v, v, n, red));
+      smin = (nv > 0.0 && is_finite(nv)) ? 1.0 / sqrt(nv) : 0.0;   // ||(R^T R)^{-1} v|| ~ 1/s_min^2
+      const double inv = (nv > 0.0 && is_finite(nv)) ? 1.0 / nv : 0.0;
+      for (int i = tid; i < n; i += TRI_NT) v[i] *= inv;
+      __syncthreads();
+    }
+    if (!(smin > LM_GATE_MARGIN * LM_EPS * lm.m * smax) || !is_finite(smax) || smax == 0.0) ok = 0;
+  }
+  if (tid == 0) {
+    lm.fast[b] = ok;
+    lm.ncols_jac[b] = ok ? 0 : N;
+    lm.sc[(long)b * 16 + SC_SMAX] = smax;
+    lm.sc[(long)b * 16 + SC_SMIN] = smin;
+    lm.st[(long)b * 4 + ST_PHASE] = LM_IDLE;
+  }
+}
+
+hipError_t launch_lm_gate(const LmState& lm, int enable, hipStream_t s) {
+  const size_t lds = sizeof(double) * 3 * (size_t)lm.ld;
+  hipLaunchKernelGGL(lm_gate_kernel, dim3(lm.B), dim3(TRI_NT), lds, s, lm, enable);
+  return hipGetLastError();
+}
+
+// restart rule of trust_region.py:128,134
+__device__ __forceinline__ double lm_restart(double lo, double hi) {
+  const double gm = sqrt(lo * hi);
+  return (0.001 * hi > gm) ? 0.001 * hi : gm;
+}
+
+// ------------------------------------------------------------------ start --
+// Gauss-Newton step (alpha = 0) on R_aug, acceptance test, bracket initialisation.
+__global__ __launch_bounds__(TRI_NT) void lm_start_kernel(LmState lm, const double* Delta_in,
+                                                          const double* alpha_in) {
+  extern __shared__ double sh[];
+  __shared__ double red[32];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (!lm.fast[b]) return;
+  const int n = lm.n, ld = lm.ld;
+  const double* R = lm.Raug + (long)b * ld * ld;
+  double* p = sh;
+  double* q = p + ld;
+  double* invd = q + ld;
+  double* sc = lm.sc + (long)b * 16;
+  int* st = lm.st + (long)b * 4;
+  const double Delta = Delta_in[b];
+  tri_invdiag(R, n, ld, invd);
+  for (int i = tid; i < n; i += TRI_NT) p[i] = R[(long)i * ld + n];     // c_aug
+  __syncthreads();
+  // alpha_upper = ||A^T b|| / Delta
+  tri_mtv(R, n, ld, p, q);
+  const double gnorm = sqrt(tri_dot(q, q, n, red));
+  tri_solve_upper(R, n, ld, invd, p);                                     // R^{-1} c
+  const double pn = sqrt(tri_dot(p, p, n, red));
+  for (int i = tid; i < n; i += TRI_NT) {
+    p[i] = -p[i];
+    lm.ph[(long)b * ld + i] = p[i];
+  }
+  __syncthreads();
+  if (pn <= Delta) {                                                      // trust_region.py:116-117
+    if (tid == 0) { sc[SC_ALPHA] = 0.0; st[ST_NITER] = 0; st[ST_PHASE] = LM_IDLE; sc[SC_DELTA] = Delta; }
+    return;
+  }
+  // phi(0), phi'(0) -> alpha_lower (trust_region.py:121-123)
+  for (int i = tid; i < n; i += TRI_NT) q[i] = p[i];
+  __syncthreads();
+  tri_solve_upper_t(R, n, ld, invd, q);
+  const double qq = tri_dot(q, q, n, red);
+  const double phi = pn - Delta;
+  const double dphi = -qq / pn;
+  double hi = gnorm / Delta;
+  double lo = -phi / dphi;
+  double alpha = alpha_in[b];                                             // :127-130 (full rank)
+  if (alpha < lo || alpha > hi) alpha = lm_restart(lo, hi);               // :133-134, iteration 0
+  if (tid == 0) {
+    sc[SC_ALPHA] = alpha; sc[SC_LO] = lo; sc[SC_HI] = hi; sc[SC_PHI] = phi; sc[SC_DPHI] = dphi;
+    sc[SC_DELTA] = Delta;
+    st[ST_IT] = 0; st[ST_PHASE] = LM_EVAL; st[ST_NITER] = 0;
+    atomicAdd(lm.active_count, 1);
+  }
+}
+
+hipError_t launch_lm_start(const LmState& lm, const double* Delta, const double* alpha_in,
+                           hipStream_t s) {
+  const size_t lds = sizeof(double) * 3 * (size_t)lm.ld;
+  hipLaunchKernelGGL(lm_start_kernel, dim3(lm.B), dim3(TRI_NT), lds, s, lm, Delta, alpha_in);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------- prep --
+// stacked source  [R_aug | c_aug ; sqrt(alpha) I | 0]  for the problems that evaluate
+__global__ __launch_bounds__(TRI_NT) void lm_prep_kernel(LmState lm) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = lm.n, ld = lm.ld, N = n + 1;
+  const int phase = lm.fast[b] ? lm.st[(long)b * 4 + ST_PHASE] : LM_IDLE;
+  if (tid == 0) lm.ncols_lm[b] = (phase == LM_IDLE) ? 0 : N;
+  if (phase == LM_IDLE) return;
+  const double* R = lm.Raug + (long)b * ld * ld;
+  double* S = lm.S2 + (long)b * 2 * ld * ld;
+  const double sa = sqrt(lm.sc[(long)b * 16 + SC_ALPHA]);
+  for (int idx = tid; idx < 2 * n * N; idx += TRI_NT) {
+    const int row = idx / N, col = idx - row * N;
+    double val;
+    if (row < n) val = (col >= row) ? R[(long)row * ld + col] : 0.0;
+    else val = (col == row - n) ? sa : 0.0;
+    S[(long)row * ld + col] = val;
+  }
+}
+
+hipError_t launch_lm_prep(const LmState& lm, hipStream_t s) {
+  hipLaunchKernelGGL(lm_prep_kernel, dim3(lm.B), dim3(TRI_NT), 0, s, lm);
+  return hipGetLastError();
+}
+
+// ----------------------------------------------------------------- update --
+// one evaluation of phi / phi' at the current alpha + the Newton update (:132-150)
+__global__ __launch_bounds__(TRI_NT) void lm_update_kernel(LmState lm) {
+  extern __shared__ double sh[];
+  __shared__ double red[32];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (!lm.fast[b]) return;
+  int* st = lm.st + (long)b * 4;
+  const int phase = st[ST_PHASE];
+  if (phase == LM_IDLE) return;
+  const int n = lm.n, ld = lm.ld;
+  const double* R = lm.Xa + (long)b * ld * ld;            // R_alpha | c_alpha
+  double* p = sh;
+  double* q = p + ld;
+  double* invd = q + ld;
+  double* sc = lm.sc + (long)b * 16;
+  const double Delta = sc[SC_DELTA];
+  tri_invdiag(R, n, ld, invd);
+  for (int i = tid; i < n; i += TRI_NT) p[i] = R[(long)i * ld + n];
+  __syncthreads();
+  tri_solve_upper(R, n, ld, invd, p);
+  const double pn = sqrt(tri_dot(p, p, n, red));
+  for (int i = tid; i < n; i += TRI_NT) p[i] = -p[i];
+  __syncthreads();
+  double alpha = sc[SC_ALPHA], lo = sc[SC_LO], hi = sc[SC_HI];
+  double phi = sc[SC_PHI], dphi = sc[SC_DPHI];
+  int it = st[ST_IT];
+  int next_phase = LM_IDLE;
+  int n_iter = st[ST_NITER];
+  bool finished = false;
+  if (phase == LM_FINAL) {
+    // loop exhausted (:132 ran 10 times without break): p at the UPDATED alpha, rescale
+    // test on the STALE phi (:149)
+    finished = true;
+  } else {
+    for (int i = tid; i < n; i += TRI_NT) q[i] = p[i];
+    __syncthreads();
+    tri_solve_upper_t(R, n, ld, invd, q);
+    const double qq = tri_dot(q, q, n, red);
+    phi = pn - Delta;
+    dphi = -qq / pn;
+    if (fabs(phi) < 0.01 * Delta) {                       // :138-139
+      finished = true;
+      n_iter = it + 1;
+    } else {
+      if (phi < 0.0) hi = alpha;                          // :141-142
+      const double ratio = phi / dphi;
+      const double cand = alpha - ratio;
+      lo = (cand > lo) ? cand : lo;                       // :145
+      alpha -= (phi + Delta) * ratio / Delta;             // :146
+      ++it;
+      if (it >= 10) {                                     // max_iter reached: final p at new alpha
+        n_iter = 10;
+        next_phase = LM_FINAL;
+      } else {
+        if (alpha < lo || alpha > hi) alpha = lm_restart(lo, hi);   // :133-134 of the next pass
+        next_phase = LM_EVAL;
+      }
+    }
+  }
+  if (finished) {
+    const double f = (phi > 0.0) ? Delta / pn : 1.0;      // :149-150
+    for (int i = tid; i < n; i += TRI_NT) lm.ph[(long)b * ld + i] = p[i] * f;
+    next_phase = LM_IDLE;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    sc[SC_ALPHA] = alpha; sc[SC_LO] = lo; sc[SC_HI] = hi; sc[SC_PHI] = phi; sc[SC_DPHI] = dphi;
+    st[ST_IT] = it; st[ST_PHASE] = next_phase; st[ST_NITER] = n_iter;
+    if (next_phase != LM_IDLE) atomicAdd(lm.active_count, 1);
+  }
+}
+
+hipError_t launch_lm_update(const LmState& lm, hipStream_t s) {
+  const size_t lds = sizeof(double) * 3 * (size_t)lm.ld;
+  hipLaunchKernelGGL(lm_update_kernel, dim3(lm.B), dim3(TRI_NT), lds, s, lm);
+  return hipGetLastError();
+}
+
+}  // namespace blsq

@@ -153,7 +153,9 @@ __device__ double quad_min_dev(double a, double b, double lo, double hi) {
   return tbest;
 }
 
-__global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const double* Delta_in,
+__global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int* lm_fast,
+                                                         const double* lm_ph, const double* lm_sc,
+                                                         const int* lm_st, const double* Delta_in,
                                                          const double* alpha_in,
                                                          double active_rtol, TrfStepOut out) {
   extern __shared__ double sh[];
@@ -191,7 +193,13 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const doub
   double alpha = 0.0;
   int n_iter = 0;
   bool have_p = false;
-  if (full_rank) {
+  const bool fast = lm_fast && lm_fast[b];       // SVD-free path already produced p (lm_kernels.hip)
+  if (fast) {
+    for (int j = tid; j < n; j += NS_NT) ph[j] = lm_ph[vo + j];
+    alpha = lm_sc[(long)b * 16];
+    n_iter = lm_st[(long)b * 4 + 2];
+    have_p = true;
+  } else if (full_rank) {
     // p = -V (uf / s); rows of X are s_i v_i^T
     for (int i = tid; i < n; i += NS_NT) coef[i] = (uf[i] / sv[i]) / sv[i];
     __syncthreads();
@@ -446,11 +454,13 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const doub
   }
 }
 
-hipError_t launch_trf_step(const TrfState& st, const double* Delta, const double* alpha_in,
-                           double active_rtol, const TrfStepOut& out, hipStream_t s) {
+hipError_t launch_trf_step(const TrfState& st, const LmState* lm, const double* Delta,
+                           const double* alpha_in, double active_rtol, const TrfStepOut& out,
+                           hipStream_t s) {
   const size_t lds = sizeof(double) * 8 * (size_t)st.ld;
-  hipLaunchKernelGGL(trf_step_kernel, dim3(st.B), dim3(NS_NT), lds, s, st, Delta, alpha_in,
-                     active_rtol, out);
+  hipLaunchKernelGGL(trf_step_kernel, dim3(st.B), dim3(NS_NT), lds, s, st,
+                     lm ? lm->fast : nullptr, lm ? lm->ph : nullptr, lm ? lm->sc : nullptr,
+                     lm ? lm->st : nullptr, Delta, alpha_in, active_rtol, out);
   return hipGetLastError();
 }
 

@@ -108,6 +108,10 @@ int blsq_trf_fetch_step(blsq_trf_plan* plan, double* alpha_out, double* step_h, 
  * build writes them): 8 doubles per workgroup into the given device buffer */
 int blsq_debug_qr_stamps(void* dbuf);
 
+/* diagnostics: 1 where the last factor call chose the SVD-free trust-region path
+ * (full-rank gate passed), 0 where it went through the Jacobi SVD */
+int blsq_trf_debug_fast(blsq_trf_plan* plan, int32_t* fast /*B*/);
+
 /* diagnostics: Jacobi sweeps used by the last factor call, per problem */
 int blsq_trf_debug_sweeps(blsq_trf_plan* plan, int32_t* sweeps /*B*/);
 

@@ -37,8 +37,16 @@ def bl():
 TRF_CASES = load_npz("trf_small.npz") + load_npz("trf_large.npz")
 
 
+@pytest.fixture(params=["svd_free", "svd_only"])
+def tr_path(request, monkeypatch):
+    """Both trust-region paths: the SVD-free one (QR of [R; sqrt(alpha) I], taken when the
+    full-rank gate passes) and the Jacobi-SVD one forced for every problem."""
+    monkeypatch.setenv("BLSQ_NO_SVDFREE", "1" if request.param == "svd_only" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("name,ins,out", TRF_CASES, ids=[c[0] for c in TRF_CASES])
-def test_trf_golden(bl, name, ins, out):
+def test_trf_golden(bl, tr_path, name, ins, out):
     P = trf_inputs(ins)
     m, n = P["J"].shape
     sol = bl.TrfStepSolver(1, m, n)
@@ -53,7 +61,13 @@ def test_trf_golden(bl, name, ins, out):
     D = sol.fetch_step()
     _, sing = sol.fetch_factor(want_singular=True)
     sref = np.asarray(out["s"], float)
-    assert rel(np.sort(sing[0])[::-1], sref) < 1e-12
+    used_fast = int(sol.debug_fast()[0])
+    if tr_path == "svd_only":
+        assert used_fast == 0
+    if not used_fast:                       # singular values exist only on the SVD path
+        assert rel(np.sort(sing[0])[::-1], sref) < 1e-12
+    else:                                   # the gate must never pass a rank-deficient problem
+        assert m >= n and sref[-1] > 1e3 * np.finfo(float).eps * m * sref[0]
     if name in KNIFE_EDGE:
         Delta = P["Delta"]
         assert abs(np.linalg.norm(D.p_h_tr[0]) - Delta) <= 0.011 * Delta
@@ -115,7 +129,7 @@ def test_dogbox_golden(bl, name, ins, out):
 @pytest.mark.parametrize("B,m,n", [(16, 512, 64), (5, 200, 37), (3, 1500, 20), (2, 4096, 256),
                                    (2, 2500, 50), (3, 1100, 17), (4, 700, 100), (2, 5000, 33),
                                    (2, 3000, 200), (6, 90, 5), (2, 1089, 16)])
-def test_trf_batch_vs_oracle(bl, B, m, n):
+def test_trf_batch_vs_oracle(bl, tr_path, B, m, n):
     from oracle import blsq_oracle as orc
     from bounded_lsq import _synth
     P = _synth.trf_batch(1000 + n, B, m, n)
@@ -230,3 +244,33 @@ def test_tsqr_row_blocks_single_gpu(bl, m, n, nranks):
         assert int(S.n_iter[0]) == So.n_iter
     for sol in sols:
         sol.close()
+
+
+def test_mixed_rank_batch_takes_both_paths(bl):
+    """A batch mixing well-conditioned, rank-deficient and badly conditioned problems:
+    the gate must send only the clearly full-rank ones down the SVD-free path, and
+    every problem must still match the oracle."""
+    from oracle import blsq_oracle as orc
+    from bounded_lsq import _synth
+    B, m, n = 6, 120, 12
+    P = _synth.trf_batch(31337, B, m, n, unbounded=True)
+    P["J"][1, :, 5] = P["J"][1, :, 2]                      # exactly rank deficient
+    P["J"][3, :, 7] = 0.0                                  # zero column
+    P["J"][4, :, 9] = P["J"][4, :, 1] * (1 + 1e-13)        # cond ~ 1e13: beyond the gate
+    # rank-deficient problems get a Delta inside the min-norm step (beyond it the reference's
+    # answer is decided by LAPACK null-space noise, see KNIFE_EDGE)
+    Delta = np.array([0.3, 0.1, 5.0, 0.1, 0.1, 0.05])
+    sol = bl.TrfStepSolver(B, m, n)
+    sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+    fast = sol.debug_fast()
+    assert list(fast) == [1, 0, 1, 0, 0, 1]
+    S = sol.step(Delta, np.zeros(B))
+    for b in range(B):
+        _, So = orc.trf_step_solve(P["J"][b], P["f"][b], P["x"][b], P["lb"][b], P["ub"][b],
+                                   P["scale"][b], Delta[b], 0.0)
+        if b == 4:      # cond 1e13: the reference's own answer is only good to ~cond*eps
+            assert rel(S.step[b], So.step) < 1e-2
+            continue
+        assert int(S.n_iter[b]) == So.n_iter, b
+        assert rel(S.step[b], So.step) < RTOL, (b, rel(S.step[b], So.step))
+    sol.close()
