@@ -222,6 +222,8 @@ struct blsq_dogbox_plan {
   DevBuf S, X, vecs, ivecs, scal2, sweeps, active, onb;
   DevBuf o_vec, o_onb, o_scal, o_info;
   DevBuf in_J, in_f, in_vec, in_scal;
+  DevBuf gate_ints;                 // [2B] fast flags, Jacobi launch mask
+  int svdfree_enable = 1;
   DogState st{};
   DogStepOut out{};
 };
@@ -393,8 +395,13 @@ int trf_alloc_state(blsq_trf_plan* p) {
     lm.fast = ii; lm.ncols_jac = ii + B; lm.ncols_lm = ii + 2 * (size_t)B; lm.st = ii + 3 * (size_t)B;
     lm.active_count = ii + 7 * (size_t)B;
     lm.sc = p->lm_sc.as<double>(); lm.ph = p->lm_ph.as<double>();
+    // The SVD-free Newton iteration costs one small stacked QR per iteration; below
+    // n ~ 64 those QRs are latency-bound and the in-LDS Jacobi SVD is cheaper (measured
+    // 512x64: 491k vs 421k step-solves/s), so small problems keep the SVD.
     const char* env = getenv("BLSQ_NO_SVDFREE");
-    p->lm_enable = (env && env[0] == '1') ? 0 : 1;
+    const char* envn = getenv("BLSQ_SVDFREE_MIN_N");
+    const int min_n = envn ? atoi(envn) : 65;
+    p->lm_enable = ((env && env[0] == '1') || p->n < min_n) ? 0 : 1;
   }
   p->aug_RP = std::max(round_up(2 * p->n, 16), ld);
   if (p->aug_RP > RMAX) return ctx->bad(4, "n too large for the augmented system (2n <= 1088)");
@@ -813,6 +820,12 @@ int dog_alloc_state(blsq_dogbox_plan* p) {
   ALLOC(p->o_scal, sizeof(double) * (size_t)B * 4);
   ALLOC(p->o_info, sizeof(int) * (size_t)B * 4);
   ALLOC(p->in_scal, sizeof(double) * (size_t)B);
+  ALLOC(p->gate_ints, sizeof(int) * 2 * (size_t)B);
+  {
+    const char* env = getenv("BLSQ_NO_SVDFREE");
+    p->svdfree_enable = (env && env[0] == '1') ? 0 : 1;
+  }
+  HIPCHK(ctx, hipMemsetAsync(p->gate_ints.p, 0, p->gate_ints.bytes, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(p->S.p, 0, p->S.bytes, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(p->X.p, 0, p->X.bytes, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(p->vecs.p, 0, p->vecs.bytes, ctx->stream));
@@ -863,8 +876,14 @@ int dog_after_triangle(blsq_dogbox_plan* p, int scale_mode) {
   e = launch_qr(q, 1, p->B, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_qr(free block)");
+  int* gfast = p->gate_ints.as<int>();
+  int* gmask = gfast + p->B;
+  ctx->begin(K_LM_GATE);
+  e = launch_dog_gate_solve(p->st, gfast, gmask, p->svdfree_enable, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_dog_gate_solve");
   JacobiArgs ja{};
-  ja.X = p->st.X; ja.strideX = (long)p->ld * p->ld; ja.ld = p->ld; ja.ncols_dev = p->st.ncols;
+  ja.X = p->st.X; ja.strideX = (long)p->ld * p->ld; ja.ld = p->ld; ja.ncols_dev = gmask;
   ja.N = p->n + 1; ja.s = p->st.s; ja.uf = p->st.uf; ja.srange = p->st.srange;
   ja.sweeps = p->sweeps.as<int>(); ja.max_sweeps = 40;
   ctx->begin(K_JACOBI);
@@ -872,7 +891,7 @@ int dog_after_triangle(blsq_dogbox_plan* p, int scale_mode) {
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_jacobi");
   ctx->begin(K_STEP);
-  e = launch_dog_solve(p->st, ctx->stream);
+  e = launch_dog_solve(p->st, gfast, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_dog_solve");
   return 0;
@@ -906,7 +925,7 @@ extern "C" int blsq_dogbox_plan_destroy(blsq_dogbox_plan* p) {
   p->S.release(); p->X.release(); p->vecs.release(); p->ivecs.release(); p->scal2.release();
   p->sweeps.release(); p->active.release(); p->onb.release(); p->o_vec.release();
   p->o_onb.release(); p->o_scal.release(); p->o_info.release(); p->in_J.release();
-  p->in_f.release(); p->in_vec.release(); p->in_scal.release();
+  p->in_f.release(); p->in_vec.release(); p->in_scal.release(); p->gate_ints.release();
   delete p;
   return 0;
 }

@@ -118,7 +118,9 @@ struct DogState {
   unsigned char* active;                  // [B][ld]
 };
 hipError_t launch_dog_prep(const DogState& st, int jac_scaling, hipStream_t s);
-hipError_t launch_dog_solve(const DogState& st, hipStream_t s);
+hipError_t launch_dog_solve(const DogState& st, const int* skip, hipStream_t s);
+hipError_t launch_dog_gate_solve(const DogState& st, int* fast, int* ncols_jac, int enable,
+                                 hipStream_t s);
 
 struct DogStepOut {
   double* step;           // [B][ld]  full length

@@ -107,9 +107,10 @@ hipError_t launch_dog_prep(const DogState& st, int jac_scaling, hipStream_t s) {
 
 // ----------------------------------------------------------------- solve --
 // newton = lstsq(J_free, -f)[0] from the Jacobi rows  X[i] = s_i v_i^T | uf_i
-__global__ __launch_bounds__(DG_NT) void dog_solve_kernel(DogState st) {
+__global__ __launch_bounds__(DG_NT) void dog_solve_kernel(DogState st, const int* skip) {
   extern __shared__ double sh[];
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (skip && skip[b]) return;             // Newton step already solved without the SVD
   const int ld = st.ld;
   const long vo = (long)b * ld;
   const int N = st.ncols[b];
@@ -131,9 +132,9 @@ __global__ __launch_bounds__(DG_NT) void dog_solve_kernel(DogState st) {
   }
 }
 
-hipError_t launch_dog_solve(const DogState& st, hipStream_t s) {
+hipError_t launch_dog_solve(const DogState& st, const int* skip, hipStream_t s) {
   const size_t lds = sizeof(double) * (size_t)st.ld;
-  hipLaunchKernelGGL(dog_solve_kernel, dim3(st.B), dim3(DG_NT), lds, s, st);
+  hipLaunchKernelGGL(dog_solve_kernel, dim3(st.B), dim3(DG_NT), lds, s, st, skip);
   return hipGetLastError();
 }
 

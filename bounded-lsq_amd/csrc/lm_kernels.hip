@@ -59,7 +59,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_gate_kernel(LmState lm, int enable)
     for (int i = tid; i < n; i += TRI_NT) v[i] = (i & 1) ? -s0 : s0;
     __syncthreads();
     // s_max: power iteration on R^T R (a lower bound on s_max)
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < 2; ++it) {
       tri_mv(R, n, ld, v, u);
       tri_mtv(R, n, ld, u, v);
       const double nv = sqrt(tri_dot(v, v, n, red));
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_gate_kernel(LmState lm, int enable)
     // s_min: inverse power iteration on (R^T R)^{-1} (an upper bound on s_min)
     for (int i = tid; i < n; i += TRI_NT) v[i] = (i % 3 == 0) ? s0 : -0.5 * s0;
     __syncthreads();
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < 3; ++it) {
       tri_solve_upper_t(R, n, ld, invd, v);
       tri_solve_upper(R, n, ld, invd, v);
       const double nv = sqrt(tri_dot(v, v, n, red));
@@ -263,6 +263,82 @@ __global__ __launch_bounds__(TRI_NT) void lm_update_kernel(LmState lm) {
 hipError_t launch_lm_update(const LmState& lm, hipStream_t s) {
   const size_t lds = sizeof(double) * 3 * (size_t)lm.ld;
   hipLaunchKernelGGL(lm_update_kernel, dim3(lm.B), dim3(TRI_NT), lds, s, lm);
+  return hipGetLastError();
+}
+
+
+// ---------------------------------------------------------------- dogbox --
+// lstsq(J_free, -f)[0] (dogbox.py:197) without an SVD when the free block is clearly of
+// full column rank: newton = -R_f^{-1} c_f.  gelsd drops singular values below
+// rcond * s_max with rcond = eps * max(m, n_free); the gate requires the inverse-power
+// upper bound on s_min to clear that threshold by the same 1e3 margin, otherwise the
+// Jacobi SVD computes the truncated min-norm solution as before.
+__global__ __launch_bounds__(TRI_NT) void dog_gate_solve_kernel(DogState st, int* fast,
+                                                                int* ncols_jac, int enable) {
+  extern __shared__ double sh[];
+  __shared__ double red[32];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int ld = st.ld;
+  const int N = st.ncols[b];
+  const int nf = N - 1;
+  if (N <= 0) {
+    if (tid == 0) { fast[b] = 0; ncols_jac[b] = 0; }
+    return;
+  }
+  const double* R = st.X + (long)b * ld * ld;             // triangle of [R[:, free] | c]
+  double* v = sh;
+  double* u = v + ld;
+  double* invd = u + ld;
+  int ok = (enable != 0) && (st.m >= nf);
+  int bad = 0;
+  for (int i = tid; i < nf; i += TRI_NT) {
+    const double dgi = R[(long)i * ld + i];
+    if (!(is_finite(dgi)) || dgi == 0.0) bad = 1;
+  }
+  if (block_or(bad, red)) ok = 0;
+  if (ok) {
+    tri_invdiag(R, nf, ld, invd);
+    const double s0 = 1.0 / sqrt((double)nf);
+    for (int i = tid; i < nf; i += TRI_NT) v[i] = (i & 1) ? -s0 : s0;
+    __syncthreads();
+    double smax = 0.0, smin = 0.0;
+    for (int it = 0; it < 2; ++it) {
+      tri_mv(R, nf, ld, v, u);
+      tri_mtv(R, nf, ld, u, v);
+      const double nv = sqrt(tri_dot(v, v, nf, red));
+      smax = sqrt(nv);
+      const double inv = (nv > 0.0) ? 1.0 / nv : 0.0;
+      for (int i = tid; i < nf; i += TRI_NT) v[i] *= inv;
+      __syncthreads();
+    }
+    for (int i = tid; i < nf; i += TRI_NT) v[i] = (i % 3 == 0) ? s0 : -0.5 * s0;
+    __syncthreads();
+    for (int it = 0; it < 3; ++it) {
+      tri_solve_upper_t(R, nf, ld, invd, v);
+      tri_solve_upper(R, nf, ld, invd, v);
+      const double nv = sqrt(tri_dot(v, v, nf, red));
+      smin = (nv > 0.0 && is_finite(nv)) ? 1.0 / sqrt(nv) : 0.0;
+      const double inv = (nv > 0.0 && is_finite(nv)) ? 1.0 / nv : 0.0;
+      for (int i = tid; i < nf; i += TRI_NT) v[i] *= inv;
+      __syncthreads();
+    }
+    const int mx = (st.m > nf) ? st.m : nf;
+    if (!(smin > LM_GATE_MARGIN * LM_EPS * mx * smax) || !is_finite(smax) || smax == 0.0) ok = 0;
+  }
+  if (ok) {
+    for (int i = tid; i < nf; i += TRI_NT) v[i] = R[(long)i * ld + nf];      // c_f
+    __syncthreads();
+    tri_solve_upper(R, nf, ld, invd, v);
+    for (int i = tid; i < nf; i += TRI_NT) st.newton[(long)b * ld + i] = -v[i];
+  }
+  if (tid == 0) { fast[b] = ok; ncols_jac[b] = ok ? 0 : N; }
+}
+
+hipError_t launch_dog_gate_solve(const DogState& st, int* fast, int* ncols_jac, int enable,
+                                 hipStream_t s) {
+  const size_t lds = sizeof(double) * 3 * (size_t)st.ld;
+  hipLaunchKernelGGL(dog_gate_solve_kernel, dim3(st.B), dim3(TRI_NT), lds, s, st, fast,
+                     ncols_jac, enable);
   return hipGetLastError();
 }
 

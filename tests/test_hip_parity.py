@@ -42,6 +42,7 @@ def tr_path(request, monkeypatch):
     """Both trust-region paths: the SVD-free one (QR of [R; sqrt(alpha) I], taken when the
     full-rank gate passes) and the Jacobi-SVD one forced for every problem."""
     monkeypatch.setenv("BLSQ_NO_SVDFREE", "1" if request.param == "svd_only" else "0")
+    monkeypatch.setenv("BLSQ_SVDFREE_MIN_N", "0")      # let small fixtures take the SVD-free path too
     return request.param
 
 
@@ -101,7 +102,7 @@ DOG_CASES = load_npz("dog_small.npz") + load_npz("dog_large.npz")
 
 
 @pytest.mark.parametrize("name,ins,out", DOG_CASES, ids=[c[0] for c in DOG_CASES])
-def test_dogbox_golden(bl, name, ins, out):
+def test_dogbox_golden(bl, tr_path, name, ins, out):
     P = dog_inputs(ins)
     m, n = P["J"].shape
     sol = bl.DogboxStepSolver(1, m, n)
@@ -150,7 +151,7 @@ def test_trf_batch_vs_oracle(bl, tr_path, B, m, n):
 
 @pytest.mark.parametrize("B,m,n", [(16, 512, 64), (5, 200, 37), (2, 4096, 256), (3, 1500, 20),
                                    (2, 2500, 50), (4, 700, 100), (6, 90, 5)])
-def test_dogbox_batch_vs_oracle(bl, B, m, n):
+def test_dogbox_batch_vs_oracle(bl, tr_path, B, m, n):
     from oracle import blsq_oracle as orc
     from bounded_lsq import _synth
     P = _synth.dogbox_batch(2000 + n, B, m, n)
@@ -252,6 +253,9 @@ def test_mixed_rank_batch_takes_both_paths(bl):
     every problem must still match the oracle."""
     from oracle import blsq_oracle as orc
     from bounded_lsq import _synth
+    import os
+    os.environ["BLSQ_SVDFREE_MIN_N"] = "0"
+    os.environ["BLSQ_NO_SVDFREE"] = "0"
     B, m, n = 6, 120, 12
     P = _synth.trf_batch(31337, B, m, n, unbounded=True)
     P["J"][1, :, 5] = P["J"][1, :, 2]                      # exactly rank deficient
@@ -274,3 +278,5 @@ def test_mixed_rank_batch_takes_both_paths(bl):
         assert int(S.n_iter[b]) == So.n_iter, b
         assert rel(S.step[b], So.step) < RTOL, (b, rel(S.step[b], So.step))
     sol.close()
+    os.environ.pop("BLSQ_SVDFREE_MIN_N", None)
+    os.environ.pop("BLSQ_NO_SVDFREE", None)
