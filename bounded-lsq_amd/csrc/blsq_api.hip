@@ -210,7 +210,7 @@ struct blsq_trf_plan {
   double* d_alpha_in = nullptr;
   int aug_RP = 0, aug_LDP = 0;
   // SVD-free trust-region path (lm_kernels.hip)
-  DevBuf lm_S2, lm_Xa, lm_ints, lm_sc, lm_ph;
+  DevBuf lm_Xa, lm_ints, lm_sc, lm_ph, lm_sa;
   LmState lm{};
   int lm_enable = 1;
 };
@@ -380,17 +380,17 @@ int trf_alloc_state(blsq_trf_plan* p) {
   p->out.active_new = p->o_act.as<long long>();
   p->out.scal = p->o_scal.as<double>();
   p->out.info = p->o_info.as<int>();
-  ALLOC(p->lm_S2, sizeof(double) * B * 2 * mat);
+  ALLOC(p->lm_sa, sizeof(double) * (size_t)B);
   ALLOC(p->lm_Xa, sizeof(double) * B * mat);
   ALLOC(p->lm_ints, sizeof(int) * ((size_t)B * 7 + 4));
   ALLOC(p->lm_sc, sizeof(double) * (size_t)B * 16);
   ALLOC(p->lm_ph, sizeof(double) * vs);
-  HIPCHK(ctx, hipMemsetAsync(p->lm_S2.p, 0, p->lm_S2.bytes, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(p->lm_sa.p, 0, p->lm_sa.bytes, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(p->lm_ints.p, 0, p->lm_ints.bytes, ctx->stream));
   {
     LmState& lm = p->lm;
     lm.B = B; lm.m = p->m_total; lm.n = p->n; lm.ld = ld;
-    lm.Raug = p->X.as<double>(); lm.S2 = p->lm_S2.as<double>(); lm.Xa = p->lm_Xa.as<double>();
+    lm.Raug = p->X.as<double>(); lm.sa = p->lm_sa.as<double>(); lm.Xa = p->lm_Xa.as<double>();
     int* ii = p->lm_ints.as<int>();
     lm.fast = ii; lm.ncols_jac = ii + B; lm.ncols_lm = ii + 2 * (size_t)B; lm.st = ii + 3 * (size_t)B;
     lm.active_count = ii + 7 * (size_t)B;
@@ -459,12 +459,10 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   for (int round = 0; round < 12 && active > 0; ++round) {
     HIPCHK(ctx, hipMemsetAsync(p->lm.active_count, 0, sizeof(int), ctx->stream));
-    ctx->begin(K_LM_SOLVE);
-    e = launch_lm_prep(p->lm, ctx->stream);
-    ctx->end();
-    if (e != hipSuccess) return ctx->fail(e, "launch_lm_prep");
+    // source = [R_aug | c_aug] read in place, stacked on a VIRTUAL sqrt(alpha) I block
     QrArgs q = p->tree.base_args();
-    q.A = p->lm.S2; q.strideA = 2L * p->ld * p->ld; q.ldA = p->ld; q.rowsA = 2 * p->n;
+    q.A = p->lm.Raug; q.strideA = (long)p->ld * p->ld; q.ldA = p->ld; q.rowsA = 2 * p->n;
+    q.vdiag_row0 = p->n; q.vdiag = p->lm.sa;
     q.F = nullptr; q.strideF = 0; q.ncols_dev = p->lm.ncols_lm;
     q.rows_per_leaf = p->aug_RP; q.RP = p->aug_RP; q.LDP = p->aug_LDP;
     q.Rout = p->lm.Xa;
@@ -513,7 +511,7 @@ extern "C" int blsq_trf_plan_destroy(blsq_trf_plan* p) {
   p->o_vec.release(); p->o_hits.release(); p->o_act.release(); p->o_scal.release();
   p->o_info.release(); p->in_J.release(); p->in_f.release(); p->in_vec.release();
   p->in_scal.release();
-  p->lm_S2.release(); p->lm_Xa.release(); p->lm_ints.release(); p->lm_sc.release();
+  p->lm_sa.release(); p->lm_Xa.release(); p->lm_ints.release(); p->lm_sc.release();
   p->lm_ph.release();
   delete p;
   return 0;

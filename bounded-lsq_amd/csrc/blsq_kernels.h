@@ -24,6 +24,9 @@ struct QrArgs {
   double* V;              // scratch [slot][NPmax][RP][16]
   double* T;              // scratch [slot][NPmax][256]
   double* Rout;           // [slot][NPAD][NPAD], slot = b*nleaf + leaf
+  // virtual bottom block: source rows >= vdiag_row0 are  vdiag[b] * I  (rhs 0) instead of memory
+  int vdiag_row0;         // 0: off
+  const double* vdiag;    // [B] per-problem scalar on that diagonal
   double* dbg;            // diagnostic stamps (nullptr in the product)
   int stack_rows;         // >0: source is a stack of upper-triangular blocks of this many rows
 };
@@ -85,7 +88,7 @@ hipError_t launch_trf_step(const TrfState& st, const LmState* lm, const double* 
 struct LmState {
   int B, m, n, ld;
   const double* Raug;     // [B][ld*ld]  augmented triangle | c_aug (TrfState.X before Jacobi)
-  double* S2;             // [B][2*ld*ld] stacked [R_aug | c ; sqrt(alpha) I | 0]
+  double* sa;             // [B] sqrt(alpha) of the current evaluation (virtual diagonal block)
   double* Xa;             // [B][ld*ld]  its triangle R_alpha | c_alpha
   int* fast;              // [B] 1: problem uses the SVD-free path
   int* ncols_jac;         // [B] N or 0: launch mask of the Jacobi kernel
@@ -98,7 +101,6 @@ struct LmState {
 hipError_t launch_lm_gate(const LmState& lm, int enable, hipStream_t s);
 hipError_t launch_lm_start(const LmState& lm, const double* Delta, const double* alpha_in,
                            hipStream_t s);
-hipError_t launch_lm_prep(const LmState& lm, hipStream_t s);
 hipError_t launch_lm_update(const LmState& lm, hipStream_t s);
 
 // -------------------------------------------------------------- dogbox ----

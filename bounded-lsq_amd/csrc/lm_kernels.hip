@@ -56,22 +56,19 @@ __global__ __launch_bounds__(TRI_NT) void lm_gate_kernel(LmState lm, int enable)
   if (ok) {                                             // uniform
     tri_invdiag(R, n, ld, invd);
     const double s0 = 1.0 / sqrt((double)n);
-    for (int i = tid; i < n; i += TRI_NT) v[i] = (i & 1) ? -s0 : s0;
-    __syncthreads();
-    // s_max: power iteration on R^T R (a lower bound on s_max)
-    for (int it = 0; it < 2; ++it) {
-      tri_mv(R, n, ld, v, u);
-      tri_mtv(R, n, ld, u, v);
-      const double nv = sqrt(tri_dot(v, v, n, red));
-      smax = sqrt(nv);
-      const double inv = (nv > 0.0) ? 1.0 / nv : 0.0;
-      for (int i = tid; i < n; i += TRI_NT) v[i] *= inv;
-      __syncthreads();
+    // s_max <= ||R||_F: an UPPER bound makes the gate more conservative, and costs one pass
+    {
+      double fro = 0.0;
+      for (int i = tid; i < n; i += TRI_NT) {
+        const double* row = R + (long)i * ld;
+        for (int j = i; j < n; ++j) fro = fma(row[j], row[j], fro);
+      }
+      smax = sqrt(block_sum(fro, red));
     }
     // s_min: inverse power iteration on (R^T R)^{-1} (an upper bound on s_min)
     for (int i = tid; i < n; i += TRI_NT) v[i] = (i % 3 == 0) ? s0 : -0.5 * s0;
     __syncthreads();
-    for (int it = 0; it < 3; ++it) {
+    for (int it = 0; it < 2; ++it) {
       tri_solve_upper_t(R, n, ld, invd, v);
       tri_solve_upper(R, n, ld, invd, v);
       const double nv = sqrt(tri_dot(v, v, n, red));
@@ -110,7 +107,10 @@ __global__ __launch_bounds__(TRI_NT) void lm_start_kernel(LmState lm, const doub
   extern __shared__ double sh[];
   __shared__ double red[32];
   const int b = blockIdx.x, tid = threadIdx.x;
-  if (!lm.fast[b]) return;
+  if (!lm.fast[b]) {
+    if (tid == 0) lm.ncols_lm[b] = 0;
+    return;
+  }
   const int n = lm.n, ld = lm.ld;
   const double* R = lm.Raug + (long)b * ld * ld;
   double* p = sh;
@@ -133,7 +133,10 @@ __global__ __launch_bounds__(TRI_NT) void lm_start_kernel(LmState lm, const doub
   }
   __syncthreads();
   if (pn <= Delta) {                                                      // trust_region.py:116-117
-    if (tid == 0) { sc[SC_ALPHA] = 0.0; st[ST_NITER] = 0; st[ST_PHASE] = LM_IDLE; sc[SC_DELTA] = Delta; }
+    if (tid == 0) {
+      sc[SC_ALPHA] = 0.0; st[ST_NITER] = 0; st[ST_PHASE] = LM_IDLE; sc[SC_DELTA] = Delta;
+      lm.ncols_lm[b] = 0;
+    }
     return;
   }
   // phi(0), phi'(0) -> alpha_lower (trust_region.py:121-123)
@@ -151,6 +154,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_start_kernel(LmState lm, const doub
     sc[SC_ALPHA] = alpha; sc[SC_LO] = lo; sc[SC_HI] = hi; sc[SC_PHI] = phi; sc[SC_DPHI] = dphi;
     sc[SC_DELTA] = Delta;
     st[ST_IT] = 0; st[ST_PHASE] = LM_EVAL; st[ST_NITER] = 0;
+    lm.sa[b] = sqrt(alpha); lm.ncols_lm[b] = n + 1;
     atomicAdd(lm.active_count, 1);
   }
 }
@@ -159,31 +163,6 @@ hipError_t launch_lm_start(const LmState& lm, const double* Delta, const double*
                            hipStream_t s) {
   const size_t lds = sizeof(double) * 3 * (size_t)lm.ld;
   hipLaunchKernelGGL(lm_start_kernel, dim3(lm.B), dim3(TRI_NT), lds, s, lm, Delta, alpha_in);
-  return hipGetLastError();
-}
-
-// ------------------------------------------------------------------- prep --
-// stacked source  [R_aug | c_aug ; sqrt(alpha) I | 0]  for the problems that evaluate
-__global__ __launch_bounds__(TRI_NT) void lm_prep_kernel(LmState lm) {
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int n = lm.n, ld = lm.ld, N = n + 1;
-  const int phase = lm.fast[b] ? lm.st[(long)b * 4 + ST_PHASE] : LM_IDLE;
-  if (tid == 0) lm.ncols_lm[b] = (phase == LM_IDLE) ? 0 : N;
-  if (phase == LM_IDLE) return;
-  const double* R = lm.Raug + (long)b * ld * ld;
-  double* S = lm.S2 + (long)b * 2 * ld * ld;
-  const double sa = sqrt(lm.sc[(long)b * 16 + SC_ALPHA]);
-  for (int idx = tid; idx < 2 * n * N; idx += TRI_NT) {
-    const int row = idx / N, col = idx - row * N;
-    double val;
-    if (row < n) val = (col >= row) ? R[(long)row * ld + col] : 0.0;
-    else val = (col == row - n) ? sa : 0.0;
-    S[(long)row * ld + col] = val;
-  }
-}
-
-hipError_t launch_lm_prep(const LmState& lm, hipStream_t s) {
-  hipLaunchKernelGGL(lm_prep_kernel, dim3(lm.B), dim3(TRI_NT), 0, s, lm);
   return hipGetLastError();
 }
 
@@ -256,6 +235,8 @@ __global__ __launch_bounds__(TRI_NT) void lm_update_kernel(LmState lm) {
   if (tid == 0) {
     sc[SC_ALPHA] = alpha; sc[SC_LO] = lo; sc[SC_HI] = hi; sc[SC_PHI] = phi; sc[SC_DPHI] = dphi;
     st[ST_IT] = it; st[ST_PHASE] = next_phase; st[ST_NITER] = n_iter;
+    lm.sa[b] = sqrt(alpha);
+    lm.ncols_lm[b] = (next_phase != LM_IDLE) ? n + 1 : 0;
     if (next_phase != LM_IDLE) atomicAdd(lm.active_count, 1);
   }
 }

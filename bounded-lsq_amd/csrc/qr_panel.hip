@@ -97,6 +97,8 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
   if (nrows < 0) nrows = 0;
   const double* A = q.A + (long)b * q.strideA + (long)r0 * q.ldA;
   const double* F = q.F ? q.F + (long)b * q.strideF + r0 : nullptr;
+  const int vrow0 = q.vdiag_row0;                       // single-leaf launches only
+  const double vdiag = (vrow0 > 0) ? q.vdiag[b] : 0.0;
   double* V = q.V + slot * (long)q.NPmax * RP * 16;     // tiles [t][row][col]
   double* T = q.T + slot * (long)q.NPmax * 256;
 
@@ -111,10 +113,11 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const int row = tid + r * QR_NT;
-    const int rc = (nrows > 0) ? (row < nrows ? row : nrows - 1) : 0;
+    const int rlim = (vrow0 > 0 && vrow0 < nrows) ? vrow0 : nrows;   // rows backed by memory
+    const int rc = (rlim > 0) ? (row < rlim ? row : rlim - 1) : 0;
     double val = 0.0;
-    if (nrows > 0) val = F ? F[rc] : A[(long)rc * q.ldA + nc];
-    fr[r] = (row < nrows) ? val : 0.0;
+    if (rlim > 0) val = F ? F[rc] : A[(long)rc * q.ldA + nc];
+    fr[r] = (row < rlim) ? val : 0.0;
   }
 
   STAMP_DECL
@@ -124,7 +127,9 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
     // flight per thread: a guarded load would serialise into branch+load+wait.
     {
       const int total = RP * 16;
-      const int rmax = nrows > 0 ? nrows - 1 : 0;
+      // rows of the virtual diagonal block are never read from memory
+      const int rmem = (vrow0 > 0 && vrow0 < nrows) ? vrow0 : nrows;
+      const int rmax = rmem > 0 ? rmem - 1 : 0;
       for (int i0 = 0; i0 < total; i0 += 8 * QR_NT) {
         double tmp[8];
 #pragma unroll
@@ -141,7 +146,8 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
           const int idx = i0 + uu * QR_NT + tid;
           const int row = idx >> 4, c = idx & 15;
           const int col = k * TILE + c;
-          const double val = (row < nrows && col < nA) ? tmp[uu] : 0.0;
+          double val = (row < nrows && col < nA) ? tmp[uu] : 0.0;
+          if (vrow0 > 0 && row >= vrow0) val = (col == row - vrow0 && col < nA) ? vdiag : 0.0;
           if (idx < total) P[c * LDP + row] = val;
         }
       }
