@@ -25,6 +25,11 @@ const char* kSlotNames[K_NSLOT] = {"qr_leaf", "qr_merge", "prep", "qr_aug", "jac
                                    "lm_gate", "lm_qr", "lm_solve"};
 
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
+// rows of the stacked systems [R D; E] / [R_aug; sqrt(alpha) I]: two blocks of
+// round_up(n, 16) rows each (the second block starts on a tile boundary, see qr_panel.hip)
+inline int aug_block_rows(int n) { return (n + 15) / 16 * 16; }
+inline int aug_rows(int n) { return 2 * aug_block_rows(n); }
+
 inline int panel_ldp(int RP) {      // smallest LDP >= RP with LDP == 2 (mod 32)
   int l = RP;
   while ((l & 31) != 2) ++l;
@@ -403,7 +408,7 @@ int trf_alloc_state(blsq_trf_plan* p) {
     const int min_n = envn ? atoi(envn) : 65;
     p->lm_enable = ((env && env[0] == '1') || p->n < min_n) ? 0 : 1;
   }
-  p->aug_RP = std::max(round_up(2 * p->n, 16), ld);
+  p->aug_RP = std::max(aug_rows(p->n), ld);
   if (p->aug_RP > RMAX) return ctx->bad(4, "n too large for the augmented system (2n <= 1088)");
   p->aug_LDP = panel_ldp(p->aug_RP);
   return 0;
@@ -419,11 +424,12 @@ int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode) {
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_trf_prep");
   QrArgs q = p->tree.base_args();
-  q.A = p->st.S; q.strideA = 2L * p->ld * p->ld; q.ldA = p->ld; q.rowsA = 2 * p->n;
+  q.A = p->st.S; q.strideA = 2L * p->ld * p->ld; q.ldA = p->ld;
+  q.rowsA = aug_block_rows(p->n) + p->n;
   q.F = nullptr; q.strideF = 0;
   q.rows_per_leaf = p->aug_RP; q.RP = p->aug_RP; q.LDP = p->aug_LDP;
   q.Rout = p->st.X;
-  q.stack_rows = p->n;                 // [R D; E]: two upper-triangular blocks of n rows
+  q.stack_rows = aug_block_rows(p->n); // [R D; E]: two upper-triangular blocks
   ctx->begin(K_QR_AUG);
   e = launch_qr(q, 1, p->B, ctx->stream);
   ctx->end();
@@ -461,12 +467,13 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
     HIPCHK(ctx, hipMemsetAsync(p->lm.active_count, 0, sizeof(int), ctx->stream));
     // source = [R_aug | c_aug] read in place, stacked on a VIRTUAL sqrt(alpha) I block
     QrArgs q = p->tree.base_args();
-    q.A = p->lm.Raug; q.strideA = (long)p->ld * p->ld; q.ldA = p->ld; q.rowsA = 2 * p->n;
-    q.vdiag_row0 = p->n; q.vdiag = p->lm.sa;
+    q.A = p->lm.Raug; q.strideA = (long)p->ld * p->ld; q.ldA = p->ld;
+    q.rowsA = aug_block_rows(p->n) + p->n;
+    q.vdiag_row0 = aug_block_rows(p->n); q.vdiag = p->lm.sa;
     q.F = nullptr; q.strideF = 0; q.ncols_dev = p->lm.ncols_lm;
     q.rows_per_leaf = p->aug_RP; q.RP = p->aug_RP; q.LDP = p->aug_LDP;
     q.Rout = p->lm.Xa;
-    q.stack_rows = p->n;
+    q.stack_rows = aug_block_rows(p->n);
     ctx->begin(K_LM_QR);
     e = launch_qr(q, 1, p->B, ctx->stream);
     ctx->end();
@@ -494,7 +501,7 @@ extern "C" int blsq_trf_plan_create(blsq_ctx* ctx, int B, int m, int n, blsq_trf
   HIPCHK(ctx, hipSetDevice(ctx->device));
   blsq_trf_plan* p = new blsq_trf_plan();
   p->ctx = ctx; p->B = B; p->m = m; p->n = n; p->m_total = m; p->nranks = 1;
-  const int aug_rp = std::max(round_up(2 * n, 16), round_up(n + 1, 16));
+  const int aug_rp = std::max(aug_rows(n), round_up(n + 1, 16));
   int rc = p->tree.build(ctx, B, m, n, (size_t)B * aug_rp);
   if (rc == 0) { p->ld = p->tree.NPAD; rc = trf_alloc_state(p); }
   if (rc != 0) { blsq_trf_plan_destroy(p); return rc; }
@@ -715,7 +722,7 @@ extern "C" int blsq_tsqr_plan_create(blsq_ctx* ctx, int m_local, int n, int nran
     delete p;
     return ctx->bad(3, "TSQR needs n + 1 <= 544");
   }
-  const int aug_rp = std::max(round_up(2 * n, 16), NPAD);
+  const int aug_rp = std::max(aug_rows(n), NPAD);
   // scratch must also cover the combine merges: nranks triangles, G per workgroup
   const int G = std::max(2, RMAX / NPAD);
   const size_t comb_rows = (size_t)((nranks + G - 1) / G) * (size_t)(G * NPAD);

@@ -46,21 +46,18 @@ __device__ __forceinline__ v4d mfma_f64(double a, double b, v4d c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-// Stacked-triangle inputs (TSQR merges, [R D; E]): the source is a stack of
-// upper-triangular blocks of `sr` rows, so block reflector j is zero outside
-// tile j of the first block and the rows i <= 16j+15 of every later block.
-// sr == 0: dense source, every tile >= j is live.  (wave-uniform)
-__device__ __forceinline__ bool tile_active(int t, int j, int sr) {
-  if (sr <= 0) return true;
-  const int rlo = t * TILE, rhi = rlo + TILE - 1;
-  const int glo = rlo / sr, ghi = rhi / sr;
-  if (glo != ghi) return true;              // straddles a block boundary (holds row 0 of a block)
-  if (glo == 0) return t == j;
-  return (rlo - glo * sr) <= j * TILE + TILE - 1;
-}
-
-// MAXT = tile slots per wave (ceil(RP/16/8)); tile of slot i is t0 + 8 i.
-template <int MAXT>
+// Structured sources (ST): TSQR merges, the Coleman-Li system [R D; E] and the
+// Newton systems [R_aug; sqrt(alpha) I] are stacks of G upper-triangular blocks of
+// `sr` rows (sr % 16 == 0, RP % sr == 0).  Row tile tl of block qb holds zeros in
+// every column panel < tl, and the reflectors of panel j only ever touch (and fill)
+// tiles with tl <= j.  QR does not depend on the row order, so the workgroup stages
+// the stack INTERLEAVED: LDS tile tau = tl * G + qb.  The rows a reflector j touches
+// are then the contiguous tile range [j, G (j+1)): V_j is stored, loaded and
+// multiplied only there, the cyclic tile->wave map stays balanced, and tiles with
+// tl >= NP (padding rows of each block) never enter at all.
+//
+// MAXT = tile slots per wave (ceil(ntile/8)); tile of slot i is t0 + 8 i.
+template <int MAXT, bool ST>
 __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
   constexpr int NR = (MAXT * QR_NW * TILE + QR_NT - 1) / QR_NT;   // rows per thread
   extern __shared__ double lds[];
@@ -73,7 +70,6 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
   const int RP = q.RP;
   const int LDP = q.LDP;
   const int NPAD = q.NPAD;
-  const int ntile = RP / TILE;
 
   double* P = lds;                          // [16][LDP], column-major panel
   double* Wred = P + 16 * LDP;              // [NW][256] partial W tiles
@@ -91,6 +87,18 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
   const int nc = N - 1;                     // columns to factor
   const int NP = (nc + TILE - 1) / TILE;
   const int nA = nc;                        // columns taken from A
+  const int sr = ST ? q.stack_rows : 0;
+  const int G = ST ? RP / sr : 1;           // blocks in the stack
+  const unsigned Gm = ST ? 65536u / (unsigned)G + 1u : 0u;   // tau / G == (tau * Gm) >> 16  (tau * G < 65536)
+  const int ntile = (ST && G * NP < RP / TILE) ? G * NP : RP / TILE;   // tiles that can ever be live
+  const int RPe = ntile * TILE;
+  // LDS row -> source row
+  auto src_row = [&](int row) -> int {
+    if (!ST) return row;
+    const int tau = row >> 4;
+    const int tl = (int)(((unsigned)tau * Gm) >> 16);
+    return (tau - tl * G) * sr + tl * TILE + (row & 15);
+  };
   const int r0 = leaf * q.rows_per_leaf;
   int nrows = q.rowsA - r0;
   if (nrows > q.rows_per_leaf) nrows = q.rows_per_leaf;
@@ -113,11 +121,12 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const int row = tid + r * QR_NT;
+    const int srow = src_row(row);
     const int rlim = (vrow0 > 0 && vrow0 < nrows) ? vrow0 : nrows;   // rows backed by memory
-    const int rc = (rlim > 0) ? (row < rlim ? row : rlim - 1) : 0;
+    const int rc = (rlim > 0) ? (srow < rlim ? srow : rlim - 1) : 0;
     double val = 0.0;
     if (rlim > 0) val = F ? F[rc] : A[(long)rc * q.ldA + nc];
-    fr[r] = (row < rlim) ? val : 0.0;
+    fr[r] = (row < RPe && srow < rlim) ? val : 0.0;
   }
 
   STAMP_DECL
@@ -125,8 +134,11 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
     // ---- 1. stage panel k of the source into LDS (single HBM read) --------
     // Loads are unconditional (clamped addresses, select afterwards) and 8 are in
     // flight per thread: a guarded load would serialise into branch+load+wait.
+    // live tiles of this panel: [k, hik); rows past them are never read or written
+    const int hik = (ST && G * (k + 1) < ntile) ? G * (k + 1) : ntile;
+    const int rows_k = hik * TILE;
     {
-      const int total = RP * 16;
+      const int total = rows_k * 16;
       // rows of the virtual diagonal block are never read from memory
       const int rmem = (vrow0 > 0 && vrow0 < nrows) ? vrow0 : nrows;
       const int rmax = rmem > 0 ? rmem - 1 : 0;
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
 #pragma unroll
         for (int uu = 0; uu < 8; ++uu) {
           const int idx = i0 + uu * QR_NT + tid;
-          const int row = idx >> 4, c = idx & 15;
+          const int row = src_row(idx >> 4), c = idx & 15;
           const int col = k * TILE + c;
           const int rc = row < rmax ? row : rmax;
           const int cc = col < nA ? col : (nA > 0 ? nA - 1 : 0);
@@ -144,11 +156,11 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
 #pragma unroll
         for (int uu = 0; uu < 8; ++uu) {
           const int idx = i0 + uu * QR_NT + tid;
-          const int row = idx >> 4, c = idx & 15;
+          const int row = src_row(idx >> 4), c = idx & 15;
           const int col = k * TILE + c;
           double val = (row < nrows && col < nA) ? tmp[uu] : 0.0;
           if (vrow0 > 0 && row >= vrow0) val = (col == row - vrow0 && col < nA) ? vdiag : 0.0;
-          if (idx < total) P[c * LDP + row] = val;
+          if (idx < total) P[c * LDP + (idx >> 4)] = val;
         }
       }
     }
@@ -167,20 +179,29 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
       const double* Vj = V + (long)j * RP * 16;
       const double* Tj = T + j * 256;
       const int t0 = j + ((w - j) % QR_NW + QR_NW) % QR_NW;   // first own tile >= j
+      const int hij = (ST && G * (j + 1) < ntile) ? G * (j + 1) : ntile;   // live tiles of V_j: [j, hij)
       const int tlast = ntile - 1;
       double va[MAXT][4];
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) {
         const int t = t0 + QR_NW * i;
-        const double* vt = Vj + (long)(t < ntile ? t : tlast) * 256;
+        if (ST) {                             // wave-uniform: dead slots issue no loads
+          if (t < hij) {
+            const double* vt = Vj + (long)t * 256;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) va[i][s] = vt[64 * s + lane];
+            for (int s = 0; s < 4; ++s) va[i][s] = vt[64 * s + lane];
+          }
+        } else {
+          const double* vt = Vj + (long)(t < ntile ? t : tlast) * 256;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) va[i][s] = vt[64 * s + lane];
+        }
       }
       v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) {
         const int t = t0 + QR_NW * i;
-        if (t < ntile && tile_active(t, j, q.stack_rows)) {
+        if (t < hij) {
           const double* pt = P + lc * LDP + t * TILE + lr;
           v4d tr = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -207,7 +228,7 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) {
         const int t = t0 + QR_NW * i;
-        if (t < ntile && tile_active(t, j, q.stack_rows)) {
+        if (t < hij) {
           double* pt = P + lc * LDP + t * TILE + lr;
           v4d C;
 #pragma unroll
@@ -236,7 +257,7 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       rowi[r] = tid + r * QR_NT;
-      rci[r] = rowi[r] < RP ? rowi[r] : RP - 1;
+      rci[r] = rowi[r] < rows_k ? rowi[r] : rows_k - 1;
     }
 #pragma unroll
     for (int c = 0; c < TILE; ++c) {
@@ -246,14 +267,14 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
 #pragma unroll
     for (int c = 0; c < TILE; ++c) {
       const int p = base + c;               // pivot row == global column
-      if (!(p < nc && p < RP)) {            // padding column: H = I (uniform)
+      if (!(p < nc && p < RPe)) {           // padding column: H = I (uniform)
         if (tid == 0) taus[c] = 0.0;
       } else {
         bool inr[NR], own[NR];
         double x[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-          inr[r] = rowi[r] > p && rowi[r] < RP;
+          inr[r] = rowi[r] > p && rowi[r] < rows_k;
           own[r] = rowi[r] == p;
           x[r] = inr[r] ? pr[r][c] : 0.0;
         }
@@ -324,7 +345,7 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
     for (int c = 0; c < TILE; ++c) {
 #pragma unroll
       for (int r = 0; r < NR; ++r)
-        if (rowi[r] < RP) P[c * LDP + rowi[r]] = pr[r][c];
+        if (rowi[r] < rows_k) P[c * LDP + rowi[r]] = pr[r][c];
     }
     __syncthreads();
 
@@ -335,7 +356,7 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
       const int col = base + c;
       if (col < NPAD) {
         double val = 0.0;
-        if (row <= col && row < RP) val = P[c * LDP + row];
+        if (row <= col && row < RPe) val = P[c * LDP + row];
         Rout[(long)row * NPAD + col] = val;
       }
     }
@@ -345,7 +366,7 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
     // ---- 5. make V_k explicit (unit lower trapezoid, zeros above) ---------
     for (int idx = tid; idx < (base + TILE) * 16; idx += QR_NT) {
       const int row = idx >> 4, c = idx & 15;
-      if (row < RP) {
+      if (row < RPe) {
         if (row < base + c) P[c * LDP + row] = 0.0;
         else if (row == base + c) P[c * LDP + row] = 1.0;
       }
@@ -356,8 +377,7 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
     {
       int t0 = k + ((w - k) % QR_NW + QR_NW) % QR_NW;
       v4d acc = {0.0, 0.0, 0.0, 0.0};
-      for (int t = t0; t < ntile; t += QR_NW) {
-        if (!tile_active(t, k, q.stack_rows)) continue;
+      for (int t = t0; t < hik; t += QR_NW) {
         const double* pt = P + lc * LDP + t * TILE + lr;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -403,7 +423,7 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
     // ---- 7. spill V_k (tile-contiguous: [row][16]) for later panels -------
     if (k < NP - 1) {
       double* Vk = V + (long)k * RP * 16;
-      for (int idx = tid; idx < RP * 16; idx += QR_NT) {
+      for (int idx = tid; idx < rows_k * 16; idx += QR_NT) {
         const int row = idx >> 4, c = idx & 15;
         Vk[idx] = P[c * LDP + row];
       }
@@ -420,7 +440,7 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           const double val = P[c * LDP + rci[r]];
-          vk[r][c] = (rowi[r] < RP) ? val : 0.0;      // rows past the leaf must stay inert
+          vk[r][c] = (rowi[r] < rows_k) ? val : 0.0;  // rows past the live range must stay inert
         }
       }
       double part[TILE];
@@ -456,7 +476,7 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const int row = tid + r * QR_NT;
-    if (row < NPAD) Rout[(long)row * NPAD + nc] = (row < nc && row < RP) ? fr[r] : 0.0;
+    if (row < NPAD) Rout[(long)row * NPAD + nc] = (row < nc && row < RPe) ? fr[r] : 0.0;
   }
   STAMP_OUT
 }
@@ -466,17 +486,26 @@ size_t qr_lds_bytes(int LDP) {
                                    2 * (QR_NW * 16 + 16) + 16);
 }
 
-template <int MAXT>
+template <int MAXT, bool ST>
 static hipError_t launch_qr_t(const QrArgs& q, int nleaf, int B, size_t lds, hipStream_t st) {
   static size_t configured = 0;
   if (lds > configured) {
-    hipError_t e = hipFuncSetAttribute((const void*)qr_panel_kernel<MAXT>,
+    hipError_t e = hipFuncSetAttribute((const void*)qr_panel_kernel<MAXT, ST>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     configured = lds;
   }
-  hipLaunchKernelGGL(qr_panel_kernel<MAXT>, dim3(nleaf, B), dim3(QR_NT), lds, st, q);
+  hipLaunchKernelGGL((qr_panel_kernel<MAXT, ST>), dim3(nleaf, B), dim3(QR_NT), lds, st, q);
   return hipGetLastError();
+}
+
+template <bool ST>
+static hipError_t launch_qr_s(const QrArgs& q, int nleaf, int B, size_t lds, int slots, hipStream_t st) {
+  if (slots <= 2) return launch_qr_t<2, ST>(q, nleaf, B, lds, st);
+  if (slots <= 4) return launch_qr_t<4, ST>(q, nleaf, B, lds, st);
+  if (slots <= 6) return launch_qr_t<6, ST>(q, nleaf, B, lds, st);
+  if (slots <= 8) return launch_qr_t<8, ST>(q, nleaf, B, lds, st);
+  return launch_qr_t<9, ST>(q, nleaf, B, lds, st);
 }
 
 static double* g_qr_dbg = nullptr;
@@ -487,12 +516,19 @@ hipError_t launch_qr(const QrArgs& q_in, int nleaf, int B, hipStream_t st) {
   q.dbg = g_qr_dbg;
   if (g_qr_dbg) g_qr_dbg += (size_t)nleaf * B * 8;   // successive launches append
   const size_t lds = qr_lds_bytes(q.LDP);
-  const int slots = (q.RP / TILE + QR_NW - 1) / QR_NW;
-  if (slots <= 2) return launch_qr_t<2>(q, nleaf, B, lds, st);
-  if (slots <= 4) return launch_qr_t<4>(q, nleaf, B, lds, st);
-  if (slots <= 6) return launch_qr_t<6>(q, nleaf, B, lds, st);
-  if (slots <= 8) return launch_qr_t<8>(q, nleaf, B, lds, st);
-  return launch_qr_t<9>(q, nleaf, B, lds, st);
+  int ntile = q.RP / TILE;
+  // a stack the interleaved staging cannot express is factored as a dense source
+  const bool st_ok = q.stack_rows > 0 && q.stack_rows % TILE == 0 && q.RP % q.stack_rows == 0 &&
+                     q.RP / q.stack_rows >= 2;
+  if (!st_ok) q.stack_rows = 0;
+  if (st_ok) {
+    const int G = q.RP / q.stack_rows;
+    const int NP = (q.N - 1 + TILE - 1) / TILE;       // q.N bounds every per-problem column count
+    if (G * NP < ntile) ntile = G * NP;
+  }
+  const int slots = (ntile + QR_NW - 1) / QR_NW;
+  return st_ok ? launch_qr_s<true>(q, nleaf, B, lds, slots, st)
+               : launch_qr_s<false>(q, nleaf, B, lds, slots, st);
 }
 
 }  // namespace blsq

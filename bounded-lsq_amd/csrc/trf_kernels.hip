@@ -65,16 +65,19 @@ __global__ __launch_bounds__(NS_NT) void trf_prep_kernel(TrfState st, int jac_sc
     st.theta[b] = (th > 0.995) ? th : 0.995;             // trf.py:277
   }
   __syncthreads();
-  // stacked system  [R D | c ; E | 0],  E = diag(sqrt(diag_h))   (trf.py:264-270)
+  // stacked system  [R D | c ; E | 0],  E = diag(sqrt(diag_h))   (trf.py:264-270).
+  // The E block starts on a 16-row boundary (rows n..nb-1 are zero): the QR stages the
+  // two triangular blocks tile-interleaved (qr_panel.hip).
   const int N = n + 1;
-  for (int idx = tid; idx < 2 * n * N; idx += NS_NT) {
+  const int nb = (n + 15) / 16 * 16;
+  for (int idx = tid; idx < (nb + n) * N; idx += NS_NT) {
     const int row = idx / N, col = idx - row * N;
-    double val;
+    double val = 0.0;
     if (row < n) {
       if (col < n) val = (col >= row) ? Rt[(long)row * ld + col] * st.d[vo + col] : 0.0;
       else val = Rt[(long)row * ld + n];
-    } else {
-      const int i = row - n;
+    } else if (row >= nb) {
+      const int i = row - nb;
       val = (col == i) ? sqrt(st.diag_h[vo + i]) : 0.0;
     }
     S[(long)row * ld + col] = val;
