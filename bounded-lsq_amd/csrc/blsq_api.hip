@@ -17,7 +17,7 @@ using namespace blsq;
 
 namespace {
 
-constexpr int RMAX = 1088;          // max padded leaf rows: LDS panel 16 x 1090 doubles
+constexpr int RMAX = QR_MAX_TILES * 16;   // rows a workgroup can stage (qr_panel.hip): 1024
 
 enum Slot { K_QR_LEAF = 0, K_QR_MERGE, K_PREP, K_QR_AUG, K_JACOBI, K_STEP, K_LM_GATE, K_LM_QR, K_LM_SOLVE,
             K_NSLOT };
@@ -30,11 +30,9 @@ inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
 inline int aug_block_rows(int n) { return (n + 15) / 16 * 16; }
 inline int aug_rows(int n) { return 2 * aug_block_rows(n); }
 
-inline int panel_ldp(int RP) {      // smallest LDP >= RP with LDP == 2 (mod 32)
-  int l = RP;
-  while ((l & 31) != 2) ++l;
-  return l;
-}
+// triangles merged per workgroup: the kernel stages ceil(n/16) tiles of each (>= 2 must fit)
+inline int merge_group(int n) { return std::max(2, QR_MAX_TILES / ((n + 15) / 16)); }
+inline bool merge_fits(int n) { return 2 * ((n + 15) / 16) <= QR_MAX_TILES; }
 
 }  // namespace
 
@@ -122,7 +120,7 @@ struct QrTree {
   int build(blsq_ctx* ctx, int B_, int rows, int n_, size_t extra_rp_rows) {
     B = B_; m = rows; n = n_;
     N = n + 1; NPAD = round_up(N, 16); NP = NPAD / 16;
-    if (NPAD > RMAX) return ctx->bad(4, "n too large (n + 1 must be <= 1088)");
+    if (NPAD > RMAX) return ctx->bad(4, "n too large (n + 1 must be <= 1024)");
     int cur_rows = rows;
     bool first = true;
     size_t max_slot_rows = extra_rp_rows;   // max over launches of nslot*RP
@@ -132,19 +130,20 @@ struct QrTree {
       L.rowsA = cur_rows;
       if (first) {
         L.nleaf = std::max(1, (cur_rows + RMAX - 1) / RMAX);
-        if (L.nleaf > 1 && 2 * NPAD > RMAX)
-          return ctx->bad(4, "m > 1088 needs n + 1 <= 544 (TSQR merge capacity)");
+        if (L.nleaf > 1 && !merge_fits(n))
+          return ctx->bad(4, "m > 1024 needs n <= 512 (TSQR merge capacity)");
         L.rows_per_leaf = round_up((cur_rows + L.nleaf - 1) / L.nleaf, 16);
         if (L.rows_per_leaf < NPAD && L.nleaf > 1) L.rows_per_leaf = NPAD;
         L.nleaf = std::max(1, (cur_rows + L.rows_per_leaf - 1) / L.rows_per_leaf);
       } else {
-        const int G = RMAX / NPAD;  // triangles merged per workgroup (>= 2 here)
+        const int G = merge_group(n);   // triangles merged per workgroup (>= 2)
         L.rows_per_leaf = G * NPAD;
         L.nleaf = (cur_rows + L.rows_per_leaf - 1) / L.rows_per_leaf;
       }
       L.RP = std::max(round_up(std::min(L.rows_per_leaf, std::max(cur_rows, 1)), 16), NPAD);
-      if (L.RP > RMAX) return ctx->bad(3, "leaf does not fit LDS");
-      L.LDP = panel_ldp(L.RP);
+      if (qr_staged_tiles(L.RP, first ? 0 : NPAD, N) > QR_MAX_TILES)
+        return ctx->bad(3, "leaf does not fit LDS");
+      L.LDP = 0;
       hipError_t e = L.R.alloc(sizeof(double) * (size_t)B * L.nleaf * NPAD * NPAD);
       if (e != hipSuccess) return ctx->fail(e, "hipMalloc(R level)");
       max_slot_rows = std::max(max_slot_rows, (size_t)B * L.nleaf * L.RP);
@@ -409,8 +408,8 @@ int trf_alloc_state(blsq_trf_plan* p) {
     p->lm_enable = ((env && env[0] == '1') || p->n < min_n) ? 0 : 1;
   }
   p->aug_RP = std::max(aug_rows(p->n), ld);
-  if (p->aug_RP > RMAX) return ctx->bad(4, "n too large for the augmented system (2n <= 1088)");
-  p->aug_LDP = panel_ldp(p->aug_RP);
+  if (aug_rows(p->n) > RMAX) return ctx->bad(4, "n too large for the augmented system (n <= 512)");
+  p->aug_LDP = 0;
   return 0;
 #undef ALLOC
 }
@@ -718,13 +717,13 @@ extern "C" int blsq_tsqr_plan_create(blsq_ctx* ctx, int m_local, int n, int nran
   long long mt = (long long)m_local * nranks;
   p->m_total = mt > 2147483647LL ? 2147483647 : (int)mt;
   const int NPAD = round_up(n + 1, 16);
-  if (nranks > 1 && 2 * NPAD > RMAX) {
+  if (nranks > 1 && !merge_fits(n)) {
     delete p;
-    return ctx->bad(3, "TSQR needs n + 1 <= 544");
+    return ctx->bad(3, "TSQR needs n <= 512");
   }
   const int aug_rp = std::max(aug_rows(n), NPAD);
   // scratch must also cover the combine merges: nranks triangles, G per workgroup
-  const int G = std::max(2, RMAX / NPAD);
+  const int G = merge_group(n);
   const size_t comb_rows = (size_t)((nranks + G - 1) / G) * (size_t)(G * NPAD);
   int rc = p->tree.build(ctx, 1, m_local, n, std::max((size_t)aug_rp, comb_rows));
   if (rc == 0) { p->ld = p->tree.NPAD; rc = trf_alloc_state(p); }
@@ -770,7 +769,7 @@ extern "C" int blsq_tsqr_combine_dev(blsq_trf_plan* p, const double* dtri_stack,
   const int NPAD = p->ld;
   const double* src = dtri_stack;
   int ntri = p->nranks;
-  const int G = std::max(2, RMAX / NPAD);
+  const int G = merge_group(p->n);
   double* pp[2] = {p->Rcomb.as<double>(),
                    p->Rcomb.as<double>() + (size_t)((p->nranks + G - 1) / G + 1) * NPAD * NPAD};
   int flip = 0;
@@ -781,7 +780,6 @@ extern "C" int blsq_tsqr_combine_dev(blsq_trf_plan* p, const double* dtri_stack,
     q.rows_per_leaf = G * NPAD;
     const int nleaf = (ntri + G - 1) / G;
     q.RP = std::max(round_up(std::min(q.rows_per_leaf, q.rowsA), 16), NPAD);
-    q.LDP = panel_ldp(q.RP);
     q.Rout = pp[flip];
     ctx->begin(K_QR_MERGE);
     hipError_t e = launch_qr(q, nleaf, 1, ctx->stream);
@@ -875,7 +873,7 @@ int dog_after_triangle(blsq_dogbox_plan* p, int scale_mode) {
   QrArgs q = p->tree.base_args();
   q.A = p->st.S; q.strideA = (long)p->ld * p->ld; q.ldA = p->ld; q.rowsA = p->n;
   q.F = nullptr; q.strideF = 0; q.ncols_dev = p->st.ncols;
-  q.rows_per_leaf = p->ld; q.RP = p->ld; q.LDP = panel_ldp(p->ld);
+  q.rows_per_leaf = p->ld; q.RP = p->ld;
   q.Rout = p->st.X;
   ctx->begin(K_QR_AUG);
   e = launch_qr(q, 1, p->B, ctx->stream);

@@ -18,7 +18,7 @@ struct QrArgs {
   int N;                  // columns to factor (incl. the rhs column if any)
   int rows_per_leaf;      // source rows per leaf (workgroup)
   int RP;                 // padded leaf rows (multiple of 16, >= NPAD)
-  int LDP;                // LDS column stride of the panel (== 2 mod 32)
+  int LDP;                // LDS column stride of the panel (set by launch_qr)
   int NPAD;               // leading dimension (and row count) of each R output
   int NPmax;              // panels reserved in the V/T scratch per slot
   double* V;              // scratch [slot][NPmax][RP][16]
@@ -30,7 +30,13 @@ struct QrArgs {
   double* dbg;            // diagnostic stamps (nullptr in the product)
   int stack_rows;         // >0: source is a stack of upper-triangular blocks of this many rows
 };
-size_t qr_lds_bytes(int LDP);
+// The kernel stages at most QR_MAX_TILES 16-row tiles per workgroup: all RP/16 tiles of a
+// dense source, G * ceil((N-1)/16) of a stack of G triangular blocks (qr_panel.hip).
+constexpr int QR_MAX_TILES = 64;
+inline bool qr_stack_ok(int RP, int stack_rows) {
+  return stack_rows > 0 && stack_rows % 16 == 0 && RP % stack_rows == 0 && RP / stack_rows >= 2;
+}
+int qr_staged_tiles(int RP, int stack_rows, int N);
 hipError_t launch_qr(const QrArgs& q, int nleaf, int B, hipStream_t st);
 void set_qr_debug_buffer(double* p);
 

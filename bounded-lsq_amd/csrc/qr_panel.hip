@@ -7,21 +7,32 @@
 // here from  [J f] = Q [R c; 0 rho]  — one pass over J.
 //
 // One workgroup factors one (problem, row-leaf):
-//   * left-looking over 16-column panels: panel k of the SOURCE is read from
-//     HBM exactly once (coalesced rows), held column-major in LDS, updated by
-//     all previous block reflectors  P -= V_j (T_j^T (V_j^T P)),  then
-//     factored in LDS (Householder, one fused wave-shuffle + LDS reduction per
-//     column for the norm and the 15 dot products);
-//   * the three GEMMs of each block-reflector application run on
-//     v_mfma_f64_16x16x4_f64; the f64 accumulator layout (row = lane/16 + 4*reg)
-//     is exactly the B-operand layout of k-step `reg`, so W = V^T P feeds
-//     T^T W and V W straight from registers;
-//   * wave w owns row tiles t = w (mod NW) (cyclic, so the shrinking active
-//     row range stays balanced); cross-wave reduction of the 16x16 W goes
-//     through LDS in a fixed order (deterministic results).
+//   * left-looking over 16-column panels.  Panel k of the SOURCE is read from HBM
+//     exactly once, straight into REGISTERS in the f64 MFMA accumulator layout
+//     (lane (lr, lc) holds rows lr + 4 g, column lc of its wave's row tiles), and
+//     stays there while all previous block reflectors are applied:
+//         P -= V_j (T_j^T (V_j^T P)).
+//     The accumulator layout is exactly the B-operand layout of k-step g, so the
+//     panel feeds V_j^T P directly and V_j W accumulates into it in place: the
+//     panel never touches LDS during the update;
+//   * the V_j tiles stream HBM -> LDS by LDS-DMA (global_load_lds, 16 B / lane, no
+//     VGPR staging).  Each wave stages only ITS tiles (tile t belongs to wave
+//     t mod 8), so the staging needs no workgroup barrier: as soon as a tile slot has
+//     fed its last MFMA of reflector j it is refilled with the tile of V_{j+1}, and the
+//     wave later waits with a counted s_waitcnt vmcnt(N) for exactly that slot.  Both
+//     operand shapes (V^T for the first GEMM, V for the third) are read from the same
+//     LDS image — V is stored in HBM pre-swizzled (col ^ row within a tile) so both
+//     reads are bank-conflict-free — and no on-chip transposes are needed;
+//   * the updated panel is then written to LDS (column-major) and Householder-
+//     factored with each thread's rows in registers (one fused wave-shuffle + LDS
+//     reduction per column for the norm and the 15 dot products);
+//   * cross-wave reduction of the 16x16 W goes through LDS in a fixed order
+//     (deterministic results).
 // Leaves produce (N x N) triangles; the same kernel merges stacked triangles
-// (TSQR tree), factors the Coleman-Li augmented system [R D; E] and the
-// dogbox free-column block R[:, free].
+// (TSQR tree), factors the Coleman-Li augmented system [R D; E], the Newton systems
+// [R_aug; sqrt(alpha) I] and the dogbox free-column block R[:, free].
+#include <algorithm>
+
 #include "blsq_device.h"
 #include "blsq_kernels.h"
 
@@ -46,6 +57,43 @@ __device__ __forceinline__ v4d mfma_f64(double a, double b, v4d c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+// One LDS-DMA instruction: 64 lanes x 16 B, global (per-lane address) -> LDS
+// (wave-uniform base + 16 lane).  Completion is tracked by vmcnt, in issue order.
+// The source is (wave-uniform base) + (per-lane 32-bit byte offset): the SGPR-base
+// addressing form, so a slot costs no 64-bit address VGPRs.
+__device__ __forceinline__ void glds16(const double* base_uniform, unsigned byte_off_lane,
+                                       double* lds_uniform) {
+  __builtin_amdgcn_global_load_lds((gptr_t*)((const char*)base_uniform + byte_off_lane),
+                                   (lptr_t*)lds_uniform, 16, 0, 0);
+}
+// copy one 2 KB tile (two DMA instructions); lane16 = 16 * lane id (bytes)
+__device__ __forceinline__ void glds_tile(const double* src_tile_uniform, double* lds_tile,
+                                          unsigned lane16) {
+  glds16(src_tile_uniform, lane16, lds_tile);
+  glds16(src_tile_uniform, lane16 + 1024u, lds_tile + 128);
+}
+// wait until at most 2*n of this wave's DMA instructions are outstanding (n wave-uniform)
+__device__ __forceinline__ void wait_tiles_outstanding(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+// workgroup barrier that orders LDS traffic only: DMA loads stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Structured sources (ST): TSQR merges, the Coleman-Li system [R D; E] and the
 // Newton systems [R_aug; sqrt(alpha) I] are stacks of G upper-triangular blocks of
 // `sr` rows (sr % 16 == 0, RP % sr == 0).  Row tile tl of block qb holds zeros in
@@ -56,14 +104,14 @@ __device__ __forceinline__ v4d mfma_f64(double a, double b, v4d c) {
 // multiplied only there, the cyclic tile->wave map stays balanced, and tiles with
 // tl >= NP (padding rows of each block) never enter at all.
 //
-// MAXT = tile slots per wave (ceil(ntile/8)); tile of slot i is t0 + 8 i.
+// MAXT = tile slots per wave (ceil(ntile/8)); slot i of wave w is tile w + 8 i.
 template <int MAXT, bool ST>
 __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
   constexpr int NR = (MAXT * QR_NW * TILE + QR_NT - 1) / QR_NT;   // rows per thread
   extern __shared__ double lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int w = tid >> 6;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id, in an SGPR
   const int leaf = blockIdx.x;
   const int b = blockIdx.y;
   const int N = q.ncols_dev ? q.ncols_dev[b] : q.N;       // columns to factor
@@ -71,11 +119,18 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
   const int LDP = q.LDP;
   const int NPAD = q.NPAD;
 
-  double* P = lds;                          // [16][LDP], column-major panel
-  double* Wred = P + 16 * LDP;              // [NW][256] partial W tiles
+  // ONE LDS array (a second object de-pipelines the DMA waits).  Region 0 is the
+  // column-major panel [16][LDP] while a panel is factored, and the V staging slots
+  // [NW][MAXT][256] while block reflectors are applied.
+  const int r0sz = (16 * LDP > QR_NW * MAXT * 256) ? 16 * LDP : QR_NW * MAXT * 256;
+  double* P = lds;
+  double* Vs = lds + w * MAXT * 256;        // this wave's staging slots
+  const unsigned lane16_ = 16u * (unsigned)lane;
+  double* Wred = lds + r0sz;                // [NW][256] partial W tiles
   double* Gs = Wred + QR_NW * 256;          // [256]
   double* xch = Gs + 256;                   // [2][NW*16 + 16] per-column exchange
   double* taus = xch + 2 * (QR_NW * 16 + 16);  // [16]
+  double* Tst = taus + 16;                  // [2][256] staged T_j (parity j & 1)
 
   const long slot = (long)b * gridDim.x + leaf;
   double* Rout = q.Rout + slot * (long)NPAD * NPAD;
@@ -112,9 +167,6 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
 
   const int lr = lane >> 4;                 // 0..3
   const int lc = lane & 15;                 // 0..15
-  double ident[4];                          // B-operand slices of the 16x16 identity
-#pragma unroll
-  for (int s = 0; s < 4; ++s) ident[s] = (lc == 4 * s + lr) ? 1.0 : 0.0;
 
   // right-hand side rows owned by this thread (rows tid + 512 r)
   double fr[NR];
@@ -131,91 +183,90 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
 
   STAMP_DECL
   for (int k = 0; k < NP; ++k) {
-    // ---- 1. stage panel k of the source into LDS (single HBM read) --------
-    // Loads are unconditional (clamped addresses, select afterwards) and 8 are in
-    // flight per thread: a guarded load would serialise into branch+load+wait.
     // live tiles of this panel: [k, hik); rows past them are never read or written
     const int hik = (ST && G * (k + 1) < ntile) ? G * (k + 1) : ntile;
     const int rows_k = hik * TILE;
+    // slots of this wave that reflector jj touches: tiles [jj, hi_jj) -> slots [lo, hi)
+    auto slot_lo = [&](int jj) { const int d = jj - w; return d > 0 ? (d + QR_NW - 1) / QR_NW : 0; };
+    auto slot_hi = [&](int jj) {
+      const int hi = (ST && G * (jj + 1) < ntile) ? G * (jj + 1) : ntile;
+      const int d = hi - w;
+      const int n = d > 0 ? (d + QR_NW - 1) / QR_NW : 0;
+      return n < MAXT ? n : MAXT;
+    };
+    unsigned lane16 = lane16_;
+    asm volatile("" : "+v"(lane16));          // keeps per-slot DMA addresses out of long-lived registers
+    // ---- 0. start the DMA of V_0 / T_0 (overlaps the panel load) -----------
+    if (k > 0) {
+      if (w == 0) glds_tile(T, Tst, lane16);
+      const int lo = slot_lo(0), hi = slot_hi(0);
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i)
+        if (i >= lo && i < hi) glds_tile(V + (w + QR_NW * i) * 256, Vs + i * 256, lane16);
+    }
+    // ---- 1. panel k of the source -> registers, accumulator layout (single HBM read)
+    // pc[i][g] = element (row 16 t + lr + 4 g, column 16 k + lc) of tile t = w + 8 i.
+    // Loads are unconditional (clamped addresses, select afterwards).
+    v4d pc[MAXT];
     {
-      const int total = rows_k * 16;
-      // rows of the virtual diagonal block are never read from memory
-      const int rmem = (vrow0 > 0 && vrow0 < nrows) ? vrow0 : nrows;
+      const int rmem = (vrow0 > 0 && vrow0 < nrows) ? vrow0 : nrows;   // rows backed by memory
       const int rmax = rmem > 0 ? rmem - 1 : 0;
-      for (int i0 = 0; i0 < total; i0 += 8 * QR_NT) {
-        double tmp[8];
+      const int col = k * TILE + lc;
+      const int cc = col < nA ? col : (nA > 0 ? nA - 1 : 0);
+      const bool have = nrows > 0 && nA > 0;
+      int lrk = lr;
+      asm volatile("" : "+v"(lrk));           // per-panel recomputation instead of 32 hoisted addresses
 #pragma unroll
-        for (int uu = 0; uu < 8; ++uu) {
-          const int idx = i0 + uu * QR_NT + tid;
-          const int row = src_row(idx >> 4), c = idx & 15;
-          const int col = k * TILE + c;
+      for (int i = 0; i < MAXT; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = src_row((w + QR_NW * i) * TILE + lrk + 4 * g);
           const int rc = row < rmax ? row : rmax;
-          const int cc = col < nA ? col : (nA > 0 ? nA - 1 : 0);
-          tmp[uu] = (nrows > 0 && nA > 0) ? A[(long)rc * q.ldA + cc] : 0.0;
+          pc[i][g] = have ? A[(unsigned)(rc * q.ldA + cc)] : 0.0;
         }
+      }
 #pragma unroll
-        for (int uu = 0; uu < 8; ++uu) {
-          const int idx = i0 + uu * QR_NT + tid;
-          const int row = src_row(idx >> 4), c = idx & 15;
-          const int col = k * TILE + c;
-          double val = (row < nrows && col < nA) ? tmp[uu] : 0.0;
+      for (int i = 0; i < MAXT; ++i) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = src_row((w + QR_NW * i) * TILE + lr + 4 * g);
+          double val = (row < nrows && col < nA) ? pc[i][g] : 0.0;
           if (vrow0 > 0 && row >= vrow0) val = (col == row - vrow0 && col < nA) ? vdiag : 0.0;
-          if (idx < total) P[c * LDP + (idx >> 4)] = val;
+          if (w + QR_NW * i >= hik) val = 0.0;
+          pc[i][g] = val;
         }
       }
     }
-    __syncthreads();
     STAMP(0)
 
     // ---- 2. apply block reflectors 0..k-1:  P -= V_j (T_j^T (V_j^T P)) ----
-    // HBM traffic is what bounds this phase (the V panels of a leaf do not fit
-    // L2/MALL), so every V_j tile is read ONCE (contiguous 512 B per k-step, all
-    // loads of a wave issued before the first MFMA).  The second GEMM needs the
-    // transposed operand layout; it is produced on chip by 4 MFMAs against the
-    // identity: feeding the loaded registers as A = V^T gives D = V^T in C layout
-    // (row = lane/16 + 4 reg), which IS the A-operand layout of V for k-step
-    // `reg`.  Multiplying by exact 0/1 is exact.
+    // HBM traffic bounds this phase (the V panels of a leaf do not fit L2/MALL): every
+    // V_j tile is read ONCE, by DMA into its wave's LDS slot, prefetched one reflector
+    // ahead.  Tile image (2 KB): element (r, c) at 16 r + (c ^ r).  First GEMM operand
+    // A = V^T: lane reads (r = 4 s + lr, c = lc) — a permuted full row per 16 lanes;
+    // third GEMM operand A = V: lane reads (r = lc, c = 4 s + lr) — 2 lanes per bank
+    // pair.  Both conflict-free.
     for (int j = 0; j < k; ++j) {
-      const double* Vj = V + (long)j * RP * 16;
-      const double* Tj = T + j * 256;
-      const int t0 = j + ((w - j) % QR_NW + QR_NW) % QR_NW;   // first own tile >= j
-      const int hij = (ST && G * (j + 1) < ntile) ? G * (j + 1) : ntile;   // live tiles of V_j: [j, hij)
-      const int tlast = ntile - 1;
-      double va[MAXT][4];
-#pragma unroll
-      for (int i = 0; i < MAXT; ++i) {
-        const int t = t0 + QR_NW * i;
-        if (ST) {                             // wave-uniform: dead slots issue no loads
-          if (t < hij) {
-            const double* vt = Vj + (long)t * 256;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) va[i][s] = vt[64 * s + lane];
-          }
-        } else {
-          const double* vt = Vj + (long)(t < ntile ? t : tlast) * 256;
-#pragma unroll
-          for (int s = 0; s < 4; ++s) va[i][s] = vt[64 * s + lane];
-        }
-      }
+      const int lo = slot_lo(j), hi = slot_hi(j);
+      const int lon = slot_lo(j + 1), hin = (j + 1 < k) ? slot_hi(j + 1) : 0;
+      const double* Tj = Tst + (j & 1) * 256;
       v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) {
-        const int t = t0 + QR_NW * i;
-        if (t < hij) {
-          const double* pt = P + lc * LDP + t * TILE + lr;
-          v4d tr = {0.0, 0.0, 0.0, 0.0};
+        if (i >= lo && i < hi) {
+          wait_tiles_outstanding(hi - 1 - i);   // slot i has landed (later slots may still fly)
+          const double* vt = Vs + i * 256;
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            acc = mfma_f64(va[i][s], pt[4 * s], acc);
-            tr = mfma_f64(va[i][s], ident[s], tr);        // on-chip transpose
+            const int r = 4 * s + lr;
+            acc = mfma_f64(vt[16 * r + (lc ^ r)], pc[i][s], acc);
           }
-#pragma unroll
-          for (int s = 0; s < 4; ++s) va[i][s] = tr[s];
         }
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (wave 0: T_j has landed too)
 #pragma unroll
       for (int g = 0; g < 4; ++g) Wred[w * 256 + g * 64 + lane] = acc[g];
-      __syncthreads();
+      lds_barrier();
       v4d W = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int ww = 0; ww < QR_NW; ++ww) {
@@ -226,21 +277,39 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) W2 = mfma_f64(Tj[64 * s + lane], W[s], W2);
 #pragma unroll
+      for (int g = 0; g < 4; ++g) W2[g] = -W2[g];
+      asm volatile("" ::: "memory");
+      if (w == 0 && j + 1 < k) glds_tile(T + (j + 1) * 256, Tst + ((j + 1) & 1) * 256, lane16);
+      const double* Vn = V + (long)(j + 1) * RP * 16;
+#pragma unroll
       for (int i = 0; i < MAXT; ++i) {
-        const int t = t0 + QR_NW * i;
-        if (t < hij) {
-          double* pt = P + lc * LDP + t * TILE + lr;
-          v4d C;
+        if (i >= lo && i < hi) {
+          const double* vt = Vs + i * 256;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) C[g] = pt[4 * g];
-#pragma unroll
-          for (int s = 0; s < 4; ++s) C = mfma_f64(-va[i][s], W2[s], C);
-#pragma unroll
-          for (int g = 0; g < 4; ++g) pt[4 * g] = C[g];
+          for (int s = 0; s < 4; ++s) {
+            const int c = 4 * s + lr;
+            pc[i] = mfma_f64(vt[16 * lc + (c ^ lc)], W2[s], pc[i]);
+          }
+        }
+        if (i >= lon && i < hin) {            // refill the slot with its tile of V_{j+1}
+          asm volatile("" ::: "memory");
+          glds_tile(Vn + (w + QR_NW * i) * 256, Vs + i * 256, lane16);
         }
       }
-      __syncthreads();                      // Wred is reused by the next j
+      lds_barrier();                          // Wred is reused by the next j
     }
+    // ---- 2b. hand the updated panel to LDS (column-major) for the factorisation
+    lds_barrier();                            // every wave is done with the staging slots
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      const int t = w + QR_NW * i;
+      if (t < hik) {
+        double* pt = P + lc * LDP + t * TILE + lr;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pt[4 * g] = pc[i][g];
+      }
+    }
+    __syncthreads();
 
     STAMP(1)
     // ---- 3. Householder-factor rows >= 16k of the panel --------------------
@@ -420,11 +489,11 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
       }
     }
     STAMP(4)
-    // ---- 7. spill V_k (tile-contiguous: [row][16]) for later panels -------
+    // ---- 7. spill V_k for later panels: 2 KB tile images, element (r, c) at 16 r + (c ^ r)
     if (k < NP - 1) {
       double* Vk = V + (long)k * RP * 16;
       for (int idx = tid; idx < rows_k * 16; idx += QR_NT) {
-        const int row = idx >> 4, c = idx & 15;
+        const int row = idx >> 4, c = (idx & 15) ^ (row & 15);   // image position idx holds column c
         Vk[idx] = P[c * LDP + row];
       }
     }
@@ -481,13 +550,14 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
   STAMP_OUT
 }
 
-size_t qr_lds_bytes(int LDP) {
-  return sizeof(double) * (size_t)(16 * LDP + QR_NW * 256 + 256 +
-                                   2 * (QR_NW * 16 + 16) + 16);
+size_t qr_lds_bytes(int LDP, int maxt) {
+  const size_t r0 = std::max((size_t)16 * LDP, (size_t)QR_NW * maxt * 256);
+  return sizeof(double) * (r0 + QR_NW * 256 + 256 + 2 * (QR_NW * 16 + 16) + 16 + 512);
 }
 
 template <int MAXT, bool ST>
-static hipError_t launch_qr_t(const QrArgs& q, int nleaf, int B, size_t lds, hipStream_t st) {
+static hipError_t launch_qr_t(const QrArgs& q, int nleaf, int B, hipStream_t st) {
+  const size_t lds = qr_lds_bytes(q.LDP, MAXT);
   static size_t configured = 0;
   if (lds > configured) {
     hipError_t e = hipFuncSetAttribute((const void*)qr_panel_kernel<MAXT, ST>,
@@ -500,35 +570,39 @@ static hipError_t launch_qr_t(const QrArgs& q, int nleaf, int B, size_t lds, hip
 }
 
 template <bool ST>
-static hipError_t launch_qr_s(const QrArgs& q, int nleaf, int B, size_t lds, int slots, hipStream_t st) {
-  if (slots <= 2) return launch_qr_t<2, ST>(q, nleaf, B, lds, st);
-  if (slots <= 4) return launch_qr_t<4, ST>(q, nleaf, B, lds, st);
-  if (slots <= 6) return launch_qr_t<6, ST>(q, nleaf, B, lds, st);
-  if (slots <= 8) return launch_qr_t<8, ST>(q, nleaf, B, lds, st);
-  return launch_qr_t<9, ST>(q, nleaf, B, lds, st);
+static hipError_t launch_qr_s(const QrArgs& q, int nleaf, int B, int slots, hipStream_t st) {
+  if (slots <= 2) return launch_qr_t<2, ST>(q, nleaf, B, st);
+  if (slots <= 4) return launch_qr_t<4, ST>(q, nleaf, B, st);
+  if (slots <= 6) return launch_qr_t<6, ST>(q, nleaf, B, st);
+  return launch_qr_t<8, ST>(q, nleaf, B, st);
 }
 
 static double* g_qr_dbg = nullptr;
 void set_qr_debug_buffer(double* p) { g_qr_dbg = p; }
 
+int qr_staged_tiles(int RP, int stack_rows, int N) {
+  int ntile = RP / TILE;
+  if (qr_stack_ok(RP, stack_rows)) {
+    const int G = RP / stack_rows;
+    const int NP = (N - 1 + TILE - 1) / TILE;
+    if (G * NP < ntile) ntile = G * NP;
+  }
+  return ntile;
+}
+
 hipError_t launch_qr(const QrArgs& q_in, int nleaf, int B, hipStream_t st) {
   QrArgs q = q_in;
   q.dbg = g_qr_dbg;
   if (g_qr_dbg) g_qr_dbg += (size_t)nleaf * B * 8;   // successive launches append
-  const size_t lds = qr_lds_bytes(q.LDP);
-  int ntile = q.RP / TILE;
   // a stack the interleaved staging cannot express is factored as a dense source
-  const bool st_ok = q.stack_rows > 0 && q.stack_rows % TILE == 0 && q.RP % q.stack_rows == 0 &&
-                     q.RP / q.stack_rows >= 2;
+  const bool st_ok = qr_stack_ok(q.RP, q.stack_rows);
   if (!st_ok) q.stack_rows = 0;
-  if (st_ok) {
-    const int G = q.RP / q.stack_rows;
-    const int NP = (q.N - 1 + TILE - 1) / TILE;       // q.N bounds every per-problem column count
-    if (G * NP < ntile) ntile = G * NP;
-  }
+  const int ntile = qr_staged_tiles(q.RP, q.stack_rows, q.N);   // q.N bounds every per-problem column count
+  if (ntile > QR_MAX_TILES) return hipErrorInvalidValue;
+  // LDS column stride of the staged panel: smallest value >= rows with LDP == 2 (mod 32)
+  q.LDP = (ntile * TILE + 29) / 32 * 32 + 2;
   const int slots = (ntile + QR_NW - 1) / QR_NW;
-  return st_ok ? launch_qr_s<true>(q, nleaf, B, lds, slots, st)
-               : launch_qr_s<false>(q, nleaf, B, lds, slots, st);
+  return st_ok ? launch_qr_s<true>(q, nleaf, B, slots, st) : launch_qr_s<false>(q, nleaf, B, slots, st);
 }
 
 }  // namespace blsq
