@@ -256,11 +256,16 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
         if (i >= lo && i < hi) {
           wait_tiles_outstanding(hi - 1 - i);   // slot i has landed (later slots may still fly)
           const double* vt = Vs + i * 256;
+          double a[4];
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const int r = 4 * s + lr;
-            acc = mfma_f64(vt[16 * r + (lc ^ r)], pc[i][s], acc);
+            a[s] = vt[16 * r + (lc ^ r)];
           }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc = mfma_f64(a[s], pc[i][s], acc);
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 4 LDS reads, then 4 MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (wave 0: T_j has landed too)
@@ -285,11 +290,16 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
       for (int i = 0; i < MAXT; ++i) {
         if (i >= lo && i < hi) {
           const double* vt = Vs + i * 256;
+          double a[4];
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const int c = 4 * s + lr;
-            pc[i] = mfma_f64(vt[16 * lc + (c ^ lc)], W2[s], pc[i]);
+            a[s] = vt[16 * lc + (c ^ lc)];
           }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) pc[i] = mfma_f64(a[s], W2[s], pc[i]);
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
         if (i >= lon && i < hin) {            // refill the slot with its tile of V_{j+1}
           asm volatile("" ::: "memory");
