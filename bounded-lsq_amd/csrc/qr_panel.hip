@@ -181,135 +181,201 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
     fr[r] = (row < RPe && srow < rlim) ? val : 0.0;
   }
 
+  // Panels are processed in PAIRS (k even, k+1): both live in registers while the
+  // reflectors 0..k-1 are applied, so every V_j tile read from HBM (and from LDS)
+  // serves two panels — half the V traffic, which is what bounds the update phase.
+  // Panel k is then factored (panel k+1 stays parked in registers), V_k — still
+  // explicit in LDS — is applied to panel k+1 straight from LDS, and panel k+1 is
+  // factored without touching HBM for V at all.
+  // (Small stacks — MAXT <= 4: the latency-bound [R D; E] / Newton systems — keep one
+  // panel per pass: their V tiles are L2-resident and the pair costs two extra barriers.)
+  constexpr bool PAIR = MAXT >= 6;
+  v4d pd[MAXT];                             // the pair's second panel
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) pd[i] = v4d{0.0, 0.0, 0.0, 0.0};
+
+  // slots of this wave that reflector jj touches: tiles [jj, hi_jj) -> slots [lo, hi)
+  auto slot_lo = [&](int jj) { const int d = jj - w; return d > 0 ? (d + QR_NW - 1) / QR_NW : 0; };
+  auto slot_hi = [&](int jj) {
+    const int hi = (ST && G * (jj + 1) < ntile) ? G * (jj + 1) : ntile;
+    const int d = hi - w;
+    const int n = d > 0 ? (d + QR_NW - 1) / QR_NW : 0;
+    return n < MAXT ? n : MAXT;
+  };
+  // panel kk of the source -> registers, accumulator layout (single HBM read):
+  // x[i][g] = element (row 16 t + lr + 4 g, column 16 kk + lc) of tile t = w + 8 i.
+  // Loads are unconditional (clamped addresses, select afterwards).
+  auto load_panel = [&](v4d* x, int kk) {
+    const int hi = (ST && G * (kk + 1) < ntile) ? G * (kk + 1) : ntile;
+    const int rmem = (vrow0 > 0 && vrow0 < nrows) ? vrow0 : nrows;   // rows backed by memory
+    const int rmax = rmem > 0 ? rmem - 1 : 0;
+    const int col = kk * TILE + lc;
+    const int cc = col < nA ? col : (nA > 0 ? nA - 1 : 0);
+    const bool have = nrows > 0 && nA > 0;
+    int lrk = lr;
+    asm volatile("" : "+v"(lrk));           // per-panel recomputation instead of 32 hoisted addresses
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = src_row((w + QR_NW * i) * TILE + lrk + 4 * g);
+        const int rc = row < rmax ? row : rmax;
+        x[i][g] = have ? A[(unsigned)(rc * q.ldA + cc)] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = src_row((w + QR_NW * i) * TILE + lrk + 4 * g);
+        double val = (row < nrows && col < nA) ? x[i][g] : 0.0;
+        if (vrow0 > 0 && row >= vrow0) val = (col == row - vrow0 && col < nA) ? vdiag : 0.0;
+        if (w + QR_NW * i >= hi) val = 0.0;
+        x[i][g] = val;
+      }
+    }
+  };
+  // cross-wave sum of the 16x16 partial products, then  -(T^T W)  (fixed order: deterministic)
+  auto reduce_w = [&](const v4d& part, const double* Tl) -> v4d {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) Wred[w * 256 + g * 64 + lane] = part[g];
+    lds_barrier();
+    v4d W = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ww = 0; ww < QR_NW; ++ww) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) W[g] += Wred[ww * 256 + g * 64 + lane];
+    }
+    v4d W2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) W2 = mfma_f64(Tl[64 * s + lane], W[s], W2);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) W2[g] = -W2[g];
+    return W2;
+  };
+
   STAMP_DECL
   for (int k = 0; k < NP; ++k) {
     // live tiles of this panel: [k, hik); rows past them are never read or written
     const int hik = (ST && G * (k + 1) < ntile) ? G * (k + 1) : ntile;
     const int rows_k = hik * TILE;
-    // slots of this wave that reflector jj touches: tiles [jj, hi_jj) -> slots [lo, hi)
-    auto slot_lo = [&](int jj) { const int d = jj - w; return d > 0 ? (d + QR_NW - 1) / QR_NW : 0; };
-    auto slot_hi = [&](int jj) {
-      const int hi = (ST && G * (jj + 1) < ntile) ? G * (jj + 1) : ntile;
-      const int d = hi - w;
-      const int n = d > 0 ? (d + QR_NW - 1) / QR_NW : 0;
-      return n < MAXT ? n : MAXT;
-    };
-    unsigned lane16 = lane16_;
-    asm volatile("" : "+v"(lane16));          // keeps per-slot DMA addresses out of long-lived registers
-    // ---- 0. start the DMA of V_0 / T_0 (overlaps the panel load) -----------
-    if (k > 0) {
-      if (w == 0) glds_tile(T, Tst, lane16);
-      const int lo = slot_lo(0), hi = slot_hi(0);
-#pragma unroll
-      for (int i = 0; i < MAXT; ++i)
-        if (i >= lo && i < hi) glds_tile(V + (w + QR_NW * i) * 256, Vs + i * 256, lane16);
-    }
-    // ---- 1. panel k of the source -> registers, accumulator layout (single HBM read)
-    // pc[i][g] = element (row 16 t + lr + 4 g, column 16 k + lc) of tile t = w + 8 i.
-    // Loads are unconditional (clamped addresses, select afterwards).
+    const bool second = PAIR && (k & 1);      // panel k arrives in pd (reflectors 0..k-2 applied)
+    const bool lead = PAIR && !second && (k + 1 < NP);   // panel k+1 rides along in pd
     v4d pc[MAXT];
-    {
-      const int rmem = (vrow0 > 0 && vrow0 < nrows) ? vrow0 : nrows;   // rows backed by memory
-      const int rmax = rmem > 0 ? rmem - 1 : 0;
-      const int col = k * TILE + lc;
-      const int cc = col < nA ? col : (nA > 0 ? nA - 1 : 0);
-      const bool have = nrows > 0 && nA > 0;
-      int lrk = lr;
-      asm volatile("" : "+v"(lrk));           // per-panel recomputation instead of 32 hoisted addresses
+    if (!second) {
+      unsigned lane16 = lane16_;
+      asm volatile("" : "+v"(lane16));        // keeps per-slot DMA addresses out of long-lived registers
+      // ---- 0. start the DMA of V_0 / T_0 (overlaps the panel loads) ---------
+      if (k > 0) {
+        if (w == 0) glds_tile(T, Tst, lane16);
+        const int lo = slot_lo(0), hi = slot_hi(0);
 #pragma unroll
-      for (int i = 0; i < MAXT; ++i) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row = src_row((w + QR_NW * i) * TILE + lrk + 4 * g);
-          const int rc = row < rmax ? row : rmax;
-          pc[i][g] = have ? A[(unsigned)(rc * q.ldA + cc)] : 0.0;
-        }
+        for (int i = 0; i < MAXT; ++i)
+          if (i >= lo && i < hi) glds_tile(V + (w + QR_NW * i) * 256, Vs + i * 256, lane16);
       }
-#pragma unroll
-      for (int i = 0; i < MAXT; ++i) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int row = src_row((w + QR_NW * i) * TILE + lr + 4 * g);
-          double val = (row < nrows && col < nA) ? pc[i][g] : 0.0;
-          if (vrow0 > 0 && row >= vrow0) val = (col == row - vrow0 && col < nA) ? vdiag : 0.0;
-          if (w + QR_NW * i >= hik) val = 0.0;
-          pc[i][g] = val;
-        }
-      }
-    }
-    STAMP(0)
+      // ---- 1. panels k (and k+1) of the source -> registers ------------------
+      load_panel(pc, k);
+      if (lead) load_panel(pd, k + 1);
+      STAMP(0)
 
-    // ---- 2. apply block reflectors 0..k-1:  P -= V_j (T_j^T (V_j^T P)) ----
-    // HBM traffic bounds this phase (the V panels of a leaf do not fit L2/MALL): every
-    // V_j tile is read ONCE, by DMA into its wave's LDS slot, prefetched one reflector
-    // ahead.  Tile image (2 KB): element (r, c) at 16 r + (c ^ r).  First GEMM operand
-    // A = V^T: lane reads (r = 4 s + lr, c = lc) — a permuted full row per 16 lanes;
-    // third GEMM operand A = V: lane reads (r = lc, c = 4 s + lr) — 2 lanes per bank
-    // pair.  Both conflict-free.
-    for (int j = 0; j < k; ++j) {
+      // ---- 2. apply block reflectors 0..k-1:  P -= V_j (T_j^T (V_j^T P)) ----
+      // HBM traffic bounds this phase (the V panels of a leaf do not fit L2/MALL): every
+      // V_j tile is read ONCE per panel pair, by DMA into its wave's LDS slot, prefetched
+      // one reflector ahead.  Tile image (2 KB): element (r, c) at 16 r + (c ^ r).  First
+      // GEMM operand A = V^T: lane reads (r = 4 s + lr, c = lc) — a permuted full row per
+      // 16 lanes; third GEMM operand A = V: lane reads (r = lc, c = 4 s + lr) — 2 lanes
+      // per bank pair.  Both conflict-free.
+      for (int j = 0; j < k; ++j) {
+        const int lo = slot_lo(j), hi = slot_hi(j);
+        const int lon = slot_lo(j + 1), hin = (j + 1 < k) ? slot_hi(j + 1) : 0;
+        const double* Tj = Tst + (j & 1) * 256;
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        v4d acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) {
+          if (i >= lo && i < hi) {
+            wait_tiles_outstanding(hi - 1 - i);   // slot i has landed (later slots may still fly)
+            const double* vt = Vs + i * 256;
+            double a[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const int r = 4 * s + lr;
+              a[s] = vt[16 * r + (lc ^ r)];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              acc = mfma_f64(a[s], pc[i][s], acc);
+              if (PAIR) acc2 = mfma_f64(a[s], pd[i][s], acc2);   // (all-zero pd when there is no second panel)
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 4 LDS reads, then the MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x008, PAIR ? 8 : 4, 0);
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (wave 0: T_j has landed too)
+        const v4d W2 = reduce_w(acc, Tj);
+        v4d W2b = W2;
+        if (PAIR) {
+          lds_barrier();                        // Wred is rewritten for the second panel
+          W2b = reduce_w(acc2, Tj);
+        }
+        asm volatile("" ::: "memory");
+        if (w == 0 && j + 1 < k) glds_tile(T + (j + 1) * 256, Tst + ((j + 1) & 1) * 256, lane16);
+        const double* Vn = V + (long)(j + 1) * RP * 16;
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) {
+          if (i >= lo && i < hi) {
+            const double* vt = Vs + i * 256;
+            double a[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const int c = 4 * s + lr;
+              a[s] = vt[16 * lc + (c ^ lc)];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              pc[i] = mfma_f64(a[s], W2[s], pc[i]);
+              if (PAIR) pd[i] = mfma_f64(a[s], W2b[s], pd[i]);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, PAIR ? 8 : 4, 0);
+          }
+          if (i >= lon && i < hin) {            // refill the slot with its tile of V_{j+1}
+            asm volatile("" ::: "memory");
+            glds_tile(Vn + (w + QR_NW * i) * 256, Vs + i * 256, lane16);
+          }
+        }
+        lds_barrier();                          // Wred is reused by the next j
+      }
+      lds_barrier();                            // every wave is done with the staging slots
+    } else {
+      // ---- 1'+2'. panel k arrives in pd; V_{k-1} is still explicit in LDS (panel
+      // layout) and T_{k-1} in Gs: apply it from LDS.
+      const int j = k - 1;
       const int lo = slot_lo(j), hi = slot_hi(j);
-      const int lon = slot_lo(j + 1), hin = (j + 1 < k) ? slot_hi(j + 1) : 0;
-      const double* Tj = Tst + (j & 1) * 256;
       v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) {
         if (i >= lo && i < hi) {
-          wait_tiles_outstanding(hi - 1 - i);   // slot i has landed (later slots may still fly)
-          const double* vt = Vs + i * 256;
-          double a[4];
+          const double* pt = P + lc * LDP + (w + QR_NW * i) * TILE + lr;   // V^T operand
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int r = 4 * s + lr;
-            a[s] = vt[16 * r + (lc ^ r)];
-          }
-#pragma unroll
-          for (int s = 0; s < 4; ++s) acc = mfma_f64(a[s], pc[i][s], acc);
-          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 4 LDS reads, then 4 MFMAs
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          for (int s = 0; s < 4; ++s) acc = mfma_f64(pt[4 * s], pd[i][s], acc);
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (wave 0: T_j has landed too)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) Wred[w * 256 + g * 64 + lane] = acc[g];
-      lds_barrier();
-      v4d W = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int ww = 0; ww < QR_NW; ++ww) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) W[g] += Wred[ww * 256 + g * 64 + lane];
-      }
-      v4d W2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s = 0; s < 4; ++s) W2 = mfma_f64(Tj[64 * s + lane], W[s], W2);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) W2[g] = -W2[g];
-      asm volatile("" ::: "memory");
-      if (w == 0 && j + 1 < k) glds_tile(T + (j + 1) * 256, Tst + ((j + 1) & 1) * 256, lane16);
-      const double* Vn = V + (long)(j + 1) * RP * 16;
+      const v4d W2 = reduce_w(acc, Gs);
 #pragma unroll
       for (int i = 0; i < MAXT; ++i) {
         if (i >= lo && i < hi) {
-          const double* vt = Vs + i * 256;
-          double a[4];
+          const double* pv = P + lr * LDP + (w + QR_NW * i) * TILE + lc;   // V[row 16 t + lc][col 4 s + lr]
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int c = 4 * s + lr;
-            a[s] = vt[16 * lc + (c ^ lc)];
-          }
-#pragma unroll
-          for (int s = 0; s < 4; ++s) pc[i] = mfma_f64(a[s], W2[s], pc[i]);
-          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        }
-        if (i >= lon && i < hin) {            // refill the slot with its tile of V_{j+1}
-          asm volatile("" ::: "memory");
-          glds_tile(Vn + (w + QR_NW * i) * 256, Vs + i * 256, lane16);
+          for (int s = 0; s < 4; ++s) pd[i] = mfma_f64(pv[4 * s * LDP], W2[s], pd[i]);
         }
       }
-      lds_barrier();                          // Wred is reused by the next j
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) pc[i] = pd[i];
+      lds_barrier();                            // everyone is done reading V_{k-1} from the panel
+      STAMP(0)
     }
     // ---- 2b. hand the updated panel to LDS (column-major) for the factorisation
-    lds_barrier();                            // every wave is done with the staging slots
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
       const int t = w + QR_NW * i;
@@ -318,6 +384,10 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) pt[4 * g] = pc[i][g];
       }
+    }
+    if (PAIR && !lead) {
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) pd[i] = v4d{0.0, 0.0, 0.0, 0.0};
     }
     __syncthreads();
 
@@ -331,11 +401,13 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
     // one LDS exchange + ONE barrier; totals are summed lane-parallel and broadcast
     // with v_readlane.
     const int base = k * TILE;
+    int tidk = tid;
+    if (PAIR) asm volatile("" : "+v"(tidk));  // LDS addresses are recomputed per panel, not kept live
     int rowi[NR], rci[NR];
     double pr[NR][TILE];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-      rowi[r] = tid + r * QR_NT;
+      rowi[r] = tidk + r * QR_NT;
       rci[r] = rowi[r] < rows_k ? rowi[r] : rows_k - 1;
     }
 #pragma unroll
@@ -492,7 +564,7 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
             if (qq < c) sacc = fma(Trow[qq], Gs[qq * 16 + c], sacc);
           Trow[c] = (i == c) ? tc : ((i < c) ? -tc * sacc : 0.0);
         }
-        double* Ts = Wred + i * TILE;         // Wred is idle until the next panel; step 8 reads T here
+        double* Ts = Gs + i * TILE;           // G is consumed (one wave, program order): T_k replaces it
         double* Tk = T + k * 256;
 #pragma unroll
         for (int c = 0; c < TILE; ++c) { Ts[c] = Trow[c]; Tk[i * 16 + c] = Trow[c]; }
@@ -537,7 +609,7 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
       double wl = 0.0;                       // lane i (mod 16): (V_k^T f)_i
 #pragma unroll
       for (int ww = 0; ww < QR_NW; ++ww) wl += ex[ww * 16 + lc];
-      const double* Ts = Wred;               // T_k rows, left there by step 6
+      const double* Ts = Gs;                 // T_k rows, left there by step 6
       double zl = 0.0;                       // lane c: (T_k^T w)_c = sum_i T[i][c] w_i
 #pragma unroll
       for (int i = 0; i < TILE; ++i) zl = fma(Ts[i * TILE + lc], read_lane(wl, i), zl);
