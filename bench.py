@@ -52,7 +52,10 @@ def measured_traffic(kernel, m, n, B):
         cfg = t.get("config", {})
         if (cfg.get("m"), cfg.get("n"), cfg.get("batch")) != (m, n, B):
             return None
-        for name, v in t["kernels"].items():
+        dom = t.get("dominant")
+        if dom and dom.get("slot") == kernel:
+            return dom["hbm_bytes_per_launch"]
+        for name, v in t["kernels"].items():          # older summaries: first QR entry = leaf
             if kernel.split("_")[0] in name:
                 return v["hbm_bytes"]
     except Exception:

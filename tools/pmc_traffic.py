@@ -1,0 +1,60 @@
+"""Summarise rocprofv3 --pmc passes into profiles/<tag>_hbm_traffic.json.
+
+usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> m n batch
+
+Each directory holds the *_counter_collection.csv of ONE separate pass
+(`rocprofv3 --pmc FETCH_SIZE --kernel-trace -d <dir> -- python3 bench.py --steps 1 --warmup 0
+--no-cpu --check 0`, and the same with WRITE_SIZE).  Per MI355X_MICROARCH.md (HBM / rocprofv3
+section) FETCH_SIZE on gfx950 reports half of the bytes of a wide coalesced streaming read, so
+hbm_bytes = 2 * FETCH_SIZE + WRITE_SIZE (KB -> bytes).  Values are summed over the launches of
+one bench step; `per_launch` divides by the launch count.
+"""
+import csv, glob, json, os, sys
+
+
+def collect(d, counter):
+    out = {}
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                if row["Counter_Name"] != counter:
+                    continue
+                name = row["Kernel_Name"].split("(")[0]
+                if "blsq::" not in name:
+                    continue
+                e = out.setdefault(name, {"sum": 0.0, "launches": 0})
+                e["sum"] += float(row["Counter_Value"])
+                e["launches"] += 1
+    return out
+
+
+def main():
+    fdir, wdir, outp, m, n, B = sys.argv[1:7]
+    fetch, write = collect(fdir, "FETCH_SIZE"), collect(wdir, "WRITE_SIZE")
+    kernels = {}
+    for name in sorted(set(fetch) | set(write)):
+        f = fetch.get(name, {"sum": 0.0, "launches": 0})
+        w = write.get(name, {"sum": 0.0, "launches": 0})
+        launches = max(f["launches"], w["launches"], 1)
+        hbm = (2.0 * f["sum"] + w["sum"]) * 1024.0
+        kernels[name] = {"FETCH_SIZE_KB": f["sum"], "WRITE_SIZE_KB": w["sum"], "launches": launches,
+                         "hbm_bytes": hbm, "hbm_bytes_per_launch": hbm / launches}
+    dom = max(kernels, key=lambda k: kernels[k]["hbm_bytes"]) if kernels else None
+    doc = {
+        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 1 "
+                   "--warmup 0 --no-cpu --check 0  (separate passes)",
+        "units": "KB as reported by rocprofv3; summed over the launches of one step",
+        "note": "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads 1/2 of a wide coalesced stream; "
+                "hbm_bytes = 2*FETCH + WRITE as the guide prescribes",
+        "config": {"m": int(m), "n": int(n), "batch": int(B)},
+        "dominant": {"slot": "qr_leaf", "kernel": dom,
+                     "hbm_bytes_per_launch": kernels[dom]["hbm_bytes_per_launch"] if dom else None},
+        "kernels": kernels,
+    }
+    with open(outp, "w") as fh:
+        json.dump(doc, fh, indent=1)
+    print(json.dumps(doc["dominant"]))
+
+
+if __name__ == "__main__":
+    main()
