@@ -558,10 +558,14 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
 #pragma unroll
         for (int c = 0; c < TILE; ++c) {
           const double tc = taus[c];
-          double sacc = 0.0;
+          double gc[TILE];                     // column c of G: read up front, off the dependency chain
+#pragma unroll
+          for (int qq = 0; qq < TILE; ++qq) gc[qq] = (qq < c) ? Gs[qq * 16 + c] : 0.0;
+          double sa[4] = {0.0, 0.0, 0.0, 0.0}; // four interleaved partial sums: a 4x shorter chain
 #pragma unroll
           for (int qq = 0; qq < TILE; ++qq)
-            if (qq < c) sacc = fma(Trow[qq], Gs[qq * 16 + c], sacc);
+            if (qq < c) sa[qq & 3] = fma(Trow[qq], gc[qq], sa[qq & 3]);
+          const double sacc = (sa[0] + sa[1]) + (sa[2] + sa[3]);
           Trow[c] = (i == c) ? tc : ((i < c) ? -tc * sacc : 0.0);
         }
         double* Ts = Gs + i * TILE;           // G is consumed (one wave, program order): T_k replaces it
