@@ -67,10 +67,11 @@ __device__ __forceinline__ void tri_solve_upper(const double* R, int n, int ld,
     __syncthreads();
     for (int i = tid; i < c0; i += TRI_NT) {           // rows above the block
       const double* row = R + (long)i * ld + c0;
-      double acc = 0.0;
+      double rv[16], acc = 0.0;             // unconditional (clamped) loads: a guarded load would
+#pragma unroll                              // serialise into branch + load + wait per element
+      for (int s = 0; s < 16; ++s) rv[s] = row[(s < bs) ? s : bs - 1];
 #pragma unroll
-      for (int s = 0; s < 16; ++s)
-        if (s < bs) acc = fma(row[s], x[c0 + s], acc);
+      for (int s = 0; s < 16; ++s) acc = fma(rv[s], (s < bs) ? x[c0 + s] : 0.0, acc);
       x[i] -= acc;
     }
     __syncthreads();
@@ -102,10 +103,11 @@ __device__ __forceinline__ void tri_solve_upper_t(const double* R, int n, int ld
     }
     __syncthreads();
     for (int j = c0 + 16 + tid; j < n; j += TRI_NT) {   // columns to the right of the block
-      double acc = 0.0;
+      double rv[16], acc = 0.0;             // 16 rows = 16 cache lines: all loads in flight together
 #pragma unroll
-      for (int s = 0; s < 16; ++s)
-        if (s < bs) acc = fma(R[(long)(c0 + s) * ld + j], y[c0 + s], acc);
+      for (int s = 0; s < 16; ++s) rv[s] = R[(long)(c0 + ((s < bs) ? s : bs - 1)) * ld + j];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = fma(rv[s], (s < bs) ? y[c0 + s] : 0.0, acc);
       y[j] -= acc;
     }
     __syncthreads();
