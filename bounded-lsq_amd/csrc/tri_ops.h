@@ -53,8 +53,10 @@ __device__ __forceinline__ void tri_solve_upper(const double* R, int n, int ld,
       const int i = tid & 15;
       double D[16];
 #pragma unroll
-      for (int s = 0; s < 16; ++s)
-        D[s] = (i < bs && s < bs && s > i) ? R[(long)(c0 + i) * ld + c0 + s] : 0.0;
+      for (int s = 0; s < 16; ++s) {        // clamped unconditional loads, select afterwards
+        const double val = R[(long)(c0 + ((i < bs) ? i : bs - 1)) * ld + c0 + ((s < bs) ? s : bs - 1)];
+        D[s] = (i < bs && s < bs && s > i) ? val : 0.0;
+      }
       double r = (i < bs) ? x[c0 + i] : 0.0;
       const double iv = (i < bs) ? invd[c0 + i] : 0.0;
 #pragma unroll
@@ -90,8 +92,10 @@ __device__ __forceinline__ void tri_solve_upper_t(const double* R, int n, int ld
       const int i = tid & 15;               // row i of the lower-triangular block = column i of R's block
       double D[16];
 #pragma unroll
-      for (int s = 0; s < 16; ++s)
-        D[s] = (i < bs && s < bs && s < i) ? R[(long)(c0 + s) * ld + c0 + i] : 0.0;
+      for (int s = 0; s < 16; ++s) {
+        const double val = R[(long)(c0 + ((s < bs) ? s : bs - 1)) * ld + c0 + ((i < bs) ? i : bs - 1)];
+        D[s] = (i < bs && s < bs && s < i) ? val : 0.0;
+      }
       double r = (i < bs) ? y[c0 + i] : 0.0;
       const double iv = (i < bs) ? invd[c0 + i] : 0.0;
 #pragma unroll
