@@ -206,7 +206,7 @@ struct blsq_trf_plan {
   int nranks = 1, m_total = 0;
   DevBuf Rcomb;                     // [1][NPAD*NPAD] merged triangle
   // n-space state
-  DevBuf S, X, vecs, scal2, sweeps;
+  DevBuf X, vecs, scal2, sweeps;
   DevBuf o_vec, o_hits, o_act, o_scal, o_info;
   DevBuf in_J, in_f, in_vec, in_scal;   // staging for the host-pointer API
   TrfState st{};
@@ -354,9 +354,8 @@ int trf_alloc_state(blsq_trf_plan* p) {
     hipError_t e__ = (buf).alloc(bytes);                                \
     if (e__ != hipSuccess) return ctx->fail(e__, "hipMalloc(" #buf ")"); \
   } while (0)
-  ALLOC(p->S, sizeof(double) * B * 2 * mat);
   ALLOC(p->X, sizeof(double) * B * mat);
-  ALLOC(p->vecs, sizeof(double) * (size_t)B * ld * 11);
+  ALLOC(p->vecs, sizeof(double) * (size_t)B * ld * 12);
   ALLOC(p->scal2, sizeof(double) * (size_t)B * 8);
   ALLOC(p->sweeps, sizeof(int) * (size_t)B);
   ALLOC(p->o_vec, sizeof(double) * (size_t)B * ld * 4);
@@ -365,16 +364,15 @@ int trf_alloc_state(blsq_trf_plan* p) {
   ALLOC(p->o_scal, sizeof(double) * (size_t)B * 8);
   ALLOC(p->o_info, sizeof(int) * (size_t)B * 4);
   ALLOC(p->in_scal, sizeof(double) * (size_t)B * 2);
-  HIPCHK(ctx, hipMemsetAsync(p->S.p, 0, p->S.bytes, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(p->vecs.p, 0, p->vecs.bytes, ctx->stream));
   double* v = p->vecs.as<double>();
   const size_t vs = (size_t)B * ld;
   TrfState& st = p->st;
   st.B = B; st.m = p->m_total; st.n = p->n; st.ld = ld;
-  st.S = p->S.as<double>(); st.X = p->X.as<double>();
+  st.X = p->X.as<double>();
   st.x = v; st.lb = v + vs; st.ub = v + 2 * vs; st.scale = v + 3 * vs;
   st.g = v + 4 * vs; st.v = v + 5 * vs; st.d = v + 6 * vs; st.g_h = v + 7 * vs;
-  st.diag_h = v + 8 * vs; st.s = v + 9 * vs; st.uf = v + 10 * vs;
+  st.diag_h = v + 8 * vs; st.s = v + 9 * vs; st.uf = v + 10 * vs; st.ediag = v + 11 * vs;
   double* sc = p->scal2.as<double>();
   st.srange = sc; st.g_norm = sc + 2 * (size_t)B; st.theta = sc + 3 * (size_t)B;
   double* ov = p->o_vec.as<double>();
@@ -423,8 +421,12 @@ int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode) {
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_trf_prep");
   QrArgs q = p->tree.base_args();
-  q.A = p->st.S; q.strideA = 2L * p->ld * p->ld; q.ldA = p->ld;
+  // source = R read in place, columns scaled by d on the fly, on top of the VIRTUAL block
+  // E = diag(ediag): [R D | c ; E | 0] is never written to memory
+  q.A = Rt; q.strideA = (long)p->ld * p->ld; q.ldA = p->ld;
   q.rowsA = aug_block_rows(p->n) + p->n;
+  q.vdiag_row0 = aug_block_rows(p->n); q.vdiag_vec = p->st.ediag;
+  q.colscale = p->st.d; q.stride_vec = p->ld;
   q.F = nullptr; q.strideF = 0;
   q.rows_per_leaf = p->aug_RP; q.RP = p->aug_RP; q.LDP = p->aug_LDP;
   q.Rout = p->st.X;
@@ -513,7 +515,7 @@ extern "C" int blsq_trf_plan_destroy(blsq_trf_plan* p) {
   if (!p) return -1;
   hipStreamSynchronize(p->ctx->stream);
   p->tree.release(); p->Rcomb.release();
-  p->S.release(); p->X.release(); p->vecs.release(); p->scal2.release(); p->sweeps.release();
+  p->X.release(); p->vecs.release(); p->scal2.release(); p->sweeps.release();
   p->o_vec.release(); p->o_hits.release(); p->o_act.release(); p->o_scal.release();
   p->o_info.release(); p->in_J.release(); p->in_f.release(); p->in_vec.release();
   p->in_scal.release();

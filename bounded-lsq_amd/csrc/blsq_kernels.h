@@ -26,7 +26,12 @@ struct QrArgs {
   double* Rout;           // [slot][NPAD][NPAD], slot = b*nleaf + leaf
   // virtual bottom block: source rows >= vdiag_row0 are  vdiag[b] * I  (rhs 0) instead of memory
   int vdiag_row0;         // 0: off
-  const double* vdiag;    // [B] per-problem scalar on that diagonal
+  const double* vdiag;    // [B] per-problem scalar on that diagonal (when vdiag_vec is null)
+  const double* vdiag_vec;   // optional [B][stride_vec]: per-column values on that diagonal
+  // optional column scaling fused into the panel load: source element (r, c) is A[r][c] *
+  // colscale[b][c] for the factored columns (the rhs column is not scaled)
+  const double* colscale;    // [B][stride_vec]
+  long stride_vec;
   double* dbg;            // diagnostic stamps (nullptr in the product)
   int stack_rows;         // >0: source is a stack of upper-triangular blocks of this many rows
 };
@@ -62,10 +67,10 @@ hipError_t launch_jacobi(const JacobiArgs& a, int B, hipStream_t st);
 struct TrfState {         // all device pointers, batch-major, vector stride ld
   int B, m, n, ld;        // ld == NPAD
   const double* Rt;       // [B][ld*ld]   R~ = [R c; 0 rho] of [J f]
-  double* S;              // [B][2*ld*ld] stacked [R D | c ; E | 0]
   double* X;              // [B][ld*ld]   R~_aug, then (Jacobi) rows s_i v_i^T | uf_i
   double *x, *lb, *ub, *scale;            // [B][ld]
   double *g, *v, *d, *g_h, *diag_h;       // [B][ld]
+  double *ediag;                          // [B][ld]  sqrt(diag_h): diagonal of the Coleman-Li block E
   double *s, *uf;                         // [B][ld]
   double *srange;                         // [B][2]
   double *g_norm, *theta;                 // [B]

@@ -161,7 +161,9 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
   const double* A = q.A + (long)b * q.strideA + (long)r0 * q.ldA;
   const double* F = q.F ? q.F + (long)b * q.strideF + r0 : nullptr;
   const int vrow0 = q.vdiag_row0;                       // single-leaf launches only
-  const double vdiag = (vrow0 > 0) ? q.vdiag[b] : 0.0;
+  const double vdiag = (vrow0 > 0 && !q.vdiag_vec) ? q.vdiag[b] : 0.0;
+  const double* vdvec = q.vdiag_vec ? q.vdiag_vec + (long)b * q.stride_vec : nullptr;
+  const double* cscale = q.colscale ? q.colscale + (long)b * q.stride_vec : nullptr;
   double* V = q.V + slot * (long)q.NPmax * RP * 16;     // tiles [t][row][col]
   double* T = q.T + slot * (long)q.NPmax * 256;
 
@@ -212,6 +214,8 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
     const int col = kk * TILE + lc;
     const int cc = col < nA ? col : (nA > 0 ? nA - 1 : 0);
     const bool have = nrows > 0 && nA > 0;
+    const double cs = (cscale && nA > 0) ? cscale[cc] : 1.0;          // fused column scaling
+    const double vd = (vdvec && nA > 0) ? vdvec[cc] : vdiag;          // this column's diagonal value
     int lrk = lr;
     asm volatile("" : "+v"(lrk));           // per-panel recomputation instead of 32 hoisted addresses
 #pragma unroll
@@ -228,8 +232,8 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int row = src_row((w + QR_NW * i) * TILE + lrk + 4 * g);
-        double val = (row < nrows && col < nA) ? x[i][g] : 0.0;
-        if (vrow0 > 0 && row >= vrow0) val = (col == row - vrow0 && col < nA) ? vdiag : 0.0;
+        double val = (row < nrows && col < nA) ? x[i][g] * cs : 0.0;
+        if (vrow0 > 0 && row >= vrow0) val = (col == row - vrow0 && col < nA) ? vd : 0.0;
         if (w + QR_NW * i >= hi) val = 0.0;
         x[i][g] = val;
       }

@@ -24,7 +24,6 @@ __global__ __launch_bounds__(NS_NT) void trf_prep_kernel(TrfState st, int jac_sc
   const int b = blockIdx.x, tid = threadIdx.x;
   const int n = st.n, ld = st.ld;
   const double* Rt = st.Rt + (long)b * ld * ld;
-  double* S = st.S + (long)b * 2 * ld * ld;
   const long vo = (long)b * ld;
   double gmax = 0.0;
   for (int j = tid; j < n; j += NS_NT) {
@@ -55,7 +54,9 @@ __global__ __launch_bounds__(NS_NT) void trf_prep_kernel(TrfState st, int jac_sc
     st.v[vo + j] = v;
     st.d[vo + j] = d;
     st.g_h[vo + j] = d * gj;                             // trf.py:249
-    st.diag_h[vo + j] = gj * jv * (sc * sc);             // trf.py:250
+    const double dhj = gj * jv * (sc * sc);              // trf.py:250
+    st.diag_h[vo + j] = dhj;
+    st.ediag[vo + j] = sqrt(dhj);                        // E = diag(sqrt(diag_h))  (trf.py:264-270)
     gmax = nanmax2(gmax, fabs(gj * v));                  // trf.py:252
   }
   gmax = block_max(gmax, red);
@@ -64,24 +65,8 @@ __global__ __launch_bounds__(NS_NT) void trf_prep_kernel(TrfState st, int jac_sc
     const double th = 1.0 - gmax;
     st.theta[b] = (th > 0.995) ? th : 0.995;             // trf.py:277
   }
-  __syncthreads();
-  // stacked system  [R D | c ; E | 0],  E = diag(sqrt(diag_h))   (trf.py:264-270).
-  // The E block starts on a 16-row boundary (rows n..nb-1 are zero): the QR stages the
-  // two triangular blocks tile-interleaved (qr_panel.hip).
-  const int N = n + 1;
-  const int nb = (n + 15) / 16 * 16;
-  for (int idx = tid; idx < (nb + n) * N; idx += NS_NT) {
-    const int row = idx / N, col = idx - row * N;
-    double val = 0.0;
-    if (row < n) {
-      if (col < n) val = (col >= row) ? Rt[(long)row * ld + col] * st.d[vo + col] : 0.0;
-      else val = Rt[(long)row * ld + n];
-    } else if (row >= nb) {
-      const int i = row - nb;
-      val = (col == i) ? sqrt(st.diag_h[vo + i]) : 0.0;
-    }
-    S[(long)row * ld + col] = val;
-  }
+  // The stacked system [R D | c ; E | 0] (trf.py:264-270) is never materialised: the QR reads
+  // R in place, scales column j by d_j while loading and takes E from `ediag` (qr_panel.hip).
 }
 
 hipError_t launch_trf_prep(const TrfState& st, int jac_scaling, hipStream_t s) {
@@ -115,14 +100,15 @@ __device__ double step_to_bound_dev(const StepCtx& c, const double* xs,
   return block_min(tmin, c.red);
 }
 
-// u = R_h s  (R_h upper triangular, row-major, stride ld): one wave per row.
-__device__ void tri_matvec(const double* Rh, int n, int ld, const double* svec,
+// u = R_h s = (R D) s  (R upper triangular, row-major, stride ld; D = diag(dvec)): one wave per row.
+__device__ void tri_matvec(const double* R, const double* dvec, int n, int ld, const double* svec,
                            double* u) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int i = w; i < n; i += NS_NW) {
-    const double* row = Rh + (long)i * ld;
+    const double* row = R + (long)i * ld;
     double acc = 0.0;
-    for (int j = i + lane; j < n; j += WAVE) acc = fma(row[j], svec[j], acc);
+    // (R[i][j] * d[j]) * s[j]: the same roundings as a materialised R_h = R D
+    for (int j = i + lane; j < n; j += WAVE) acc = fma(row[j] * dvec[j], svec[j], acc);
     acc = wave_sum(acc);
     if (lane == 0) u[i] = acc;
   }
@@ -178,7 +164,7 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
   const double* sv = st.s + vo;
   const double* uf = st.uf + vo;
   const double* X = st.X + (long)b * ld * ld;
-  const double* Rh = st.S + (long)b * 2 * ld * ld;        // top block = R D
+  const double* Rh = st.Rt + (long)b * ld * ld;           // R; R_h = R D is applied on the fly
   const double* xg = st.x + vo;
   const double* dg = st.d + vo;
   const double* gh = st.g_h + vo;
@@ -301,7 +287,7 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     const double f = (tt < 1.0) ? tt : 1.0;                  // min(theta*to_bound, 1)
     for (int j = tid; j < n; j += NS_NT) ph[j] *= f;
     __syncthreads();
-    tri_matvec(Rh, n, ld, ph, up);
+    tri_matvec(Rh, dg, n, ld, ph, up);
     const double q2 = dot_dev(up, up, n, red);
     double dq = 0.0, lin = 0.0;
     for (int j = tid; j < n; j += NS_NT) {
@@ -350,11 +336,11 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     double r_lo;
     if (r_hi > 0.0) r_lo = (1.0 - theta) * p_stride / r_hi;
     else r_lo = -1.0;
-    tri_matvec(Rh, n, ld, ph, up);                           // J_h p_h (stride-scaled)
+    tri_matvec(Rh, dg, n, ld, ph, up);                           // J_h p_h (stride-scaled)
     bool have_r = false;
     double r_t = 0.0;
     if (status == 0 && r_lo <= r_hi) {
-      tri_matvec(Rh, n, ld, rh, ur);
+      tri_matvec(Rh, dg, n, ld, rh, ur);
       const double vv = dot_dev(ur, ur, n, red);
       const double sds = dot3_dev(rh, dh, rh, n, red);
       const double qa = 0.5 * (vv + sds);
@@ -383,7 +369,7 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     double g_hi = (to_trg < to_bg) ? to_trg : to_bg;
     for (int j = tid; j < n; j += NS_NT) tmp[j] = -gh[j];
     __syncthreads();
-    tri_matvec(Rh, n, ld, tmp, ug);                          // J_h (-g_h)
+    tri_matvec(Rh, dg, n, ld, tmp, ug);                          // J_h (-g_h)
     const double gvv = dot_dev(ug, ug, n, red);
     const double gsds = dot3_dev(tmp, dh, tmp, n, red);
     const double ga = 0.5 * (gvv + gsds);
