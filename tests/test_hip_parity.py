@@ -280,3 +280,98 @@ def test_mixed_rank_batch_takes_both_paths(bl):
     sol.close()
     os.environ.pop("BLSQ_SVDFREE_MIN_N", None)
     os.environ.pop("BLSQ_NO_SVDFREE", None)
+
+
+# ---- size-independent properties at BASELINE.json's full size (4096 x 256) -----------------
+FULL = (4096, 256)
+
+
+def _full_batch(kind, B, seed):
+    from bounded_lsq import _synth
+    m, n = FULL
+    return (_synth.trf_batch if kind == "trf" else _synth.dogbox_batch)(seed, B, m, n)
+
+
+def test_full_size_batch_independence_and_determinism(bl):
+    """A problem's result does not depend on its batch neighbours or on the run: solving a
+    batch of 24, the same batch again, and two of its problems alone (B = 1 plans) gives
+    bit-identical steps and masks."""
+    m, n = FULL
+    B = 24
+    P = _full_batch("trf", B, 77)
+    Delta = np.where(np.arange(B) % 2 == 0, 10.0, 0.5)
+    sol = bl.TrfStepSolver(B, m, n)
+    sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+    S1 = sol.step(Delta, np.zeros(B))
+    step1, hits1, xnew1 = S1.step.copy(), S1.hits.copy(), S1.x_new.copy()
+    sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+    S2 = sol.step(Delta, np.zeros(B))
+    np.testing.assert_array_equal(step1, S2.step)
+    np.testing.assert_array_equal(hits1, S2.hits)
+    sol.close()
+    one = bl.TrfStepSolver(1, m, n)
+    for b in (3, 20):
+        sl = slice(b, b + 1)
+        one.factor(P["J"][sl], P["f"][sl], P["x"][sl], P["lb"][sl], P["ub"][sl], P["scale"][sl])
+        S = one.step(Delta[sl], np.zeros(1))
+        np.testing.assert_array_equal(S.step[0], step1[b])
+        np.testing.assert_array_equal(S.hits[0], hits1[b])
+        np.testing.assert_array_equal(S.x_new[0], xnew1[b])
+    one.close()
+
+
+def test_full_size_row_permutation_invariance(bl):
+    """J^T J and J^T f do not change when the residuals are reordered, so neither does the
+    step: permuting the m rows of (J, f) moves the TRF and dogbox steps by rounding only and
+    leaves every mask unchanged."""
+    m, n = FULL
+    B = 4
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(m)
+    P = _full_batch("trf", B, 78)
+    Delta = np.where(np.arange(B) % 2 == 0, 10.0, 0.5)
+    sol = bl.TrfStepSolver(B, m, n)
+    sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+    S = sol.step(Delta, np.zeros(B))
+    step, hits, branch = S.step.copy(), S.hits.copy(), S.branch.copy()
+    sol.factor(np.ascontiguousarray(P["J"][:, perm]), np.ascontiguousarray(P["f"][:, perm]),
+               P["x"], P["lb"], P["ub"], P["scale"])
+    Sp = sol.step(Delta, np.zeros(B))
+    for b in range(B):
+        assert rel(Sp.step[b], step[b]) < RTOL
+    np.testing.assert_array_equal(Sp.hits, hits)
+    np.testing.assert_array_equal(Sp.branch, branch)
+    sol.close()
+    Pd = _full_batch("dogbox", B, 79)
+    Dd = np.where(np.arange(B) % 2 == 0, 0.02, 0.005)
+    dog = bl.DogboxStepSolver(B, m, n)
+    dog.factor(Pd["J"], Pd["f"], Pd["x"], Pd["lb"], Pd["ub"], Pd["scale"], Pd["on_bound"])
+    D = dog.step(Dd)
+    dstep, donb = D.step.copy(), D.on_bound_new.copy()
+    dog.factor(np.ascontiguousarray(Pd["J"][:, perm]), np.ascontiguousarray(Pd["f"][:, perm]),
+               Pd["x"], Pd["lb"], Pd["ub"], Pd["scale"], Pd["on_bound"])
+    Dp = dog.step(Dd)
+    for b in range(B):
+        assert rel(Dp.step[b], dstep[b]) < RTOL
+    np.testing.assert_array_equal(Dp.on_bound_new, donb)
+    dog.close()
+
+
+def test_full_size_residual_scaling(bl):
+    """Scaling f and Delta by 4 (a power of two: exact in binary floating point) scales the
+    unconstrained trust-region step exactly — same Newton iterates, same masks."""
+    m, n = FULL
+    B = 4
+    P = _full_batch("trf", B, 80)
+    lb = np.full_like(P["lb"], -np.inf); ub = np.full_like(P["ub"], np.inf)
+    Delta = np.full(B, 0.5)
+    sol = bl.TrfStepSolver(B, m, n)
+    sol.factor(P["J"], P["f"], P["x"], lb, ub, P["scale"])
+    S = sol.step(Delta, np.zeros(B))
+    step, niter = S.step.copy(), S.n_iter.copy()
+    sol.factor(P["J"], 4.0 * P["f"], P["x"], lb, ub, P["scale"])
+    S4 = sol.step(4.0 * Delta, np.zeros(B))
+    np.testing.assert_array_equal(S4.n_iter, niter)
+    for b in range(B):
+        assert rel(S4.step[b], 4.0 * step[b]) < RTOL
+    sol.close()
