@@ -461,18 +461,36 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
         __syncthreads();
         STAMP(7)
         double totl = 0.0;                   // lane i (mod 16): total of value i
+        double exv[QR_NW];
 #pragma unroll
-        for (int ww = 0; ww < QR_NW; ++ww) totl += ex[ww * 16 + lc];
+        for (int ww = 0; ww < QR_NW; ++ww) exv[ww] = ex[ww * 16 + lc];
         const double pvl = ex[QR_NW * 16 + lc];
+        __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);   // all exchange reads in flight together
+#pragma unroll
+        for (int ww = 0; ww < QR_NW; ++ww) totl += exv[ww];
         const double xn2 = read_lane(totl, 0);
         const double alpha = read_lane(pvl, 0);
         double beta, tau, scal;
         if (xn2 == 0.0) {
           beta = alpha; tau = 0.0; scal = 0.0;
         } else {
-          beta = -copysign(sqrt(alpha * alpha + xn2), alpha);
-          tau = (beta - alpha) / beta;
-          scal = 1.0 / (alpha - beta);
+          // The column step is a latency chain every wave runs: one v_rsq + one v_rcp (two Newton
+          // steps each, full precision) instead of a sqrt and two divisions:
+          //   norm = s rsqrt(s),  tau = (beta - alpha)/beta = 1 + |alpha|/norm,
+          //   1/(alpha - beta) = sign(alpha)/(|alpha| + norm).
+          const double ssq = fma(alpha, alpha, xn2);
+          double y = __builtin_amdgcn_rsq(ssq);
+          y = y * fma(-0.5 * ssq * y, y, 1.5);
+          y = y * fma(-0.5 * ssq * y, y, 1.5);
+          const double nrm = ssq * y;
+          const double aa = fabs(alpha);
+          beta = -copysign(nrm, alpha);
+          tau = fma(aa, y, 1.0);
+          const double den = aa + nrm;
+          double rc = __builtin_amdgcn_rcp(den);
+          rc = rc * fma(-den, rc, 2.0);
+          rc = rc * fma(-den, rc, 2.0);
+          scal = copysign(rc, alpha);
         }
         const double wvl = tau * (pvl + scal * totl);      // lane i holds w_i
         double vv[NR];
