@@ -11,9 +11,11 @@ from ._hip_step import (TrfStepSolver, DogboxStepSolver, SCALE_GIVEN,  # noqa: F
 from ._drivers import trf, dogbox  # noqa: F401
 from ._frontend import least_squares  # noqa: F401
 from ._batch import least_squares_batch  # noqa: F401
+from ._outer import OuterDriver  # noqa: F401
 from ._hostmath import (active_mask as find_active_constraints,  # noqa: F401
                         prepare_bounds, cl_optimality as CL_optimality,
                         shift_into_interior as make_strictly_feasible)
 
 __all__ = ['dogbox', 'trf', 'find_active_constraints', 'CL_optimality', 'prepare_bounds',
-           'make_strictly_feasible', 'least_squares', 'least_squares_batch', 'TrfStepSolver', 'DogboxStepSolver']
+           'make_strictly_feasible', 'least_squares', 'least_squares_batch', 'TrfStepSolver', 'DogboxStepSolver',
+           'OuterDriver']

@@ -58,6 +58,15 @@ SIGNATURES = {
     "blsq_tsqr_plan_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "blsq_tsqr_local_dev": (C.c_int, [vp, vp, vp, vp]),
     "blsq_tsqr_combine_dev": (C.c_int, [vp] + [vp] * 5 + [C.c_int]),
+    "blsq_outer_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    "blsq_outer_destroy": (C.c_int, [vp]),
+    "blsq_outer_buffers": (C.c_int, [vp] + [C.POINTER(vp)] * 6),
+    "blsq_outer_start": (C.c_int, [vp] + [vp] * 5 + [C.c_int, C.c_double, C.c_double, C.c_double,
+                                                    C.c_int]),
+    "blsq_outer_begin": (C.c_int, [vp]),
+    "blsq_outer_propose": (C.c_int, [vp, c_int32_p]),
+    "blsq_outer_judge": (C.c_int, [vp, c_int32_p]),
+    "blsq_outer_fetch": (C.c_int, [vp] + [vp] * 8),
 }
 
 _lib = None

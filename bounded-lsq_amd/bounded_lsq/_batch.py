@@ -38,12 +38,15 @@ def _bounds_2d(bounds, B, n):
 
 def least_squares_batch(fun, x0, jac, bounds=(-np.inf, np.inf), method='trf',
                         ftol=EPS ** 0.5, xtol=EPS ** 0.5, gtol=EPS ** 0.5, max_nfev=None,
-                        scaling=1.0, ctx=None):
+                        scaling=1.0, ctx=None, driver='host'):
     """Solve B bound-constrained least-squares problems of identical shape.
 
     fun : callable, ``fun(X) -> (B, m)`` residuals for ``X`` (B, n)
     x0  : (B, n) initial guesses;  jac : callable, ``jac(X) -> (B, m, n)``
     bounds : pair broadcastable to (B, n);  scaling : 'jac' or broadcastable to (n,)
+    driver : 'host' — the per-problem accept / update logic runs here in Python around batched
+             C-ABI calls; 'device' — it runs on the GPU (``OuterDriver``, blsq_outer_*), x / f / J
+             stay resident and only fresh Jacobians are uploaded and factored.
     Returns a list of B ``OptimizeResult`` (fields as ``least_squares``).
     """
     if method not in ('trf', 'dogbox'):
@@ -63,6 +66,11 @@ def least_squares_batch(fun, x0, jac, bounds=(-np.inf, np.inf), method='trf',
     trf = method == 'trf'
     if max_nfev is None:
         max_nfev = n * 100
+    if driver not in ('host', 'device'):
+        raise ValueError("`driver` must be 'host' or 'device'.")
+    if driver == 'device':
+        return _device_batch(fun, jac, X0, lb, ub, trf, use_jac, scaling, ftol, xtol, gtol,
+                             max_nfev, ctx)
 
     def feval(X):
         F = np.ascontiguousarray(fun(X), dtype=float)
@@ -224,3 +232,57 @@ def least_squares_batch(fun, x0, jac, bounds=(-np.inf, np.inf), method='trf',
         return results
     finally:
         solver.close()
+
+
+def _device_batch(fun, jac, X0, lb, ub, trf, use_jac, scaling, ftol, xtol, gtol, max_nfev, ctx):
+    """`least_squares_batch` on the device-resident outer driver (same results, same counts)."""
+    from ._outer import OuterDriver
+    B, n = X0.shape
+    if trf:                                                   # trf.py:201
+        xs = np.stack([shift_into_interior(X0[b], lb[b], ub[b], rstep=1e-10) for b in range(B)])
+    else:
+        xs = X0.copy()
+    F0 = np.ascontiguousarray(fun(xs), dtype=float)
+    if F0.ndim != 2 or F0.shape[0] != B:
+        raise RuntimeError("`fun` must return an array of shape (B, m).")
+    m = F0.shape[1]
+    calls = {"first": True}
+
+    def fun_cached(X):                     # the driver asks for fun(x_start) first: reuse F0
+        if calls["first"]:
+            calls["first"] = False
+            return F0
+        F = np.ascontiguousarray(fun(X), dtype=float)
+        if F.shape != (B, m):
+            raise RuntimeError("`fun` must return an array of shape (B, m).")
+        return F
+
+    def jac_checked(X):
+        J = np.ascontiguousarray(jac(X), dtype=float)
+        if J.ndim != 3 or J.shape[0] != B or J.shape[2] != n:
+            raise RuntimeError("`jac` must return an array of shape (B, m, n).")
+        if J.shape[1] != m:
+            raise RuntimeError("Inconsistent dimensions between the returns of "
+                               "`fun` and `jac` on the first iteration.")
+        return J
+
+    scale = np.ones((B, n)) if use_jac else np.broadcast_to(1 / np.asarray(scaling, float), (B, n))
+    drv = OuterDriver('trf' if trf else 'dogbox', B, m, n, ctx=ctx)
+    try:
+        drv.start(X0, xs, lb, ub, scale, use_jac, ftol, xtol, gtol, max_nfev)
+        R = drv.run_host(fun_cached, jac_checked)
+        Jfin = drv._down(drv.d_J, (B, m, n))
+    finally:
+        drv.close()
+    results = []
+    for b in range(B):
+        x = R["x"][b]
+        mask = active_mask(x, lb[b], ub[b], rtol=xtol) if trf else R["on_bound"][b].astype(int)
+        r = OptimizeResult(x=x.copy(), fun=R["f"][b].copy(), jac=Jfin[b].copy(),
+                           obj_value=float(R["obj"][b]), optimality=float(R["optimality"][b]),
+                           active_mask=mask, nfev=int(R["nfev"][b]), njev=int(R["njev"][b]),
+                           status=int(R["status"][b]), x_covariance=None)
+        r.message = TERMINATION_MESSAGES[r.status]
+        r.success = r.status > 0
+        results.append(r)
+    return results

@@ -145,4 +145,33 @@ struct DogStepOut {
 hipError_t launch_dog_step(const DogState& st, const double* Delta,
                            const DogStepOut& out, hipStream_t s);
 
+
+// ------------------------------------------- batched outer drivers (8f-1) ----
+struct OuterState {       // device pointers; method 0 = TRF, 1 = dogbox
+  int B, m, n, ld, method;
+  double ftol, xtol, gtol;
+  int max_nfev;
+  // views of the step plan's state (vector stride ld)
+  double *x, *lb, *ub, *scale;
+  const double* g_norm_fac;   // [B]  from the last factorisation
+  const double* v;            // [B][ld]  Coleman-Li v (TRF)
+  const int* ncols;           // [B]  dogbox: n_free + 1 (0: every variable active)
+  long long* on_bound;        // [B][ld]  dogbox
+  const double *o_step, *o_xnew, *o_scal;   // step outputs (TrfStepOut / DogStepOut)
+  const int* o_info;
+  const long long* o_onb;
+  // driver-owned
+  double* x0;                 // [B][n]  unshifted initial point (Delta_0)
+  double *xc, *xt;            // [B][n]  current / trial point, contiguous, for the callbacks
+  double *f, *ft;             // [B][m]  residuals at x / at the trial point
+  double *Delta, *alpha, *obj, *gnorm, *actual;                    // [B]
+  int *nfev, *njev, *pending, *result, *done, *at_top, *accepted;  // [B]
+  int* ncols_fac;             // [B]  n + 1 where a fresh Jacobian must be factored, else 0
+  int* counts;                // [2]  active problems, accepted problems (of this tick)
+};
+hipError_t launch_outer_begin(const OuterState& o, hipStream_t s);
+hipError_t launch_outer_top(const OuterState& o, hipStream_t s);
+hipError_t launch_outer_trial(const OuterState& o, hipStream_t s);
+hipError_t launch_outer_judge(const OuterState& o, hipStream_t s);
+
 }  // namespace blsq

@@ -163,6 +163,48 @@ int blsq_tsqr_combine_dev(blsq_trf_plan* plan, const double* dtri_stack /*nranks
                           const double* dx, const double* dlb, const double* dub,
                           double* dscale_io, int scale_mode);
 
+/* ---- batched outer trust-region drivers, device-resident ------------------
+ * Replaces, for B problems of one shape advancing in lock-step, the Python loops around the
+ * step path: trf.py:173-237 (initialisation), :238-261 (top of the outer loop: nfev / gtol
+ * checks), :309-358 (ratio test, Delta / alpha update, ftol / xtol tests, accept) and
+ * dogbox.py:100-163, :164-194, :221-272.  x, f, J and every per-problem scalar stay on the
+ * device; only the callbacks' inputs/outputs (device buffers owned by the driver) and ONE
+ * integer per call (active / accepted problems) are visible to the host.
+ *
+ *   create -> buffers -> start(x0,lb,ub,scale,...)
+ *   caller:  f  <- fun(x),  J <- jac(x)            (into the driver's buffers)
+ *   begin                                          first factorisation, Delta_0
+ *   loop:  propose(&n_active)   if n_active == 0: stop
+ *          caller: f_trial <- fun(x_trial)
+ *          judge(&n_accepted)
+ *          caller: J[b] <- jac(x[b]) for the problems with accepted[b] != 0   (if n_accepted)
+ *   fetch(...)
+ * Per-problem results (x, nfev, njev, status, ...) are what the reference's driver returns for
+ * that problem alone; a terminated problem is frozen.  method: 0 = 'trf', 1 = 'dogbox'. */
+typedef struct blsq_outer blsq_outer;
+int blsq_outer_create(blsq_ctx* ctx, int method, int B, int m, int n, blsq_outer** out);
+int blsq_outer_destroy(blsq_outer* o);
+/* Device buffers read / written by the callbacks (any pointer argument may be NULL):
+ * x [B][n] current points, x_trial [B][n], f [B][m] residuals at x, f_trial [B][m],
+ * J [B][m][n] Jacobians at x, accepted [B] int32 flags set by blsq_outer_judge. */
+int blsq_outer_buffers(blsq_outer* o, double** x, double** x_trial, double** f, double** f_trial,
+                       double** J, int32_t** accepted);
+/* Host inputs, all [B][n]: x0 (as given by the user), x_start (x0 moved strictly inside the
+ * bounds for 'trf', trf.py:201; == x0 for 'dogbox'), lb, ub, scale (= 1/scaling, or ones with
+ * jac_scaling != 0).  max_nfev > 0.  Uploads and resets the state; afterwards buffer `x` holds
+ * x_start. */
+int blsq_outer_start(blsq_outer* o, const double* x0, const double* x_start, const double* lb,
+                     const double* ub, const double* scale, int jac_scaling, double ftol,
+                     double xtol, double gtol, int max_nfev);
+int blsq_outer_begin(blsq_outer* o);
+int blsq_outer_propose(blsq_outer* o, int32_t* n_active);
+int blsq_outer_judge(blsq_outer* o, int32_t* n_accepted);
+/* Host outputs (any may be NULL): x [B][n], f [B][m], obj [B], optimality [B], on_bound [B][n]
+ * (dogbox's final mask; zeros for 'trf' whose mask the caller derives from x, trf.py:257),
+ * nfev, njev, status [B]. */
+int blsq_outer_fetch(blsq_outer* o, double* x, double* f, double* obj, double* optimality,
+                     int64_t* on_bound, int32_t* nfev, int32_t* njev, int32_t* status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -233,6 +233,56 @@ def test_least_squares_batch_matches_sequential(method, scaling, bounded):
         assert r.success == ref.success and r.message == ref.message
 
 
+@pytest.mark.parametrize("method", ["trf", "dogbox"])
+@pytest.mark.parametrize("scaling", [1.0, "jac"])
+@pytest.mark.parametrize("bounded", [False, True])
+def test_device_outer_driver_matches_sequential(method, scaling, bounded):
+    """The device-resident outer driver (blsq_outer_*: ratio test, Delta / alpha update,
+    termination and accept on the GPU, masked re-factorisation) returns, problem by problem,
+    what the sequential host driver returns: same nfev / njev / status, same x."""
+    from bounded_lsq import least_squares, least_squares_batch
+    B = 10
+    fun, jac, Y, t = _expfit_batch(B)
+    X0 = np.tile(np.array([1.0, -0.1, 1.0, 1.0]), (B, 1))
+    X0[:, 0] += 0.05 * np.arange(B)
+    bounds = (np.array([0.0, -2.0, 0.0, 0.0]), np.array([1.8, 0.0, 3.0, 2.0])) if bounded \
+        else (-np.inf, np.inf)
+    res = least_squares_batch(fun, X0, jac, bounds=bounds, method=method, scaling=scaling,
+                              driver='device')
+    assert len(res) == B
+    for b in range(B):
+        def fun_b(p, b=b):
+            return p[0] * np.exp(p[1] * t) + p[2] * np.cos(p[3] * t) - Y[b]
+
+        def jac_b(p, b=b):
+            e = np.exp(p[1] * t)
+            return np.stack([e, p[0] * t * e, np.cos(p[3] * t), -p[2] * t * np.sin(p[3] * t)], 1)
+        ref = least_squares(fun_b, X0[b], jac_b, bounds=bounds, method=method, scaling=scaling)
+        r = res[b]
+        assert (r.nfev, r.njev, r.status) == (ref.nfev, ref.njev, ref.status), b
+        np.testing.assert_allclose(r.x, ref.x, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(r.obj_value, ref.obj_value, rtol=1e-9)
+        np.testing.assert_allclose(r.optimality, ref.optimality, rtol=1e-6, atol=1e-14)
+        np.testing.assert_array_equal(r.active_mask, ref.active_mask)
+        assert r.success == ref.success and r.message == ref.message
+
+
+def test_device_outer_driver_max_nfev_and_frozen_problems():
+    """max_nfev stops a problem with status 0 exactly like the host driver, and problems that
+    finish early are frozen while the rest of the batch continues."""
+    from bounded_lsq import least_squares_batch
+    B = 6
+    fun, jac, Y, t = _expfit_batch(B)
+    X0 = np.tile(np.array([1.0, -0.1, 1.0, 1.0]), (B, 1))
+    X0[:, 0] += 0.3 * np.arange(B)
+    for mx in (3, 7):
+        host = least_squares_batch(fun, X0, jac, method='trf', max_nfev=mx)
+        dev = least_squares_batch(fun, X0, jac, method='trf', max_nfev=mx, driver='device')
+        for h, d in zip(host, dev):
+            assert (h.nfev, h.njev, h.status) == (d.nfev, d.njev, d.status)
+            np.testing.assert_allclose(d.x, h.x, rtol=1e-9, atol=1e-12)
+
+
 def test_least_squares_batch_validation():
     from bounded_lsq import least_squares_batch
     with pytest.raises(ValueError):
