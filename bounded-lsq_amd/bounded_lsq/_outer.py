@@ -112,10 +112,14 @@ class OuterDriver:
                 acc = self._down(self.d_accepted, (B,), np.int32)
                 X = self._down(self.d_x, (B, n))
                 Jn = np.ascontiguousarray(jac(X), dtype=np.float64)
-                for b in np.nonzero(acc)[0]:                     # only fresh Jacobians travel
-                    dst = vp(self.d_J.value + int(b) * itemJ)
-                    self.ctx.check(self.ctx.lib.blsq_memcpy_h2d(self.ctx.h, dst, ptr(Jn[b]), itemJ),
-                                   "h2d(J)")
+                idx = np.nonzero(acc)[0]
+                # only fresh Jacobians travel: contiguous runs of accepted problems, one copy each
+                runs = np.split(idx, np.nonzero(np.diff(idx) > 1)[0] + 1)
+                for r in runs:
+                    b0, nb = int(r[0]), len(r)
+                    dst = vp(self.d_J.value + b0 * itemJ)
+                    self.ctx.check(self.ctx.lib.blsq_memcpy_h2d(self.ctx.h, dst, ptr(Jn[b0:b0 + nb]),
+                                                                nb * itemJ), "h2d(J)")
         return self.fetch()
 
     def run_device(self, fun_dev, jac_dev, sync=None):

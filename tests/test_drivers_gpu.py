@@ -293,3 +293,21 @@ def test_least_squares_batch_validation():
         least_squares_batch(lambda X: X, np.zeros((2, 2)), lambda X: X, bounds=(1.0, 0.0))
     with pytest.raises(ValueError):
         least_squares_batch(lambda X: X, np.full((2, 2), 5.0), lambda X: X, bounds=(0.0, 1.0))
+
+
+def test_device_outer_driver_torch_callbacks_subprocess():
+    """Fully device-resident loop: user callbacks written with torch fill the driver's device
+    buffers in place (zero copy).  Runs tools/bench_outer.py on a small batch in a child process
+    (torch must initialise the HIP runtime before libblsq_hip.so is loaded)
+    and checks that the TRF iteration counts equal the host driver's for every problem."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_outer.py"),
+                          "48", "96", "12"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    trf_i = [i for i, l in enumerate(lines) if l.startswith("trf: device driver, torch callbacks")]
+    assert trf_i, out.stdout
+    assert "differ host vs device driver: 0 of 48" in out.stdout
+    assert "nfev differs from the host driver for 0 problems" in lines[trf_i[0] + 1]
+    assert any(l.startswith("dogbox: device driver, torch callbacks") for l in lines)
