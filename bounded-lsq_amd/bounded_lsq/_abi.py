@@ -67,6 +67,8 @@ SIGNATURES = {
     "blsq_outer_propose": (C.c_int, [vp, c_int32_p]),
     "blsq_outer_judge": (C.c_int, [vp, c_int32_p]),
     "blsq_outer_fetch": (C.c_int, [vp] + [vp] * 8),
+    "blsq_fd_points_dev": (C.c_int, [vp, C.c_int, C.c_int, C.c_int] + [vp] * 7),
+    "blsq_fd_assemble_dev": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int] + [vp] * 7),
 }
 
 _lib = None

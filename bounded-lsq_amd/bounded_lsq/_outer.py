@@ -122,21 +122,47 @@ class OuterDriver:
                                                                 nb * itemJ), "h2d(J)")
         return self.fetch()
 
-    def run_device(self, fun_dev, jac_dev, sync=None):
+    def run_device(self, fun_dev, jac_dev, sync=None, rel_step=None, bounds_dev=None):
         """Lock-step loop with device callbacks:
-        ``fun_dev(x_ptr, f_ptr)`` fills f [B][m] from x [B][n];
+        ``fun_dev(x_ptr, f_ptr, reps)`` fills f [B * reps][m] from x [B * reps][n]; the points of
+        problem b are rows b * reps .. b * reps + reps - 1 (reps == 1 except for the
+        finite-difference evaluations);
         ``jac_dev(x_ptr, J_ptr, accepted_ptr)`` fills J[b] for every b (accepted_ptr None: all
-        problems) or at least those with accepted[b] != 0.  `sync()` (optional) must wait for the
-        callbacks' own stream; the library's stream is idle whenever a callback runs."""
+        problems) or at least those with accepted[b] != 0 — or one of the strings '2-point' /
+        '3-point': the Jacobian is then estimated on the device from `fun_dev` (``FdJacobian``:
+        scipy's approx_derivative restated for a batch; `rel_step` = diff_step, `bounds_dev` =
+        (lb_ptr, ub_ptr) device arrays [B][n], needed for the bounds-aware steps).
+        `sync()` (optional) must wait for the callbacks' own stream; the library's stream is idle
+        whenever a callback runs."""
         sync = sync or (lambda: None)
-        fun_dev(self.d_x, self.d_f)
-        jac_dev(self.d_x, self.d_J, None)
-        sync()
-        self.begin()
-        while self.propose() > 0:
-            fun_dev(self.d_x_trial, self.d_f_trial)
-            sync()
-            if self.judge() > 0:
-                jac_dev(self.d_x, self.d_J, self.d_accepted)
+        fd = None
+        if isinstance(jac_dev, str):
+            from ._fd import FdJacobian
+            if bounds_dev is None:
+                raise ValueError("finite differences need `bounds_dev` = (lb_ptr, ub_ptr).")
+            fd = FdJacobian(self.ctx, self.B, self.m, self.n, jac_dev, rel_step)
+            d_lb, d_ub = bounds_dev
+
+            def jac_dev(x_ptr, J_ptr, mask_ptr, fd=fd):           # noqa: F811
+                Xp = fd.points(x_ptr, d_lb, d_ub)
+                self.ctx.sync()
+                fun_dev(Xp, fd.d_F, fd.P)
                 sync()
-        return self.fetch()
+                fd.assemble(x_ptr, self.d_f, J_ptr, mask_ptr)
+                self.ctx.sync()
+        try:
+            fun_dev(self.d_x, self.d_f, 1)
+            sync()
+            jac_dev(self.d_x, self.d_J, None)
+            sync()
+            self.begin()
+            while self.propose() > 0:
+                fun_dev(self.d_x_trial, self.d_f_trial, 1)
+                sync()
+                if self.judge() > 0:
+                    jac_dev(self.d_x, self.d_J, self.d_accepted)
+                    sync()
+            return self.fetch()
+        finally:
+            if fd is not None:
+                fd.close()

@@ -1326,3 +1326,38 @@ extern "C" int blsq_outer_fetch(blsq_outer* o, double* x, double* f, double* obj
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
 }
+
+// ============================================= finite-difference Jacobians ===
+extern "C" int blsq_fd_points_dev(blsq_ctx* ctx, int B, int n, int method, const double* dx,
+                                  const double* dlb, const double* dub, const double* drel_step,
+                                  double* dX, double* dh, uint8_t* done_sided) {
+  if (!ctx) return -1;
+  if (B <= 0) return ctx->bad(2, "B must be positive");
+  if (n <= 0) return ctx->bad(3, "n must be positive");
+  if (method != 2 && method != 3) return ctx->bad(4, "method must be 2 or 3");
+  if (!dx || !dlb || !dub) return ctx->bad(5, "x/lb/ub is NULL");
+  if (!dX || !dh || !done_sided) return ctx->bad(9, "output is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipError_t e = launch_fd_points(B, n, method, dx, dlb, dub, drel_step, dX, dh, done_sided,
+                                  ctx->stream);
+  if (e != hipSuccess) return ctx->fail(e, "launch_fd_points");
+  return 0;
+}
+
+extern "C" int blsq_fd_assemble_dev(blsq_ctx* ctx, int B, int m, int n, int method,
+                                    const double* dx, const double* dh,
+                                    const uint8_t* done_sided, const double* df0,
+                                    const double* dF, double* dJ, const int32_t* dmask) {
+  if (!ctx) return -1;
+  if (B <= 0 || B > 65535) return ctx->bad(2, "B must be in 1..65535");
+  if (m <= 0) return ctx->bad(3, "m must be positive");
+  if (n <= 0) return ctx->bad(4, "n must be positive");
+  if (method != 2 && method != 3) return ctx->bad(5, "method must be 2 or 3");
+  if (!dx || !dh || !done_sided || !df0 || !dF) return ctx->bad(6, "input is NULL");
+  if (!dJ) return ctx->bad(11, "J is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipError_t e = launch_fd_assemble(B, m, n, method, dx, dh, done_sided, df0, dF, dJ, dmask,
+                                    ctx->stream);
+  if (e != hipSuccess) return ctx->fail(e, "launch_fd_assemble");
+  return 0;
+}

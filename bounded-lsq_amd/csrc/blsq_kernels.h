@@ -174,4 +174,14 @@ hipError_t launch_outer_top(const OuterState& o, hipStream_t s);
 hipError_t launch_outer_trial(const OuterState& o, hipStream_t s);
 hipError_t launch_outer_judge(const OuterState& o, hipStream_t s);
 
+
+// ------------------------------------- finite-difference Jacobians (8f-2) ----
+// method: 2 = '2-point', 3 = '3-point'.  X [B][P][n] with P = n (2) or 2n (3); F [B][P][m].
+hipError_t launch_fd_points(int B, int n, int method, const double* x, const double* lb,
+                            const double* ub, const double* rel_step, double* X, double* h,
+                            unsigned char* one_sided, hipStream_t s);
+hipError_t launch_fd_assemble(int B, int m, int n, int method, const double* x, const double* h,
+                              const unsigned char* one_sided, const double* f0, const double* F,
+                              double* J, const int* mask, hipStream_t s);
+
 }  // namespace blsq

@@ -23,7 +23,6 @@
 namespace blsq {
 
 static constexpr int OUT_NT = 256;
-static constexpr double O_EPS = 2.220446049250313e-16;
 static constexpr double O_SQRT_EPS = 1.4901161193847656e-08;
 
 enum { ST_NONE = -1 };

@@ -205,6 +205,25 @@ int blsq_outer_judge(blsq_outer* o, int32_t* n_accepted);
 int blsq_outer_fetch(blsq_outer* o, double* x, double* f, double* obj, double* optimality,
                      int64_t* on_bound, int32_t* nfev, int32_t* njev, int32_t* status);
 
+/* ---- finite-difference Jacobians for the batched drivers, on the device ----
+ * jac='2-point' / '3-point' of the reference is the THIRD-PARTY call
+ * scipy.optimize._numdiff.approx_derivative(fun, x, rel_step=diff_step, method=jac, f0=f,
+ * bounds=bounds) (least_squares.py:357-365; restated against scipy 1.15.3: _compute_absolute_step,
+ * _adjust_scheme_to_bounds, _dense_difference).  For B problems at once:
+ *   blsq_fd_points_dev    steps h [B][n], one-sided flags [B][n] and the perturbed points
+ *                         X [B][P][n] (P = n for method 2, 2n for method 3) which the caller's
+ *                         `fun` evaluates in one batched call into F [B][P][m];
+ *   blsq_fd_assemble_dev  J [B][m][n] from f0 [B][m] and F (problems with mask[b] == 0 are left
+ *                         untouched when mask != NULL).
+ * All pointers are device pointers; rel_step is NULL (scipy's default step) or [n].
+ * method: 2 = '2-point', 3 = '3-point'. */
+int blsq_fd_points_dev(blsq_ctx* ctx, int B, int n, int method, const double* dx,
+                       const double* dlb, const double* dub, const double* drel_step, double* dX,
+                       double* dh, uint8_t* done_sided);
+int blsq_fd_assemble_dev(blsq_ctx* ctx, int B, int m, int n, int method, const double* dx,
+                         const double* dh, const uint8_t* done_sided, const double* df0,
+                         const double* dF, double* dJ, const int32_t* dmask);
+
 #ifdef __cplusplus
 }
 #endif

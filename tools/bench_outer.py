@@ -65,9 +65,9 @@ for method in ("trf", "dogbox"):
 
     At = torch.as_tensor(A, device="cuda"); Yt = torch.as_tensor(Y, device="cuda")
 
-    def fun_dev(xp, fp):
-        x = wrap(xp, (B, n)); f = wrap(fp, (B, m))
-        torch.baddbmm(-Yt.unsqueeze(2), At, torch.tanh(x).unsqueeze(2), out=f.unsqueeze(2))
+    def fun_dev(xp, fp, reps):                   # reps points per problem (FD evaluations)
+        x = wrap(xp, (B, reps, n)); f = wrap(fp, (B, reps, m))
+        torch.baddbmm(-Yt.unsqueeze(1).expand(B, reps, m), torch.tanh(x), At.transpose(1, 2), out=f)
 
     def jac_dev(xp, Jp, mask):
         x = wrap(xp, (B, n)); J = wrap(Jp, (B, m, n))
@@ -83,3 +83,13 @@ for method in ("trf", "dogbox"):
     print("   nfev differs from the host driver for %d problems" % int(
         (R["nfev"] != np.array([r.nfev for r in r_host])).sum()))
     print("   max |x_dev - x_host| = %.2e" % np.abs(R["x"] - np.array([r.x for r in r_host])).max())
+    lbt = torch.as_tensor(np.broadcast_to(lb, (B, n)).copy(), device="cuda")
+    ubt = torch.as_tensor(np.broadcast_to(ub, (B, n)).copy(), device="cuda")
+    import ctypes
+    with OuterDriver(method, B, m, n, ctx=ctx) as drv:
+        t0 = time.perf_counter()
+        drv.start(X0, xs, lb, ub, np.ones(n), False, 1.49e-8, 1.49e-8, 1.49e-8, 100 * n)
+        R2 = drv.run_device(fun_dev, '2-point', sync=torch.cuda.synchronize,
+                            bounds_dev=(ctypes.c_void_p(lbt.data_ptr()), ctypes.c_void_p(ubt.data_ptr())))
+        report(method + ": device driver, torch fun, FD jac", R2, time.perf_counter() - t0)
+    print("   max |x_fd - x_analytic| = %.2e" % np.abs(R2["x"] - R["x"]).max())
