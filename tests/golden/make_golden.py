@@ -17,6 +17,9 @@ What is captured
                  dogbox.py:170-220 rather than a re-composition of them)
   e2e.json       end-to-end records (nfev, njev, status, x, ...) of the public
                  drivers on bounded Rosenbrock + a few small fitting problems
+  suite.json     the same for the 12-problem suite of tests/_suite.py (unbounded and
+                 bounded variants, both methods, numeric and 'jac' scaling, and the public
+                 front end with jac='2-point');  `python make_golden.py suite` rebuilds it alone
 """
 import json
 import os
@@ -502,11 +505,79 @@ def make_e2e():
                   indent=0)
 
 
+def make_suite():
+    """End-to-end records of the reference's public drivers / front end on tests/_suite.py."""
+    from _suite import SUITE
+    inf = np.inf
+    tol = float(np.finfo(float).eps ** 0.5)
+    recs = []
+    for prob in SUITE:
+        for bi, (lb, ub) in enumerate(prob["boxes"]):
+            lb = np.array(lb, float); ub = np.array(ub, float)
+            for method in ("trf", "dogbox"):
+                for scaling in (1.0, "jac"):
+                    drv = ref.trf if method == "trf" else ref.dogbox
+
+                    def fw(x, prob=prob):
+                        return np.atleast_1d(prob["fun"](x))
+
+                    def jw(x, f, prob=prob):
+                        return np.atleast_2d(prob["jac"](x))
+                    r = drv(fw, jw, prob["x0"].copy(), lb, ub, tol, tol, tol, None,
+                            shim(scaling, prob["x0"].size))
+                    # the reference's own answers when the start point moves by ONE ulp in one
+                    # coordinate: records whose iteration counts change there are decided by
+                    # rounding noise, and the test compares them through properties only
+                    neigh = []
+                    for j, direction in ((0, inf), (0, -inf), (-1, inf), (-1, -inf)):
+                        xp = prob["x0"].copy()
+                        xp[j] = np.nextafter(xp[j], direction)
+                        if np.any(xp < lb) or np.any(xp > ub):
+                            continue
+                        rn = drv(fw, jw, xp, lb, ub, tol, tol, tol, None, shim(scaling, xp.size))
+                        neigh.append(dict(nfev=int(rn.nfev), njev=int(rn.njev),
+                                          status=int(rn.status),
+                                          obj_value=float(rn.obj_value).hex()))
+                    stable = all((q["nfev"], q["njev"], q["status"]) ==
+                                 (int(r.nfev), int(r.njev), int(r.status)) for q in neigh)
+                    recs.append(dict(
+                        problem=prob["name"], box=bi, method=method, jac="analytic",
+                        scaling=scaling, nfev=int(r.nfev), njev=int(r.njev), status=int(r.status),
+                        x=[float(v).hex() for v in r.x], obj_value=float(r.obj_value).hex(),
+                        optimality=float(r.optimality).hex(),
+                        active_mask=[int(v) for v in r.active_mask],
+                        stable=bool(stable), neighbours=neigh))
+                    print("suite", prob["name"], bi, method, scaling, "nfev", r.nfev, "status",
+                          r.status, "" if stable else "UNSTABLE under 1-ulp start perturbations")
+            # the public front end with a finite-difference Jacobian (least_squares.py:357-365)
+            for method in ("trf", "dogbox"):
+                try:
+                    r = ref.least_squares(prob["fun"], prob["x0"].copy(), jac="2-point",
+                                          bounds=(lb, ub), method=method)
+                except Exception as exc:                      # noqa: BLE001
+                    print("suite 2-point", prob["name"], bi, method, "skipped:", repr(exc)[:80])
+                    continue
+                recs.append(dict(
+                    problem=prob["name"], box=bi, method=method, jac="2-point", scaling=1.0,
+                    nfev=int(r.nfev), njev=int(r.njev), status=int(r.status),
+                    x=[float(v).hex() for v in r.x], obj_value=float(r.obj_value).hex(),
+                    optimality=float(r.optimality).hex(),
+                    active_mask=[int(v) for v in r.active_mask]))
+                print("suite 2-point", prob["name"], bi, method, "nfev", r.nfev, "status", r.status)
+    with open(os.path.join(HERE, "suite.json"), "w") as fh:
+        json.dump(dict(tol=tol.hex(), records=recs), fh, indent=0)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "suite":
+        make_suite()
+        print("suite fixture written to", HERE)
+        sys.exit(0)
     with open(os.path.join(HERE, "helpers.json"), "w") as fh:
         json.dump(helpers(), fh, indent=0)
     make_trf()
     make_dog()
     make_first_iter()
     make_e2e()
+    make_suite()
     print("golden fixtures written to", HERE)
