@@ -34,6 +34,7 @@ struct QrArgs {
   long stride_vec;
   double* dbg;            // diagnostic stamps (nullptr in the product)
   int stack_rows;         // >0: source is a stack of upper-triangular blocks of this many rows
+  int cqr;                // 1: Cholesky-QR + Householder-reconstruction panels (set by launch_qr)
 };
 // The kernel stages at most QR_MAX_TILES 16-row tiles per workgroup: all RP/16 tiles of a
 // dense source, G * ceil((N-1)/16) of a stack of G triangular blocks (qr_panel.hip).

@@ -32,6 +32,7 @@
 // (TSQR tree), factors the Coleman-Li augmented system [R D; E], the Newton systems
 // [R_aug; sqrt(alpha) I] and the dogbox free-column block R[:, free].
 #include <algorithm>
+#include <cstdlib>
 
 #include "blsq_device.h"
 #include "blsq_kernels.h"
@@ -258,6 +259,209 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
     return W2;
   };
 
+  // ---- Cholesky-QR + Householder reconstruction of one panel --------------------------------
+  // The column-by-column Householder loop below is a latency chain (16 column steps, each a
+  // wave butterfly + an LDS exchange + a barrier + a sqrt/div chain) during which the MFMA pipe
+  // idles.  When the panel is well conditioned the same factorisation is obtained from ONE Gram
+  // matrix:  G = A^T A (MFMA, straight from the panel registers),  column-scaled Cholesky
+  // G = R^T R (16x16, one wave),  Q_top = A_top R^-1,  and the Householder representation of
+  // Q = A R^-1 is RECONSTRUCTED (Ballard, Demmel, Grigori, Jacquelin, Nguyen, Solomonik 2014):
+  // LU without pivoting of  Q - [S; 0],  S_jj = -sgn(pivot)  (all pivots >= 1 in magnitude) gives
+  //   Y_1 (unit lower), U;   Y_2 = Q_2 U^-1 = A_2 (R^-1 U^-1);   T = -U S Y_1^-T;   R_hh = S R,
+  // so that  (I - Y T Y^T)^T A = [R_hh; 0].  Only Y_2 = A_2 M needs the tall data again (one MFMA
+  // pass); everything 16x16 runs on wave 0, lane j (mod 16) owning column j in registers with
+  // v_readlane broadcasts.  The Cholesky pivots of the unit-diagonal Gram bound the conditioning;
+  // if the smallest one is below CQR_PMIN (or a column is zero / not finite) nothing has been
+  // modified and the exact Householder column loop runs instead.  Returns true on success with:
+  // P = [R_hh upper | Y_1 strictly lower] in the pivot tile and Y_2 below it, Gs = T_k (also in
+  // the global T scratch) — exactly what the column loop + T recurrence leave behind.
+  constexpr double CQR_PMIN = 0.05;
+  auto panel_cqr = [&](v4d* pa, int k, int hik) -> bool {
+    const int base = k * TILE;
+    int lcq = lc, lrq = lr, laneq = lane;
+    asm volatile("" : "+v"(lcq), "+v"(lrq), "+v"(laneq));   // per-call address arithmetic (no long-lived registers)
+    const int j = lcq;                                   // column owned by this laneq (wave 0)
+    double* Mbuf = Wred + 7 * 256;                       // M = R^-1 U^-1 for every wave
+    double* flag = xch;                                  // [0]: 1.0 success
+    // (a) Gram of the live rows, straight from the registers
+    v4d gacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+      const int t = w + QR_NW * i;
+      if (t >= k && t < hik) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) gacc = mfma_f64(pa[i][s], pa[i][s], gacc);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) Wred[w * 256 + g * 64 + laneq] = gacc[g];
+    lds_barrier();
+    if (w == 0) {
+      v4d G = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ww = 0; ww < QR_NW; ++ww) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) G[g] += Wred[ww * 256 + g * 64 + laneq];
+      }
+      double* S0 = Wred;                                 // 16x16 scratch matrices, row-major
+      double* S1 = Wred + 256;
+      double* S2 = Wred + 512;
+      double* S3 = Wred + 768;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) S0[(lrq + 4 * g) * 16 + lcq] = G[g];
+      double col[TILE];
+#pragma unroll
+      for (int i = 0; i < TILE; ++i) col[i] = S0[i * 16 + j];
+      const double gjj = S0[j * 17];
+      bool bad = !(gjj > 0.0) || !is_finite(gjj);
+      double dj = __builtin_amdgcn_rsq(bad ? 1.0 : gjj);
+      dj = dj * fma(-0.5 * gjj * dj, dj, 1.5);
+      dj = dj * fma(-0.5 * gjj * dj, dj, 1.5);
+#pragma unroll
+      for (int i = 0; i < TILE; ++i) col[i] *= read_lane(dj, i) * dj;     // unit-diagonal Gram
+      // Cholesky (right-looking): afterwards col[i] = R'[i][j] for i <= j
+      double rdv = 0.0;                                  // laneq k: 1 / R'[k][k]
+      double pmin = 1.0;
+#pragma unroll
+      for (int kk = 0; kk < TILE; ++kk) {
+        const double d = read_lane(col[kk], kk);
+        if (!(d >= pmin)) pmin = d;                      // also catches NaN
+        const double ds = (d > 1e-300) ? d : 1.0;
+        double ri = __builtin_amdgcn_rsq(ds);
+        ri = ri * fma(-0.5 * ds * ri, ri, 1.5);
+        ri = ri * fma(-0.5 * ds * ri, ri, 1.5);
+        rdv = (j == kk) ? ri : rdv;
+        const double rkj = col[kk] * ri;
+        col[kk] = (j >= kk) ? rkj : 0.0;
+#pragma unroll
+        for (int i = kk + 1; i < TILE; ++i) col[i] = fma(-read_lane(rkj, i), rkj, col[i]);
+      }
+      const bool ok = !__any(bad) && (pmin >= CQR_PMIN);
+      if (ok) {                                          // wave-uniform
+        // R'^-1, column j (back substitution); R^-1 = D R'^-1
+        double x[TILE];
+#pragma unroll
+        for (int i = TILE - 1; i >= 0; --i) {
+          double acc = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+          for (int l = i + 1; l < TILE; ++l) acc = fma(-read_lane(col[i], l), x[l], acc);
+          x[i] = acc * read_lane(rdv, i);
+        }
+#pragma unroll
+        for (int i = 0; i < TILE; ++i) S1[i * 16 + j] = read_lane(dj, i) * x[i];   // S1 = R^-1
+        // Q_top = A_top R^-1 (MFMA), back to column ownership through S2
+        v4d qt = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          qt = mfma_f64(P[(4 * s + lrq) * LDP + base + lcq], S1[(4 * s + lrq) * 16 + lcq], qt);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) S2[(lrq + 4 * g) * 16 + lcq] = qt[g];
+        // R_hh = S R' D^-1 goes to the upper part of the pivot tile once S is known: keep R'/d_j
+        const double inv_dj = gjj * dj;                  // sqrt(g_jj) = 1 / d_j
+        double rcol[TILE];
+#pragma unroll
+        for (int i = 0; i < TILE; ++i) rcol[i] = col[i] * inv_dj;
+        double qc[TILE];
+#pragma unroll
+        for (int i = 0; i < TILE; ++i) qc[i] = S2[i * 16 + j];
+        // LU of Q_top - S without pivoting, S_k = -sgn(pivot)
+        double sgv = 1.0, pnv = 0.0;                     // laneq k: S_k and 1 / U[k][k]
+#pragma unroll
+        for (int kk = 0; kk < TILE; ++kk) {
+          double piv = read_lane(qc[kk], kk);
+          const double sk = (piv >= 0.0) ? -1.0 : 1.0;
+          piv -= sk;                                     // |piv| >= 1
+          double pi = __builtin_amdgcn_rcp(piv);
+          pi = pi * fma(-piv, pi, 2.0);
+          pi = pi * fma(-piv, pi, 2.0);
+          sgv = (j == kk) ? sk : sgv;
+          pnv = (j == kk) ? pi : pnv;
+#pragma unroll
+          for (int i = kk + 1; i < TILE; ++i) {
+            const double lik = read_lane(qc[i], kk) * pi;
+            qc[i] = (j == kk) ? lik : ((j > kk) ? fma(-lik, qc[kk], qc[i]) : qc[i]);
+          }
+          if (j == kk) qc[kk] = piv;
+        }
+        // pivot tile of the panel: R_hh on and above the diagonal, Y_1 below it
+        if (laneq < TILE) {
+#pragma unroll
+          for (int i = 0; i < TILE; ++i)
+            P[j * LDP + base + i] = (i <= j) ? read_lane(sgv, i) * rcol[i] : qc[i];
+        }
+        // U^-1 (column j) -> S2;  (U S) -> S0
+        {
+          double u[TILE];
+#pragma unroll
+          for (int i = TILE - 1; i >= 0; --i) {
+            double acc = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+            for (int l = i + 1; l < TILE; ++l) acc = fma(-read_lane(qc[i], l), u[l], acc);
+            u[i] = acc * read_lane(pnv, i);
+          }
+          const double sj = sgv;                         // S_j for this laneq's column
+#pragma unroll
+          for (int i = 0; i < TILE; ++i) {
+            S2[i * 16 + j] = u[i];
+            S0[i * 16 + j] = (i <= j) ? qc[i] * sj : 0.0;
+          }
+        }
+        // Z = Y_1^-T: column j of L^-1 (unit lower, forward substitution) is row j of Z -> S3
+        {
+          double z[TILE];
+#pragma unroll
+          for (int i = 0; i < TILE; ++i) {
+            double acc = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+            for (int l = 0; l < i; ++l) acc = fma(-read_lane(qc[i], l), z[l], acc);
+            z[i] = acc;
+          }
+#pragma unroll
+          for (int i = 0; i < TILE; ++i) S3[j * 16 + i] = z[i];
+        }
+        // T = -(U S) Z  and  M = R^-1 U^-1  (16x16x16 products on the MFMA pipe)
+        v4d tacc = {0.0, 0.0, 0.0, 0.0}, macc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          tacc = mfma_f64(S0[lcq * 16 + 4 * s + lrq], S3[(4 * s + lrq) * 16 + lcq], tacc);
+          macc = mfma_f64(S1[lcq * 16 + 4 * s + lrq], S2[(4 * s + lrq) * 16 + lcq], macc);
+        }
+        double* Tk = T + k * 256;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int e = (lrq + 4 * g) * 16 + lcq;
+          Gs[e] = -tacc[g];
+          Tk[e] = -tacc[g];
+          Mbuf[e] = macc[g];
+        }
+      }
+      if (laneq == 0) flag[0] = ok ? 1.0 : 0.0;
+    }
+    lds_barrier();
+    const bool ok = flag[0] != 0.0;
+    if (ok) {
+      // Y_2 = A_2 M for the tiles below the pivot tile (A operand read back from the LDS panel)
+      double mb[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mb[s] = Mbuf[(4 * s + lrq) * 16 + lcq];
+#pragma unroll
+      for (int i = 0; i < MAXT; ++i) {
+        const int t = w + QR_NW * i;
+        if (t > k && t < hik) {
+          const double* pv = P + lrq * LDP + t * TILE + lcq;
+          v4d y = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s = 0; s < 4; ++s) y = mfma_f64(pv[4 * s * LDP], mb[s], y);
+          double* pt = P + lcq * LDP + t * TILE + lrq;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) pt[4 * g] = y[g];
+        }
+      }
+    }
+    lds_barrier();
+    return ok;
+  };
+
   STAMP_DECL
   for (int k = 0; k < NP; ++k) {
     // live tiles of this panel: [k, hik); rows past them are never read or written
@@ -408,12 +612,16 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
     int tidk = tid;
     if (PAIR) asm volatile("" : "+v"(tidk));  // LDS addresses are recomputed per panel, not kept live
     int rowi[NR], rci[NR];
-    double pr[NR][TILE];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       rowi[r] = tidk + r * QR_NT;
       rci[r] = rowi[r] < rows_k ? rowi[r] : rows_k - 1;
     }
+    // ---- 3C. fast path: Cholesky-QR + Householder reconstruction ----------
+    bool cqr_ok = false;
+    if (q.cqr && base + TILE <= nc) cqr_ok = panel_cqr(pc, k, hik);
+    if (!cqr_ok) {
+    double pr[NR][TILE];
 #pragma unroll
     for (int c = 0; c < TILE; ++c) {
 #pragma unroll
@@ -521,6 +729,7 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
         if (rowi[r] < rows_k) P[c * LDP + rowi[r]] = pr[r][c];
     }
     __syncthreads();
+    }   // !cqr_ok
 
     STAMP(2)
     // ---- 4. emit the R block column (rows 0..NPAD-1 of these 16 columns) --
@@ -547,7 +756,7 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
     __syncthreads();
 
     // ---- 6. T_k from G = V_k^T V_k (MFMA) + 16-step row recurrence --------
-    {
+    if (!cqr_ok) {
       int t0 = k + ((w - k) % QR_NW + QR_NW) % QR_NW;
       v4d acc = {0.0, 0.0, 0.0, 0.0};
       for (int t = t0; t < hik; t += QR_NW) {
@@ -701,6 +910,11 @@ int qr_staged_tiles(int RP, int stack_rows, int N) {
 hipError_t launch_qr(const QrArgs& q_in, int nleaf, int B, hipStream_t st) {
   QrArgs q = q_in;
   q.dbg = g_qr_dbg;
+  {
+    static int cqr = -1;
+    if (cqr < 0) { const char* e = getenv("BLSQ_QR_CQR"); cqr = (e && e[0] == '0') ? 0 : 1; }
+    q.cqr = cqr;
+  }
   if (g_qr_dbg) g_qr_dbg += (size_t)nleaf * B * 8;   // successive launches append
   // a stack the interleaved staging cannot express is factored as a dense source
   const bool st_ok = qr_stack_ok(q.RP, q.stack_rows);
