@@ -1361,3 +1361,14 @@ extern "C" int blsq_fd_assemble_dev(blsq_ctx* ctx, int B, int m, int n, int meth
   if (e != hipSuccess) return ctx->fail(e, "launch_fd_assemble");
   return 0;
 }
+
+extern "C" int blsq_debug_cqr_stats(blsq_ctx* ctx, uint64_t out[2], int reset) {
+  if (!ctx) return -1;
+  if (!out) return ctx->bad(2, "out is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  unsigned long long v[2] = {0ULL, 0ULL};
+  hipError_t e = qr_cqr_stats(v, reset, ctx->stream);
+  if (e != hipSuccess) return ctx->fail(e, "qr_cqr_stats");
+  out[0] = v[0]; out[1] = v[1];
+  return 0;
+}

@@ -45,6 +45,8 @@ inline bool qr_stack_ok(int RP, int stack_rows) {
 int qr_staged_tiles(int RP, int stack_rows, int N);
 hipError_t launch_qr(const QrArgs& q, int nleaf, int B, hipStream_t st);
 void set_qr_debug_buffer(double* p);
+// panels factored by the Cholesky-QR fast path [0] / the Householder column loop [1] so far
+hipError_t qr_cqr_stats(unsigned long long out[2], int reset, hipStream_t st);
 
 // ------------------------------------------------------------- Jacobi -----
 // One-sided Jacobi on the ROWS of the n x (n+1) array [R | c] (row stride ld):

@@ -51,6 +51,9 @@ namespace blsq {
 #define STAMP_OUT
 #endif
 
+// panels factored by the Cholesky-QR fast path / by the Householder column loop (diagnostics)
+__device__ unsigned long long g_cqr_stats[2];
+
 static constexpr int QR_NT = 512;
 static constexpr int QR_NW = QR_NT / WAVE;
 
@@ -435,7 +438,10 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
           Mbuf[e] = macc[g];
         }
       }
-      if (laneq == 0) flag[0] = ok ? 1.0 : 0.0;
+      if (laneq == 0) {
+        flag[0] = ok ? 1.0 : 0.0;
+        atomicAdd(&g_cqr_stats[ok ? 0 : 1], 1ULL);
+      }
     }
     lds_barrier();
     const bool ok = flag[0] != 0.0;
@@ -892,6 +898,18 @@ static hipError_t launch_qr_s(const QrArgs& q, int nleaf, int B, int slots, hipS
   if (slots <= 4) return launch_qr_t<4, ST>(q, nleaf, B, st);
   if (slots <= 6) return launch_qr_t<6, ST>(q, nleaf, B, st);
   return launch_qr_t<8, ST>(q, nleaf, B, st);
+}
+
+hipError_t qr_cqr_stats(unsigned long long out[2], int reset, hipStream_t st) {
+  hipError_t e = hipMemcpyFromSymbolAsync(out, HIP_SYMBOL(g_cqr_stats), 2 * sizeof(unsigned long long),
+                                          0, hipMemcpyDeviceToHost, st);
+  if (e != hipSuccess) return e;
+  e = hipStreamSynchronize(st);
+  if (e != hipSuccess || !reset) return e;
+  const unsigned long long z[2] = {0ULL, 0ULL};
+  e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_cqr_stats), z, sizeof(z), 0, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(st);
 }
 
 static double* g_qr_dbg = nullptr;

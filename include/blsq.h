@@ -163,6 +163,11 @@ int blsq_tsqr_combine_dev(blsq_trf_plan* plan, const double* dtri_stack /*nranks
                           const double* dx, const double* dlb, const double* dub,
                           double* dscale_io, int scale_mode);
 
+/* diagnostics: number of 16-column QR panels factored by the Cholesky-QR + Householder-
+ * reconstruction fast path (out[0]) and by the exact Householder column loop (out[1]: partial
+ * last panels and panels whose scaled Gram has a small pivot) since the last reset. */
+int blsq_debug_cqr_stats(blsq_ctx* ctx, uint64_t out[2], int reset);
+
 /* ---- batched outer trust-region drivers, device-resident ------------------
  * Replaces, for B problems of one shape advancing in lock-step, the Python loops around the
  * step path: trf.py:173-237 (initialisation), :238-261 (top of the outer loop: nfev / gtol
