@@ -265,26 +265,32 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
   // ---- Cholesky-QR + Householder reconstruction of one panel --------------------------------
   // The column-by-column Householder loop below is a latency chain (16 column steps, each a
   // wave butterfly + an LDS exchange + a barrier + a sqrt/div chain) during which the MFMA pipe
-  // idles.  When the panel is well conditioned the same factorisation is obtained from ONE Gram
-  // matrix:  G = A^T A (MFMA, straight from the panel registers),  column-scaled Cholesky
-  // G = R^T R (16x16, one wave),  Q_top = A_top R^-1,  and the Householder representation of
-  // Q = A R^-1 is RECONSTRUCTED (Ballard, Demmel, Grigori, Jacquelin, Nguyen, Solomonik 2014):
-  // LU without pivoting of  Q - [S; 0],  S_jj = -sgn(pivot)  (all pivots >= 1 in magnitude) gives
-  //   Y_1 (unit lower), U;   Y_2 = Q_2 U^-1 = A_2 (R^-1 U^-1);   T = -U S Y_1^-T;   R_hh = S R,
-  // so that  (I - Y T Y^T)^T A = [R_hh; 0].  Only Y_2 = A_2 M needs the tall data again (one MFMA
-  // pass); everything 16x16 runs on wave 0, lane j (mod 16) owning column j in registers with
-  // v_readlane broadcasts.  The Cholesky pivots of the unit-diagonal Gram bound the conditioning;
-  // if the smallest one is below CQR_PMIN (or a column is zero / not finite) nothing has been
-  // modified and the exact Householder column loop runs instead.  Returns true on success with:
-  // P = [R_hh upper | Y_1 strictly lower] in the pivot tile and Y_2 below it, Gs = T_k (also in
-  // the global T scratch) — exactly what the column loop + T recurrence leave behind.
+  // idles.  When the panel A (live rows x 16) is well conditioned the same factorisation comes
+  // from ONE Gram matrix:  G = A^T A (MFMA, straight from the panel registers),  column-scaled
+  // Cholesky G = R^T R (16x16),  and the Householder representation of Q = A R^-1 is
+  // RECONSTRUCTED (Ballard, Demmel, Grigori, Jacquelin, Nguyen, Solomonik 2014): LU without
+  // pivoting of  Q - [S; 0]  with  S_jj = -sgn(pivot)  gives  Y_1 (unit lower), U,
+  // Y_2 = Q_2 U^-1,  T = -U S Y_1^-T,  R_hh = S R,  so that (I - Y T Y^T)^T A = [R_hh; 0].
+  // Multiplying through by R, the same L comes from the LU of  A_top - S R  (pivot j is the Q-form
+  // pivot times R_jj > 0, so the signs agree), whose upper factor is U' = U R; then
+  //     Y_2 = A_2 U'^-1,        T = -U' W^-1  with  W = Y_1^T S R  (upper triangular),
+  // and neither Q nor R^-1 is ever formed.  Only Y_2 = A_2 M needs the tall data again (one MFMA
+  // pass by all waves).  The 16x16 work runs on TWO waves that repeat the (deterministic) Cholesky
+  // and LU and then split: wave 0 inverts U' (-> M), wave 1 forms W, inverts it and multiplies
+  // (-> T); lane j (mod 16) owns column j in registers, broadcasts are v_readlane, the 16x16x16
+  // products go to the MFMA pipe through small LDS scratch tiles.  The Cholesky pivots of the
+  // unit-diagonal Gram bound the conditioning: if the smallest one is below CQR_PMIN (or a column
+  // is zero / not finite) nothing has been modified and the exact Householder column loop runs
+  // instead.  Returns true on success with P = [R_hh upper | Y_1 strictly lower] in the pivot tile
+  // and Y_2 below it, Gs = T_k (also in the global T scratch) — exactly what the column loop and
+  // the T recurrence leave behind.
   constexpr double CQR_PMIN = 0.05;
   auto panel_cqr = [&](v4d* pa, int k, int hik) -> bool {
     const int base = k * TILE;
     int lcq = lc, lrq = lr, laneq = lane;
     asm volatile("" : "+v"(lcq), "+v"(lrq), "+v"(laneq));   // per-call address arithmetic (no long-lived registers)
-    const int j = lcq;                                   // column owned by this laneq (wave 0)
-    double* Mbuf = Wred + 7 * 256;                       // M = R^-1 U^-1 for every wave
+    const int j = lcq;                                   // column owned by this lane (waves 0, 1)
+    double* Mbuf = Tst;                                  // M = U'^-1 for every wave (wave 0's scratch)
     double* flag = xch;                                  // [0]: 1.0 success
     // (a) Gram of the live rows, straight from the registers
     v4d gacc = {0.0, 0.0, 0.0, 0.0};
@@ -298,32 +304,34 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) Wred[w * 256 + g * 64 + laneq] = gacc[g];
+    double ac[TILE];                                     // column j of A_top (pivot tile), read
+    if (w < 2) {                                         // BEFORE the barrier: the tile is rewritten later
+#pragma unroll
+      for (int i = 0; i < TILE; ++i) ac[i] = P[j * LDP + base + i];
+    }
     lds_barrier();
-    if (w == 0) {
+    if (w < 2) {
+      double* SA = Tst + w * 256;                        // per-wave 16x16 scratch tiles (row-major)
+      double* SB = xch + 16;                             // wave 1 only
       v4d G = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int ww = 0; ww < QR_NW; ++ww) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) G[g] += Wred[ww * 256 + g * 64 + laneq];
       }
-      double* S0 = Wred;                                 // 16x16 scratch matrices, row-major
-      double* S1 = Wred + 256;
-      double* S2 = Wred + 512;
-      double* S3 = Wred + 768;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) S0[(lrq + 4 * g) * 16 + lcq] = G[g];
+      for (int g = 0; g < 4; ++g) SA[(lrq + 4 * g) * 16 + lcq] = G[g];
       double col[TILE];
 #pragma unroll
-      for (int i = 0; i < TILE; ++i) col[i] = S0[i * 16 + j];
-      const double gjj = S0[j * 17];
-      bool bad = !(gjj > 0.0) || !is_finite(gjj);
+      for (int i = 0; i < TILE; ++i) col[i] = SA[i * 16 + j];
+      const double gjj = SA[j * 17];
+      const bool bad = !(gjj > 0.0) || !is_finite(gjj);
       double dj = __builtin_amdgcn_rsq(bad ? 1.0 : gjj);
       dj = dj * fma(-0.5 * gjj * dj, dj, 1.5);
       dj = dj * fma(-0.5 * gjj * dj, dj, 1.5);
 #pragma unroll
       for (int i = 0; i < TILE; ++i) col[i] *= read_lane(dj, i) * dj;     // unit-diagonal Gram
-      // Cholesky (right-looking): afterwards col[i] = R'[i][j] for i <= j
-      double rdv = 0.0;                                  // laneq k: 1 / R'[k][k]
+      // Cholesky (right-looking): afterwards col[i] = R'[i][j] for i <= j, 0 below
       double pmin = 1.0;
 #pragma unroll
       for (int kk = 0; kk < TILE; ++kk) {
@@ -333,47 +341,24 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
         double ri = __builtin_amdgcn_rsq(ds);
         ri = ri * fma(-0.5 * ds * ri, ri, 1.5);
         ri = ri * fma(-0.5 * ds * ri, ri, 1.5);
-        rdv = (j == kk) ? ri : rdv;
         const double rkj = col[kk] * ri;
         col[kk] = (j >= kk) ? rkj : 0.0;
 #pragma unroll
         for (int i = kk + 1; i < TILE; ++i) col[i] = fma(-read_lane(rkj, i), rkj, col[i]);
       }
       const bool ok = !__any(bad) && (pmin >= CQR_PMIN);
-      if (ok) {                                          // wave-uniform
-        // R'^-1, column j (back substitution); R^-1 = D R'^-1
-        double x[TILE];
-#pragma unroll
-        for (int i = TILE - 1; i >= 0; --i) {
-          double acc = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-          for (int l = i + 1; l < TILE; ++l) acc = fma(-read_lane(col[i], l), x[l], acc);
-          x[i] = acc * read_lane(rdv, i);
-        }
-#pragma unroll
-        for (int i = 0; i < TILE; ++i) S1[i * 16 + j] = read_lane(dj, i) * x[i];   // S1 = R^-1
-        // Q_top = A_top R^-1 (MFMA), back to column ownership through S2
-        v4d qt = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-          qt = mfma_f64(P[(4 * s + lrq) * LDP + base + lcq], S1[(4 * s + lrq) * 16 + lcq], qt);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) S2[(lrq + 4 * g) * 16 + lcq] = qt[g];
-        // R_hh = S R' D^-1 goes to the upper part of the pivot tile once S is known: keep R'/d_j
+      if (ok) {                                          // wave-uniform, identical in both waves
         const double inv_dj = gjj * dj;                  // sqrt(g_jj) = 1 / d_j
-        double rcol[TILE];
 #pragma unroll
-        for (int i = 0; i < TILE; ++i) rcol[i] = col[i] * inv_dj;
-        double qc[TILE];
-#pragma unroll
-        for (int i = 0; i < TILE; ++i) qc[i] = S2[i * 16 + j];
-        // LU of Q_top - S without pivoting, S_k = -sgn(pivot)
-        double sgv = 1.0, pnv = 0.0;                     // laneq k: S_k and 1 / U[k][k]
+        for (int i = 0; i < TILE; ++i) col[i] *= inv_dj; // col[i] = R[i][j]   (R = R' D^-1)
+        // LU of A_top - S R without pivoting, S_k = -sgn(pivot): ac -> [U' upper | Y_1 lower]
+        double sgv = 1.0, pnv = 0.0;                     // lane k: S_k and 1 / U'[k][k]
 #pragma unroll
         for (int kk = 0; kk < TILE; ++kk) {
-          double piv = read_lane(qc[kk], kk);
+          double piv = read_lane(ac[kk], kk);
           const double sk = (piv >= 0.0) ? -1.0 : 1.0;
-          piv -= sk;                                     // |piv| >= 1
+          ac[kk] = fma(-sk, col[kk], ac[kk]);            // row k -= S_k R[k][:]
+          piv = fma(-sk, read_lane(col[kk], kk), piv);   // |piv| >= R[k][k] > 0
           double pi = __builtin_amdgcn_rcp(piv);
           pi = pi * fma(-piv, pi, 2.0);
           pi = pi * fma(-piv, pi, 2.0);
@@ -381,64 +366,78 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
           pnv = (j == kk) ? pi : pnv;
 #pragma unroll
           for (int i = kk + 1; i < TILE; ++i) {
-            const double lik = read_lane(qc[i], kk) * pi;
-            qc[i] = (j == kk) ? lik : ((j > kk) ? fma(-lik, qc[kk], qc[i]) : qc[i]);
+            const double lik = read_lane(ac[i], kk) * pi;
+            ac[i] = (j == kk) ? lik : ((j > kk) ? fma(-lik, ac[kk], ac[i]) : ac[i]);
           }
-          if (j == kk) qc[kk] = piv;
         }
-        // pivot tile of the panel: R_hh on and above the diagonal, Y_1 below it
-        if (laneq < TILE) {
-#pragma unroll
-          for (int i = 0; i < TILE; ++i)
-            P[j * LDP + base + i] = (i <= j) ? read_lane(sgv, i) * rcol[i] : qc[i];
-        }
-        // U^-1 (column j) -> S2;  (U S) -> S0
-        {
+        if (w == 0) {
+          // M = U'^-1, column j (back substitution)
           double u[TILE];
 #pragma unroll
           for (int i = TILE - 1; i >= 0; --i) {
             double acc = (i == j) ? 1.0 : 0.0;
 #pragma unroll
-            for (int l = i + 1; l < TILE; ++l) acc = fma(-read_lane(qc[i], l), u[l], acc);
+            for (int l = i + 1; l < TILE; ++l) acc = fma(-read_lane(ac[i], l), u[l], acc);
             u[i] = acc * read_lane(pnv, i);
           }
-          const double sj = sgv;                         // S_j for this laneq's column
+#pragma unroll
+          for (int i = 0; i < TILE; ++i) Mbuf[i * 16 + j] = u[i];
+          // pivot tile of the panel: R_hh = S R on and above the diagonal, Y_1 below it
 #pragma unroll
           for (int i = 0; i < TILE; ++i) {
-            S2[i * 16 + j] = u[i];
-            S0[i * 16 + j] = (i <= j) ? qc[i] * sj : 0.0;
+            const double si = read_lane(sgv, i);
+            if (laneq < TILE) P[j * LDP + base + i] = (i <= j) ? si * col[i] : ac[i];
           }
-        }
-        // Z = Y_1^-T: column j of L^-1 (unit lower, forward substitution) is row j of Z -> S3
-        {
+        } else {
+          // W = Y_1^T S R (MFMA): A operand E[m][k] = Y_1[k][m] S_k, B operand R
+#pragma unroll
+          for (int i = 0; i < TILE; ++i) {
+            const double si = read_lane(sgv, i);
+            SA[j * 16 + i] = (i > j) ? ac[i] * si : ((i == j) ? si : 0.0);
+            SB[i * 16 + j] = col[i];
+          }
+          v4d wacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            wacc = mfma_f64(SA[lcq * 16 + 4 * s + lrq], SB[(4 * s + lrq) * 16 + lcq], wacc);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) SA[(lrq + 4 * g) * 16 + lcq] = wacc[g];
+          double wc[TILE];
+#pragma unroll
+          for (int i = 0; i < TILE; ++i) wc[i] = SA[i * 16 + j];
+          const double wjj = SA[j * 17];
+          double wdi = __builtin_amdgcn_rcp(wjj);
+          wdi = wdi * fma(-wjj, wdi, 2.0);
+          wdi = wdi * fma(-wjj, wdi, 2.0);
+          // W^-1, column j
           double z[TILE];
 #pragma unroll
-          for (int i = 0; i < TILE; ++i) {
+          for (int i = TILE - 1; i >= 0; --i) {
             double acc = (i == j) ? 1.0 : 0.0;
 #pragma unroll
-            for (int l = 0; l < i; ++l) acc = fma(-read_lane(qc[i], l), z[l], acc);
-            z[i] = acc;
+            for (int l = i + 1; l < TILE; ++l) acc = fma(-read_lane(wc[i], l), z[l], acc);
+            z[i] = acc * read_lane(wdi, i);
           }
+          // T = -U' W^-1 (MFMA): A operand U' (upper part of ac), B operand W^-1
 #pragma unroll
-          for (int i = 0; i < TILE; ++i) S3[j * 16 + i] = z[i];
-        }
-        // T = -(U S) Z  and  M = R^-1 U^-1  (16x16x16 products on the MFMA pipe)
-        v4d tacc = {0.0, 0.0, 0.0, 0.0}, macc = {0.0, 0.0, 0.0, 0.0};
+          for (int i = 0; i < TILE; ++i) {
+            SB[i * 16 + j] = (i <= j) ? ac[i] : 0.0;
+            SA[i * 16 + j] = z[i];
+          }
+          v4d tacc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          tacc = mfma_f64(S0[lcq * 16 + 4 * s + lrq], S3[(4 * s + lrq) * 16 + lcq], tacc);
-          macc = mfma_f64(S1[lcq * 16 + 4 * s + lrq], S2[(4 * s + lrq) * 16 + lcq], macc);
-        }
-        double* Tk = T + k * 256;
+          for (int s = 0; s < 4; ++s)
+            tacc = mfma_f64(SB[lcq * 16 + 4 * s + lrq], SA[(4 * s + lrq) * 16 + lcq], tacc);
+          double* Tk = T + k * 256;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int e = (lrq + 4 * g) * 16 + lcq;
-          Gs[e] = -tacc[g];
-          Tk[e] = -tacc[g];
-          Mbuf[e] = macc[g];
+          for (int g = 0; g < 4; ++g) {
+            const int e = (lrq + 4 * g) * 16 + lcq;
+            Gs[e] = -tacc[g];
+            Tk[e] = -tacc[g];
+          }
         }
       }
-      if (laneq == 0) {
+      if (w == 0 && laneq == 0) {
         flag[0] = ok ? 1.0 : 0.0;
         atomicAdd(&g_cqr_stats[ok ? 0 : 1], 1ULL);
       }
