@@ -46,6 +46,7 @@ struct blsq_ctx {
   struct Pending { int slot; hipEvent_t a, b; };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> pool;
+  int* pinned = nullptr;            // 4 pinned host ints: device -> host counters without staging
 
   int fail(hipError_t e, const char* where) {
     err = std::string(where) + ": " + hipGetErrorString(e);
@@ -258,6 +259,8 @@ extern "C" int blsq_ctx_create(int device_id, blsq_ctx** out) {
   c->device = device_id;
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return (int)e; }
+  e = hipHostMalloc((void**)&c->pinned, 4 * sizeof(int), hipHostMallocDefault);
+  if (e != hipSuccess) { hipStreamDestroy(c->stream); delete c; return (int)e; }
   *out = c;
   return 0;
 }
@@ -269,6 +272,7 @@ extern "C" int blsq_ctx_destroy(blsq_ctx* ctx) {
   ctx->collect();
   for (auto e : ctx->pool) hipEventDestroy(e);
   hipStreamDestroy(ctx->stream);
+  if (ctx->pinned) hipHostFree(ctx->pinned);
   delete ctx;
   return 0;
 }
@@ -465,9 +469,10 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
   hipError_t e = launch_lm_start(p->lm, dDelta, dalpha_in, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_lm_start");
-  HIPCHK(ctx, hipMemcpyAsync(&active, p->lm.active_count, sizeof(int), hipMemcpyDeviceToHost,
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, p->lm.active_count, sizeof(int), hipMemcpyDeviceToHost,
                              ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  active = ctx->pinned[0];
   for (int round = 0; round < 12 && active > 0; ++round) {
     HIPCHK(ctx, hipMemsetAsync(p->lm.active_count, 0, sizeof(int), ctx->stream));
     // source = [R_aug | c_aug] read in place, stacked on a VIRTUAL sqrt(alpha) I block
@@ -487,9 +492,10 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
     e = launch_lm_update(p->lm, ctx->stream);
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_lm_update");
-    HIPCHK(ctx, hipMemcpyAsync(&active, p->lm.active_count, sizeof(int), hipMemcpyDeviceToHost,
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, p->lm.active_count, sizeof(int), hipMemcpyDeviceToHost,
                                ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    active = ctx->pinned[0];
   }
   return 0;
 }
@@ -1269,10 +1275,10 @@ extern "C" int blsq_outer_propose(blsq_outer* o, int32_t* n_active) {
   HIPCHK(ctx, hipMemsetAsync(o->st.counts, 0, sizeof(int) * 2, ctx->stream));
   e = launch_outer_trial(o->st, ctx->stream);
   if (e != hipSuccess) return ctx->fail(e, "launch_outer_trial");
-  int c = 0;
-  HIPCHK(ctx, hipMemcpyAsync(&c, o->st.counts, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, o->st.counts, sizeof(int), hipMemcpyDeviceToHost,
+                             ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  *n_active = c;
+  *n_active = ctx->pinned[0];
   return 0;
 }
 
@@ -1284,12 +1290,11 @@ extern "C" int blsq_outer_judge(blsq_outer* o, int32_t* n_accepted) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   hipError_t e = launch_outer_judge(o->st, ctx->stream);
   if (e != hipSuccess) return ctx->fail(e, "launch_outer_judge");
-  int c = 0;
-  HIPCHK(ctx, hipMemcpyAsync(&c, o->st.counts + 1, sizeof(int), hipMemcpyDeviceToHost,
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, o->st.counts + 1, sizeof(int), hipMemcpyDeviceToHost,
                              ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  *n_accepted = c;
-  o->last_accepted = c;
+  *n_accepted = ctx->pinned[0];
+  o->last_accepted = ctx->pinned[0];
   return 0;
 }
 
