@@ -129,7 +129,11 @@ def test_dogbox_golden(bl, tr_path, name, ins, out):
 
 @pytest.mark.parametrize("B,m,n", [(16, 512, 64), (5, 200, 37), (3, 1500, 20), (2, 4096, 256),
                                    (2, 2500, 50), (3, 1100, 17), (4, 700, 100), (2, 5000, 33),
-                                   (2, 3000, 200), (6, 90, 5), (2, 1089, 16)])
+                                   (2, 3000, 200), (6, 90, 5), (2, 1089, 16),
+                                   # few live rows in the late panels (Gram of < 16 rows: the
+                                   # Cholesky-QR panel path must fall back), square and tall-thin
+                                   (3, 64, 64), (3, 70, 64), (2, 300, 256), (2, 1025, 32),
+                                   (2, 2049, 48)])
 def test_trf_batch_vs_oracle(bl, tr_path, B, m, n):
     from oracle import blsq_oracle as orc
     from bounded_lsq import _synth
