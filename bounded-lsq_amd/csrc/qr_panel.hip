@@ -279,12 +279,12 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
   // and LU and then split: wave 0 inverts U' (-> M), wave 1 forms W, inverts it and multiplies
   // (-> T); lane j (mod 16) owns column j in registers, broadcasts are v_readlane, the 16x16x16
   // products go to the MFMA pipe through small LDS scratch tiles.  The Cholesky pivots of the
-  // unit-diagonal Gram bound the conditioning: if the smallest one is below CQR_PMIN (or a column
+  // unit-diagonal Gram bound the conditioning: if the smallest one is below CQR_PMIN = 0.1 (or a column
   // is zero / not finite) nothing has been modified and the exact Householder column loop runs
   // instead.  Returns true on success with P = [R_hh upper | Y_1 strictly lower] in the pivot tile
   // and Y_2 below it, Gs = T_k (also in the global T scratch) — exactly what the column loop and
   // the T recurrence leave behind.
-  constexpr double CQR_PMIN = 0.05;
+  constexpr double CQR_PMIN = 0.1;
   auto panel_cqr = [&](v4d* pa, int k, int hik) -> bool {
     const int base = k * TILE;
     int lcq = lc, lrq = lr, laneq = lane;
