@@ -460,6 +460,14 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
           double* pt = P + lcq * LDP + t * TILE + lrq;
 #pragma unroll
           for (int g = 0; g < 4; ++g) pt[4 * g] = y[g];
+          if (k < NP - 1) {                  // spill the tile image for later panels right away
+            double* vt = V + ((long)k * RP + (long)t * TILE) * 16;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int r = lrq + 4 * g;
+              vt[16 * r + (lcq ^ r)] = y[g];
+            }
+          }
         }
       }
     }
@@ -812,9 +820,12 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
     }
     STAMP(4)
     // ---- 7. spill V_k for later panels: 2 KB tile images, element (r, c) at 16 r + (c ^ r)
+    // (tiles above the pivot tile are never read back; after the Cholesky-QR path the tiles
+    // below it have been written by that path already)
     if (k < NP - 1) {
       double* Vk = V + (long)k * RP * 16;
-      for (int idx = tid; idx < rows_k * 16; idx += QR_NT) {
+      const int hi7 = cqr_ok ? (base + TILE) * 16 : rows_k * 16;
+      for (int idx = base * 16 + tid; idx < hi7; idx += QR_NT) {
         const int row = idx >> 4, c = (idx & 15) ^ (row & 15);   // image position idx holds column c
         Vk[idx] = P[c * LDP + row];
       }
