@@ -211,15 +211,14 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
   // panel kk of the source -> registers, accumulator layout (single HBM read):
   // x[i][g] = element (row 16 t + lr + 4 g, column 16 kk + lc) of tile t = w + 8 i.
   // Loads are unconditional (clamped addresses, select afterwards).
-  auto load_panel = [&](v4d* x, int kk) {
-    const int hi = (ST && G * (kk + 1) < ntile) ? G * (kk + 1) : ntile;
+  // In two halves so that both panels of a pair have their loads in flight together:
+  // issue (raw values, clamped unconditional loads) ... finish (masks, scaling).
+  auto issue_panel = [&](v4d* x, int kk) {
     const int rmem = (vrow0 > 0 && vrow0 < nrows) ? vrow0 : nrows;   // rows backed by memory
     const int rmax = rmem > 0 ? rmem - 1 : 0;
     const int col = kk * TILE + lc;
     const int cc = col < nA ? col : (nA > 0 ? nA - 1 : 0);
     const bool have = nrows > 0 && nA > 0;
-    const double cs = (cscale && nA > 0) ? cscale[cc] : 1.0;          // fused column scaling
-    const double vd = (vdvec && nA > 0) ? vdvec[cc] : vdiag;          // this column's diagonal value
     int lrk = lr;
     asm volatile("" : "+v"(lrk));           // per-panel recomputation instead of 32 hoisted addresses
 #pragma unroll
@@ -231,6 +230,15 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
         x[i][g] = have ? A[(unsigned)(rc * q.ldA + cc)] : 0.0;
       }
     }
+  };
+  auto finish_panel = [&](v4d* x, int kk) {
+    const int hi = (ST && G * (kk + 1) < ntile) ? G * (kk + 1) : ntile;
+    const int col = kk * TILE + lc;
+    const int cc = col < nA ? col : (nA > 0 ? nA - 1 : 0);
+    const double cs = (cscale && nA > 0) ? cscale[cc] : 1.0;          // fused column scaling
+    const double vd = (vdvec && nA > 0) ? vdvec[cc] : vdiag;          // this column's diagonal value
+    int lrk = lr;
+    asm volatile("" : "+v"(lrk));
 #pragma unroll
     for (int i = 0; i < MAXT; ++i) {
 #pragma unroll
@@ -495,8 +503,10 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
           if (i >= lo && i < hi) glds_tile(V + (w + QR_NW * i) * 256, Vs + i * 256, lane16);
       }
       // ---- 1. panels k (and k+1) of the source -> registers ------------------
-      load_panel(pc, k);
-      if (lead) load_panel(pd, k + 1);
+      issue_panel(pc, k);
+      if (lead) issue_panel(pd, k + 1);
+      finish_panel(pc, k);
+      if (lead) finish_panel(pd, k + 1);
       STAMP(0)
 
       // ---- 2. apply block reflectors 0..k-1:  P -= V_j (T_j^T (V_j^T P)) ----
