@@ -258,9 +258,20 @@ __global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
     lds_barrier();
     v4d W = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int ww = 0; ww < QR_NW; ++ww) {
+    for (int h = 0; h < QR_NW; h += 2) {      // two partials (8 values) in flight at a time
+      double wp[2][4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) W[g] += Wred[ww * 256 + g * 64 + lane];
+      for (int ww = 0; ww < 2; ++ww) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) wp[ww][g] = Wred[(h + ww) * 256 + g * 64 + lane];
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int ww = 0; ww < 2; ++ww) {        // fixed order: deterministic
+#pragma unroll
+        for (int g = 0; g < 4; ++g) W[g] += wp[ww][g];
+      }
+      __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
     }
     v4d W2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
