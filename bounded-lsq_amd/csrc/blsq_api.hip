@@ -405,13 +405,18 @@ int trf_alloc_state(blsq_trf_plan* p) {
     lm.fast = ii; lm.ncols_jac = ii + B; lm.ncols_lm = ii + 2 * (size_t)B; lm.st = ii + 3 * (size_t)B;
     lm.active_count = ii + 7 * (size_t)B;
     lm.sc = p->lm_sc.as<double>(); lm.ph = p->lm_ph.as<double>();
-    // The SVD-free Newton iteration costs one small stacked QR per iteration; below
-    // n ~ 64 those QRs are latency-bound and the in-LDS Jacobi SVD is cheaper (measured
-    // 512x64: 491k vs 421k step-solves/s), so small problems keep the SVD.
+    // The SVD-free Newton iteration costs one small stacked QR per iteration.  Measured
+    // (8192..16384 problems per launch, Delta mix 10/0.5; SVD-free vs Jacobi-SVD step-solves/s):
+    // 64x8 5.3M vs 3.4M, 128x16 6.2M vs 2.9M (one panel: the QR is trivial), 256x32 1.55M vs
+    // 1.73M, 512x40 0.90M vs 0.90M, 512x48 0.98M vs 0.89M, 512x64 0.76M vs 0.70M.  So the
+    // Jacobi SVD keeps the band 16 < n < 48 where a round of tiny two-panel QRs costs as much as
+    // the whole in-LDS SVD.  BLSQ_SVDFREE_MIN_N overrides the upper edge (0: SVD-free whenever
+    // the gate passes), BLSQ_NO_SVDFREE=1 forces the SVD.
     const char* env = getenv("BLSQ_NO_SVDFREE");
     const char* envn = getenv("BLSQ_SVDFREE_MIN_N");
-    const int min_n = envn ? atoi(envn) : 65;
-    p->lm_enable = ((env && env[0] == '1') || p->n < min_n) ? 0 : 1;
+    const int min_n = envn ? atoi(envn) : 48;
+    const bool band = p->n > 16 && p->n < min_n;
+    p->lm_enable = ((env && env[0] == '1') || band) ? 0 : 1;
   }
   p->aug_RP = std::max(aug_rows(p->n), ld);
   if (aug_rows(p->n) > RMAX) return ctx->bad(4, "n too large for the augmented system (n <= 512)");
