@@ -110,7 +110,7 @@ __device__ __forceinline__ void lds_barrier() {
 //
 // MAXT = tile slots per wave (ceil(ntile/8)); slot i of wave w is tile w + 8 i.
 template <int MAXT, bool ST>
-__global__ __launch_bounds__(QR_NT) void qr_panel_kernel(QrArgs q) {
+__global__ __launch_bounds__(QR_NT, (MAXT <= 2 ? 4 : 2)) void qr_panel_kernel(QrArgs q) {
   constexpr int NR = (MAXT * QR_NW * TILE + QR_NT - 1) / QR_NT;   // rows per thread
   extern __shared__ double lds[];
   const int tid = threadIdx.x;
