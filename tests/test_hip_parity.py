@@ -454,3 +454,46 @@ def test_kahan_structured_panels(bl, s_):
         assert rel(S.step[b], So.step) < 1e-11, (s_, b, rel(S.step[b], So.step))
         np.testing.assert_array_equal(S.hits[b], So.hits)
     sol.close()
+
+
+def test_randomised_shapes_against_oracle(bl):
+    """40 seeded random shapes around every structural boundary of the QR (panel width 16, leaf
+    height 1024, pair mode, stacked merges, partial panels, one-column problems): TRF and dogbox
+    steps against the oracle."""
+    from oracle import blsq_oracle as orc
+    from bounded_lsq import _synth
+    rng = np.random.default_rng(20240)
+    ns = [1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 80, 96, 97, 128]
+    worst = 0.0
+    for it in range(40):
+        n = int(rng.choice(ns))
+        m = int(rng.choice([n, n + 1, n + 7, 2 * n + 3, 511, 512, 513, 1023, 1024, 1025, 2047,
+                            2049, 3000]))
+        m = max(m, n)
+        B = int(rng.integers(1, 4))
+        P = _synth.trf_batch(7000 + it, B, m, n)
+        Delta = rng.choice([10.0, 0.5, 0.05], size=B)
+        sol = bl.TrfStepSolver(B, m, n)
+        sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+        S = sol.step(Delta, np.zeros(B))
+        for b in range(B):
+            _, So = orc.trf_step_solve(P["J"][b], P["f"][b], P["x"][b], P["lb"][b], P["ub"][b],
+                                       P["scale"][b], Delta[b], 0.0)
+            e = rel(S.step[b], So.step)
+            worst = max(worst, e)
+            assert e < RTOL, ("trf", it, B, m, n, b, e)
+            np.testing.assert_array_equal(S.hits[b], So.hits)
+        sol.close()
+        Pd = _synth.dogbox_batch(8000 + it, B, m, n)
+        Dd = rng.choice([0.02, 0.005, 1.0], size=B)
+        dog = bl.DogboxStepSolver(B, m, n)
+        dog.factor(Pd["J"], Pd["f"], Pd["x"], Pd["lb"], Pd["ub"], Pd["scale"], Pd["on_bound"])
+        D = dog.step(Dd)
+        for b in range(B):
+            _, So = orc.dogbox_step_solve(Pd["J"][b], Pd["f"][b], Pd["x"][b], Pd["lb"][b],
+                                          Pd["ub"][b], Pd["scale"][b], Pd["on_bound"][b], Dd[b])
+            e = rel(D.step[b], So.step)
+            assert e < RTOL, ("dogbox", it, B, m, n, b, e)
+            np.testing.assert_array_equal(D.on_bound_new[b], So.on_bound_new)
+        dog.close()
+    assert worst < RTOL
