@@ -23,9 +23,13 @@
 //     operand shapes (V^T for the first GEMM, V for the third) are read from the same
 //     LDS image — V is stored in HBM pre-swizzled (col ^ row within a tile) so both
 //     reads are bank-conflict-free — and no on-chip transposes are needed;
-//   * the updated panel is then written to LDS (column-major) and Householder-
-//     factored with each thread's rows in registers (one fused wave-shuffle + LDS
-//     reduction per column for the norm and the 15 dot products);
+//   * panels go in PAIRS (both in registers) so each V_j tile read serves two panels;
+//   * the updated panel is then written to LDS (column-major) and factored: normally
+//     from its 16x16 Gram by Cholesky-QR + Householder reconstruction (panel_cqr below:
+//     two MFMA passes + a 16x16 chain on two waves, no per-column barriers); when the
+//     Gram's pivots say the panel is not well conditioned, exactly, column by column,
+//     with each thread's rows in registers (one fused wave-shuffle + LDS reduction per
+//     column for the norm and the 15 dot products);
 //   * cross-wave reduction of the 16x16 W goes through LDS in a fixed order
 //     (deterministic results).
 // Leaves produce (N x N) triangles; the same kernel merges stacked triangles
