@@ -179,4 +179,23 @@ __device__ __forceinline__ bool is_finite(double v) {
   return (v - v) == 0.0;
 }
 
+// ---- LDS-DMA (global -> LDS without VGPR staging) ------------------------------------------
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+// One LDS-DMA instruction: 64 lanes x 16 B, global (per-lane address) -> LDS
+// (wave-uniform base + 16 lane).  Completion is tracked by vmcnt, in issue order.
+// The source is (wave-uniform base) + (per-lane 32-bit byte offset): the SGPR-base
+// addressing form, so a slot costs no 64-bit address VGPRs.
+__device__ __forceinline__ void glds16(const double* base_uniform, unsigned byte_off_lane,
+                                       double* lds_uniform) {
+  __builtin_amdgcn_global_load_lds((gptr_t*)((const char*)base_uniform + byte_off_lane),
+                                   (lptr_t*)lds_uniform, 16, 0, 0);
+}
+
+// workgroup barrier that orders LDS traffic only: DMA loads stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 }  // namespace blsq

@@ -25,6 +25,16 @@
 
 namespace blsq {
 
+// dynamic LDS above 64 KB has to be granted per kernel once
+template <class K>
+static hipError_t grant_lds(K kernel, size_t bytes, size_t& granted) {
+  if (bytes <= granted) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)bytes);
+  if (e == hipSuccess) granted = bytes;
+  return e;
+}
+
 static constexpr double LM_EPS = 2.220446049250313e-16;
 static constexpr double LM_GATE_MARGIN = 1.0e3;
 
@@ -44,6 +54,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_gate_kernel(LmState lm, int enable)
   double* v = sh;
   double* u = v + ld;
   double* invd = u + ld;
+  double* pfbuf = invd + ld;                 // 2 x 16 x ld doubles: DMA staging of the solves
   int ok = (enable != 0) && (lm.m >= n);
   // diagonal: finite and non-zero
   int bad = 0;
@@ -69,8 +80,8 @@ __global__ __launch_bounds__(TRI_NT) void lm_gate_kernel(LmState lm, int enable)
     for (int i = tid; i < n; i += TRI_NT) v[i] = (i % 3 == 0) ? s0 : -0.5 * s0;
     __syncthreads();
     for (int it = 0; it < 2; ++it) {
-      tri_solve_upper_t(R, n, ld, invd, v);
-      tri_solve_upper(R, n, ld, invd, v);
+      tri_solve_upper_t_pf(R, n, ld, invd, v, pfbuf);
+      tri_solve_upper_pf(R, n, ld, invd, v, pfbuf);
       const double nv = sqrt(tri_dot(v, v, n, red));
       smin = (nv > 0.0 && is_finite(nv)) ? 1.0 / sqrt(nv) : 0.0;   // ||(R^T R)^{-1} v|| ~ 1/s_min^2
       const double inv = (nv > 0.0 && is_finite(nv)) ? 1.0 / nv : 0.0;
@@ -89,7 +100,8 @@ __global__ __launch_bounds__(TRI_NT) void lm_gate_kernel(LmState lm, int enable)
 }
 
 hipError_t launch_lm_gate(const LmState& lm, int enable, hipStream_t s) {
-  const size_t lds = sizeof(double) * 3 * (size_t)lm.ld;
+  const size_t lds = sizeof(double) * (3 + 32) * (size_t)lm.ld;
+  { static size_t granted = 0; hipError_t ge = grant_lds(lm_gate_kernel, lds, granted); if (ge != hipSuccess) return ge; }
   hipLaunchKernelGGL(lm_gate_kernel, dim3(lm.B), dim3(TRI_NT), lds, s, lm, enable);
   return hipGetLastError();
 }
@@ -116,6 +128,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_start_kernel(LmState lm, const doub
   double* p = sh;
   double* q = p + ld;
   double* invd = q + ld;
+  double* pfbuf = invd + ld;                 // 2 x 16 x ld doubles: DMA staging of the solves
   double* sc = lm.sc + (long)b * 16;
   int* st = lm.st + (long)b * 4;
   const double Delta = Delta_in[b];
@@ -125,7 +138,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_start_kernel(LmState lm, const doub
   // alpha_upper = ||A^T b|| / Delta
   tri_mtv(R, n, ld, p, q);
   const double gnorm = sqrt(tri_dot(q, q, n, red));
-  tri_solve_upper(R, n, ld, invd, p);                                     // R^{-1} c
+  tri_solve_upper_pf(R, n, ld, invd, p, pfbuf);                           // R^{-1} c
   const double pn = sqrt(tri_dot(p, p, n, red));
   for (int i = tid; i < n; i += TRI_NT) {
     p[i] = -p[i];
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_start_kernel(LmState lm, const doub
   // phi(0), phi'(0) -> alpha_lower (trust_region.py:121-123)
   for (int i = tid; i < n; i += TRI_NT) q[i] = p[i];
   __syncthreads();
-  tri_solve_upper_t(R, n, ld, invd, q);
+  tri_solve_upper_t_pf(R, n, ld, invd, q, pfbuf);
   const double qq = tri_dot(q, q, n, red);
   const double phi = pn - Delta;
   const double dphi = -qq / pn;
@@ -161,7 +174,8 @@ __global__ __launch_bounds__(TRI_NT) void lm_start_kernel(LmState lm, const doub
 
 hipError_t launch_lm_start(const LmState& lm, const double* Delta, const double* alpha_in,
                            hipStream_t s) {
-  const size_t lds = sizeof(double) * 3 * (size_t)lm.ld;
+  const size_t lds = sizeof(double) * (3 + 32) * (size_t)lm.ld;
+  { static size_t granted = 0; hipError_t ge = grant_lds(lm_start_kernel, lds, granted); if (ge != hipSuccess) return ge; }
   hipLaunchKernelGGL(lm_start_kernel, dim3(lm.B), dim3(TRI_NT), lds, s, lm, Delta, alpha_in);
   return hipGetLastError();
 }
@@ -181,12 +195,13 @@ __global__ __launch_bounds__(TRI_NT) void lm_update_kernel(LmState lm) {
   double* p = sh;
   double* q = p + ld;
   double* invd = q + ld;
+  double* pfbuf = invd + ld;                 // 2 x 16 x ld doubles: DMA staging of the solves
   double* sc = lm.sc + (long)b * 16;
   const double Delta = sc[SC_DELTA];
   tri_invdiag(R, n, ld, invd);
   for (int i = tid; i < n; i += TRI_NT) p[i] = R[(long)i * ld + n];
   __syncthreads();
-  tri_solve_upper(R, n, ld, invd, p);
+  tri_solve_upper_pf(R, n, ld, invd, p, pfbuf);
   const double pn = sqrt(tri_dot(p, p, n, red));
   for (int i = tid; i < n; i += TRI_NT) p[i] = -p[i];
   __syncthreads();
@@ -203,7 +218,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_update_kernel(LmState lm) {
   } else {
     for (int i = tid; i < n; i += TRI_NT) q[i] = p[i];
     __syncthreads();
-    tri_solve_upper_t(R, n, ld, invd, q);
+    tri_solve_upper_t_pf(R, n, ld, invd, q, pfbuf);
     const double qq = tri_dot(q, q, n, red);
     phi = pn - Delta;
     dphi = -qq / pn;
@@ -242,7 +257,8 @@ __global__ __launch_bounds__(TRI_NT) void lm_update_kernel(LmState lm) {
 }
 
 hipError_t launch_lm_update(const LmState& lm, hipStream_t s) {
-  const size_t lds = sizeof(double) * 3 * (size_t)lm.ld;
+  const size_t lds = sizeof(double) * (3 + 32) * (size_t)lm.ld;
+  { static size_t granted = 0; hipError_t ge = grant_lds(lm_update_kernel, lds, granted); if (ge != hipSuccess) return ge; }
   hipLaunchKernelGGL(lm_update_kernel, dim3(lm.B), dim3(TRI_NT), lds, s, lm);
   return hipGetLastError();
 }
@@ -270,6 +286,7 @@ __global__ __launch_bounds__(TRI_NT) void dog_gate_solve_kernel(DogState st, int
   double* v = sh;
   double* u = v + ld;
   double* invd = u + ld;
+  double* pfbuf = invd + ld;                 // 2 x 16 x ld doubles: DMA staging of the solves
   int ok = (enable != 0) && (st.m >= nf);
   int bad = 0;
   for (int i = tid; i < nf; i += TRI_NT) {
@@ -295,8 +312,8 @@ __global__ __launch_bounds__(TRI_NT) void dog_gate_solve_kernel(DogState st, int
     for (int i = tid; i < nf; i += TRI_NT) v[i] = (i % 3 == 0) ? s0 : -0.5 * s0;
     __syncthreads();
     for (int it = 0; it < 3; ++it) {
-      tri_solve_upper_t(R, nf, ld, invd, v);
-      tri_solve_upper(R, nf, ld, invd, v);
+      tri_solve_upper_t_pf(R, nf, ld, invd, v, pfbuf);
+      tri_solve_upper_pf(R, nf, ld, invd, v, pfbuf);
       const double nv = sqrt(tri_dot(v, v, nf, red));
       smin = (nv > 0.0 && is_finite(nv)) ? 1.0 / sqrt(nv) : 0.0;
       const double inv = (nv > 0.0 && is_finite(nv)) ? 1.0 / nv : 0.0;
@@ -309,7 +326,7 @@ __global__ __launch_bounds__(TRI_NT) void dog_gate_solve_kernel(DogState st, int
   if (ok) {
     for (int i = tid; i < nf; i += TRI_NT) v[i] = R[(long)i * ld + nf];      // c_f
     __syncthreads();
-    tri_solve_upper(R, nf, ld, invd, v);
+    tri_solve_upper_pf(R, nf, ld, invd, v, pfbuf);
     for (int i = tid; i < nf; i += TRI_NT) st.newton[(long)b * ld + i] = -v[i];
   }
   if (tid == 0) { fast[b] = ok; ncols_jac[b] = ok ? 0 : N; }
@@ -317,7 +334,8 @@ __global__ __launch_bounds__(TRI_NT) void dog_gate_solve_kernel(DogState st, int
 
 hipError_t launch_dog_gate_solve(const DogState& st, int* fast, int* ncols_jac, int enable,
                                  hipStream_t s) {
-  const size_t lds = sizeof(double) * 3 * (size_t)st.ld;
+  const size_t lds = sizeof(double) * (3 + 32) * (size_t)st.ld;
+  { static size_t granted = 0; hipError_t ge = grant_lds(dog_gate_solve_kernel, lds, granted); if (ge != hipSuccess) return ge; }
   hipLaunchKernelGGL(dog_gate_solve_kernel, dim3(st.B), dim3(TRI_NT), lds, s, st, fast,
                      ncols_jac, enable);
   return hipGetLastError();

@@ -65,18 +65,6 @@ __device__ __forceinline__ v4d mfma_f64(double a, double b, v4d c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-typedef __attribute__((address_space(1))) const void gptr_t;
-typedef __attribute__((address_space(3))) void lptr_t;
-
-// One LDS-DMA instruction: 64 lanes x 16 B, global (per-lane address) -> LDS
-// (wave-uniform base + 16 lane).  Completion is tracked by vmcnt, in issue order.
-// The source is (wave-uniform base) + (per-lane 32-bit byte offset): the SGPR-base
-// addressing form, so a slot costs no 64-bit address VGPRs.
-__device__ __forceinline__ void glds16(const double* base_uniform, unsigned byte_off_lane,
-                                       double* lds_uniform) {
-  __builtin_amdgcn_global_load_lds((gptr_t*)((const char*)base_uniform + byte_off_lane),
-                                   (lptr_t*)lds_uniform, 16, 0, 0);
-}
 // copy one 2 KB tile (two DMA instructions); lane16 = 16 * lane id (bytes)
 __device__ __forceinline__ void glds_tile(const double* src_tile_uniform, double* lds_tile,
                                           unsigned lane16) {
@@ -96,10 +84,6 @@ __device__ __forceinline__ void wait_tiles_outstanding(int n) {
     case 7: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
-}
-// workgroup barrier that orders LDS traffic only: DMA loads stay in flight across it
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // Structured sources (ST): TSQR merges, the Coleman-Li system [R D; E] and the

@@ -118,6 +118,127 @@ __device__ __forceinline__ void tri_solve_upper_t(const double* R, int n, int ld
   }
 }
 
+// ---- the same two solves with the operands prefetched by LDS-DMA ---------------------------
+// R does not fit any cache level for a whole batch, so each 16-wide block step of the solves
+// above pays HBM / MALL round trips for its diagonal block and its panel.  Here the operands of
+// block step kb-1 (kb+1) stream global -> LDS (global_load_lds, no VGPR staging) while step kb
+// computes from LDS; the barriers inside the loop are LDS-only so the DMA stays in flight.
+// buf: 2 * 16 * ld doubles of LDS.  R rows must be 16-byte aligned (ld % 2 == 0).
+
+// rows 0 .. c0+15, columns c0 .. c0+15  ->  dst[row * 16 + col - c0]
+__device__ __forceinline__ void tri_pf_issue_upper(const double* R, int ld, int c0, double* dst) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nrow = c0 + 16;                              // multiple of 16: whole 8-row DMA pieces
+  for (int r0 = w * 8; r0 < nrow; r0 += TRI_NW * 8) {
+    const int row = r0 + (lane >> 3);
+    glds16(R + c0, (unsigned)(row * ld + 2 * (lane & 7)) * 8u, dst + r0 * 16);
+  }
+}
+// rows c0 .. c0+15, columns c0 .. ld-1  ->  dst[s * (ld - c0) + col - c0]
+__device__ __forceinline__ void tri_pf_issue_lower(const double* R, int ld, int c0, double* dst) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int L = ld - c0;                                 // multiple of 16
+  const int half = L >> 1;                               // 16-byte pieces per row
+  const int total = 16 * half;                           // multiple of 64
+  for (int i0 = w * 64; i0 < total; i0 += TRI_NW * 64) {
+    const int idx = i0 + lane;
+    const int srow = idx / half, off = idx - srow * half;
+    glds16(R + c0, (unsigned)((c0 + srow) * ld + 2 * off) * 8u, dst + i0 * 2);
+  }
+}
+
+__device__ __forceinline__ void tri_solve_upper_pf(const double* R, int n, int ld,
+                                                   const double* invd, double* x, double* buf) {
+  const int tid = threadIdx.x;
+  const int nblk = (n + 15) / 16;
+  const int bsz = 16 * ld;
+  int cur = 0;
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  tri_pf_issue_upper(R, ld, (nblk - 1) * 16, buf);
+  for (int kb = nblk - 1; kb >= 0; --kb) {
+    const int c0 = kb * 16;
+    const int bs = (n - c0 < 16) ? n - c0 : 16;
+    const double* b = buf + cur * bsz;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();                                       // every wave's pieces have landed
+    if (kb > 0) tri_pf_issue_upper(R, ld, c0 - 16, buf + (cur ^ 1) * bsz);
+    if (tid < 64) {                                      // wave 0 (lanes >= 16 are idle copies)
+      const int i = tid & 15;
+      double D[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const double val = b[(c0 + i) * 16 + s];
+        D[s] = (i < bs && s < bs && s > i) ? val : 0.0;
+      }
+      double r = (i < bs) ? x[c0 + i] : 0.0;
+      const double iv = (i < bs) ? invd[c0 + i] : 0.0;
+#pragma unroll
+      for (int s = 15; s >= 0; --s) {
+        const double xs = read_lane(r * iv, s);
+        if (i < s) r = fma(-D[s], xs, r);
+      }
+      if (tid < bs) x[c0 + tid] = r * iv;
+    }
+    lds_barrier();
+    for (int i = tid; i < c0; i += TRI_NT) {             // rows above the block
+      const double* row = b + i * 16;
+      double acc = 0.0;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = fma(row[s], (s < bs) ? x[c0 + s] : 0.0, acc);
+      x[i] -= acc;
+    }
+    lds_barrier();
+    cur ^= 1;
+  }
+}
+
+__device__ __forceinline__ void tri_solve_upper_t_pf(const double* R, int n, int ld,
+                                                     const double* invd, double* y, double* buf) {
+  const int tid = threadIdx.x;
+  const int nblk = (n + 15) / 16;
+  const int bsz = 16 * ld;
+  int cur = 0;
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  tri_pf_issue_lower(R, ld, 0, buf);
+  for (int kb = 0; kb < nblk; ++kb) {
+    const int c0 = kb * 16;
+    const int bs = (n - c0 < 16) ? n - c0 : 16;
+    const int L = ld - c0;
+    const double* b = buf + cur * bsz;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    if (kb + 1 < nblk) tri_pf_issue_lower(R, ld, c0 + 16, buf + (cur ^ 1) * bsz);
+    if (tid < 64) {
+      const int i = tid & 15;               // row i of the lower-triangular block = column i of R's block
+      double D[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const double val = b[s * L + i];
+        D[s] = (i < bs && s < bs && s < i) ? val : 0.0;
+      }
+      double r = (i < bs) ? y[c0 + i] : 0.0;
+      const double iv = (i < bs) ? invd[c0 + i] : 0.0;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const double ys = read_lane(r * iv, s);
+        if (i > s) r = fma(-D[s], ys, r);
+      }
+      if (tid < bs) y[c0 + tid] = r * iv;
+    }
+    lds_barrier();
+    for (int j = c0 + 16 + tid; j < n; j += TRI_NT) {    // columns to the right of the block
+      double acc = 0.0;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = fma(b[s * L + (j - c0)], (s < bs) ? y[c0 + s] : 0.0, acc);
+      y[j] -= acc;
+    }
+    lds_barrier();
+    cur ^= 1;
+  }
+}
+
 __device__ __forceinline__ double tri_dot(const double* a, const double* b, int n, double* red) {
   double acc = 0.0;
   for (int j = threadIdx.x; j < n; j += TRI_NT) acc = fma(a[j], b[j], acc);
