@@ -532,11 +532,13 @@ __global__ __launch_bounds__(QR_NT, (MAXT <= 2 ? 4 : 2)) void qr_panel_kernel(Qr
               const int r = 4 * s + lr;
               a[s] = vt[16 * r + (lc ^ r)];
             }
+            __builtin_amdgcn_s_setprio(1);                 // MFMA bursts win the issue arbitration
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
               acc = mfma_f64(a[s], pc[i][s], acc);
               if (PAIR) acc2 = mfma_f64(a[s], pd[i][s], acc2);   // (all-zero pd when there is no second panel)
             }
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 4 LDS reads, then the MFMAs
             __builtin_amdgcn_sched_group_barrier(0x008, PAIR ? 8 : 4, 0);
           }
@@ -561,11 +563,13 @@ __global__ __launch_bounds__(QR_NT, (MAXT <= 2 ? 4 : 2)) void qr_panel_kernel(Qr
               const int c = 4 * s + lr;
               a[s] = vt[16 * lc + (c ^ lc)];
             }
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
               pc[i] = mfma_f64(a[s], W2[s], pc[i]);
               if (PAIR) pd[i] = mfma_f64(a[s], W2b[s], pd[i]);
             }
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, PAIR ? 8 : 4, 0);
           }
