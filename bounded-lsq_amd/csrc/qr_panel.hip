@@ -215,7 +215,7 @@ __global__ __launch_bounds__(QR_NT, (MAXT <= 2 ? 4 : 2)) void qr_panel_kernel(Qr
       for (int g = 0; g < 4; ++g) {
         const int row = src_row((w + QR_NW * i) * TILE + lrk + 4 * g);
         const int rc = row < rmax ? row : rmax;
-        x[i][g] = have ? A[(unsigned)(rc * q.ldA + cc)] : 0.0;
+        x[i][g] = have ? __builtin_nontemporal_load(A + (unsigned)(rc * q.ldA + cc)) : 0.0;   // read once: stream
       }
     }
   };
