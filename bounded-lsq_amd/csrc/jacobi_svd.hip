@@ -31,6 +31,8 @@
 //     pair costs ONE dot product; tan/cos/sin come from v_rcp_f64 / v_rsq_f64
 //     + Newton steps — any t is a valid rotation, only cos^2+sin^2 = 1 needs
 //     full precision.
+#include <atomic>
+
 #include "blsq_device.h"
 #include "blsq_kernels.h"
 
@@ -482,12 +484,16 @@ int jacobi_block_rows(int ldx) {
 
 template <int EPL>
 static hipError_t launch_jacobi_t(const JacobiArgs& a, int B, size_t lds, hipStream_t st) {
-  static size_t configured = 0;
-  if (lds > configured) {
+  // the attribute is per device; one ctx per host thread: launches may race (a repeated set is harmless)
+  static std::atomic<size_t> configured_dev[64];
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  std::atomic<size_t>& configured = configured_dev[dev_ & 63];
+  if (lds > configured.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute((const void*)jacobi_rows_kernel<EPL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    configured = lds;
+    configured.store(lds, std::memory_order_release);
   }
   hipLaunchKernelGGL(jacobi_rows_kernel<EPL>, dim3(B), dim3(JAC_NT), lds, st, a);
   return hipGetLastError();

@@ -19,6 +19,8 @@
 // everything else — rank-deficient, wide (m < n), badly conditioned — goes through
 // the Jacobi SVD exactly as before.  Batched problems advance in lock-step rounds
 // (one stacked QR per Newton iteration), finished ones drop out.
+#include <atomic>
+
 #include "blsq_device.h"
 #include "blsq_kernels.h"
 #include "tri_ops.h"
@@ -27,11 +29,14 @@ namespace blsq {
 
 // dynamic LDS above 64 KB has to be granted per kernel once
 template <class K>
-static hipError_t grant_lds(K kernel, size_t bytes, size_t& granted) {
-  if (bytes <= granted) return hipSuccess;
+static hipError_t grant_lds(K kernel, size_t bytes, std::atomic<size_t>* granted_dev) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);                      // the attribute is per device
+  std::atomic<size_t>& granted = granted_dev[dev & 63];
+  if (bytes <= granted.load(std::memory_order_acquire)) return hipSuccess;
   hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)bytes);
-  if (e == hipSuccess) granted = bytes;
+  if (e == hipSuccess) granted.store(bytes, std::memory_order_release);   // (a racing second grant is harmless)
   return e;
 }
 
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_gate_kernel(LmState lm, int enable)
 
 hipError_t launch_lm_gate(const LmState& lm, int enable, hipStream_t s) {
   const size_t lds = sizeof(double) * (3 + 32) * (size_t)lm.ld;
-  { static size_t granted = 0; hipError_t ge = grant_lds(lm_gate_kernel, lds, granted); if (ge != hipSuccess) return ge; }
+  { static std::atomic<size_t> granted[64]; hipError_t ge = grant_lds(lm_gate_kernel, lds, granted); if (ge != hipSuccess) return ge; }
   hipLaunchKernelGGL(lm_gate_kernel, dim3(lm.B), dim3(TRI_NT), lds, s, lm, enable);
   return hipGetLastError();
 }
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_start_kernel(LmState lm, const doub
 hipError_t launch_lm_start(const LmState& lm, const double* Delta, const double* alpha_in,
                            hipStream_t s) {
   const size_t lds = sizeof(double) * (3 + 32) * (size_t)lm.ld;
-  { static size_t granted = 0; hipError_t ge = grant_lds(lm_start_kernel, lds, granted); if (ge != hipSuccess) return ge; }
+  { static std::atomic<size_t> granted[64]; hipError_t ge = grant_lds(lm_start_kernel, lds, granted); if (ge != hipSuccess) return ge; }
   hipLaunchKernelGGL(lm_start_kernel, dim3(lm.B), dim3(TRI_NT), lds, s, lm, Delta, alpha_in);
   return hipGetLastError();
 }
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_update_kernel(LmState lm) {
 
 hipError_t launch_lm_update(const LmState& lm, hipStream_t s) {
   const size_t lds = sizeof(double) * (3 + 32) * (size_t)lm.ld;
-  { static size_t granted = 0; hipError_t ge = grant_lds(lm_update_kernel, lds, granted); if (ge != hipSuccess) return ge; }
+  { static std::atomic<size_t> granted[64]; hipError_t ge = grant_lds(lm_update_kernel, lds, granted); if (ge != hipSuccess) return ge; }
   hipLaunchKernelGGL(lm_update_kernel, dim3(lm.B), dim3(TRI_NT), lds, s, lm);
   return hipGetLastError();
 }
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(TRI_NT) void dog_gate_solve_kernel(DogState st, int
 hipError_t launch_dog_gate_solve(const DogState& st, int* fast, int* ncols_jac, int enable,
                                  hipStream_t s) {
   const size_t lds = sizeof(double) * (3 + 32) * (size_t)st.ld;
-  { static size_t granted = 0; hipError_t ge = grant_lds(dog_gate_solve_kernel, lds, granted); if (ge != hipSuccess) return ge; }
+  { static std::atomic<size_t> granted[64]; hipError_t ge = grant_lds(dog_gate_solve_kernel, lds, granted); if (ge != hipSuccess) return ge; }
   hipLaunchKernelGGL(dog_gate_solve_kernel, dim3(st.B), dim3(TRI_NT), lds, s, st, fast,
                      ncols_jac, enable);
   return hipGetLastError();

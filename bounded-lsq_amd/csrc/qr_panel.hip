@@ -38,6 +38,8 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <atomic>
+
 #include "blsq_device.h"
 #include "blsq_kernels.h"
 
@@ -904,12 +906,16 @@ size_t qr_lds_bytes(int LDP, int maxt) {
 template <int MAXT, bool ST>
 static hipError_t launch_qr_t(const QrArgs& q, int nleaf, int B, hipStream_t st) {
   const size_t lds = qr_lds_bytes(q.LDP, MAXT);
-  static size_t configured = 0;
-  if (lds > configured) {
+  // the attribute is per device; one ctx per host thread: launches may race (a repeated set is harmless)
+  static std::atomic<size_t> configured_dev[64];
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  std::atomic<size_t>& configured = configured_dev[dev_ & 63];
+  if (lds > configured.load(std::memory_order_acquire)) {
     hipError_t e = hipFuncSetAttribute((const void*)qr_panel_kernel<MAXT, ST>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    configured = lds;
+    configured.store(lds, std::memory_order_release);
   }
   hipLaunchKernelGGL((qr_panel_kernel<MAXT, ST>), dim3(nleaf, B), dim3(QR_NT), lds, st, q);
   return hipGetLastError();
