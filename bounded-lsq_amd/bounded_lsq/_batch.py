@@ -58,6 +58,7 @@ def least_squares_batch(fun, x0, jac, bounds=(-np.inf, np.inf), method='trf',
     lb, ub = _bounds_2d(bounds, B, n)
     if not callable(fun):
         raise ValueError("`fun` must be callable (vectorised over the batch).")
+    fd_state = {}                                  # lazily created FdJacobian (+ ctx if we own it)
     if isinstance(jac, str) and jac in ('2-point', '3-point'):
         # the reference's FD Jacobian (third-party approx_derivative, least_squares.py:357-365)
         # restated for the batch on the device (`FdJacobian`: bit-identical steps, points and
@@ -66,14 +67,15 @@ def least_squares_batch(fun, x0, jac, bounds=(-np.inf, np.inf), method='trf',
         from . import _abi
         from ._fd import FdJacobian
         fd_method = jac
-        fd_ctx = ctx if ctx is not None else _abi.Context(0)
-        ctx = fd_ctx
-        fd_state = {}
+        user_ctx = ctx
 
         def jac(X):                                                     # noqa: F811
             F = np.ascontiguousarray(fun(X), dtype=float)
             if "fd" not in fd_state:
-                fd_state["fd"] = FdJacobian(fd_ctx, B, F.shape[1], n, fd_method, None)
+                if user_ctx is None:
+                    fd_state["own_ctx"] = _abi.Context(0)
+                fd_state["fd"] = FdJacobian(user_ctx or fd_state["own_ctx"], B, F.shape[1], n,
+                                            fd_method, None)
 
             def fun_points(Xp):
                 return np.stack([np.asarray(fun(np.ascontiguousarray(Xp[:, p, :])), dtype=float)
@@ -91,9 +93,19 @@ def least_squares_batch(fun, x0, jac, bounds=(-np.inf, np.inf), method='trf',
         max_nfev = n * 100
     if driver not in ('host', 'device'):
         raise ValueError("`driver` must be 'host' or 'device'.")
+
+    def _release_fd():
+        if "fd" in fd_state:
+            fd_state.pop("fd").close()
+        if "own_ctx" in fd_state:
+            fd_state.pop("own_ctx").close()
+
     if driver == 'device':
-        return _device_batch(fun, jac, X0, lb, ub, trf, use_jac, scaling, ftol, xtol, gtol,
-                             max_nfev, ctx)
+        try:
+            return _device_batch(fun, jac, X0, lb, ub, trf, use_jac, scaling, ftol, xtol, gtol,
+                                 max_nfev, ctx)
+        finally:
+            _release_fd()
 
     def feval(X):
         F = np.ascontiguousarray(fun(X), dtype=float)
@@ -255,6 +267,7 @@ def least_squares_batch(fun, x0, jac, bounds=(-np.inf, np.inf), method='trf',
         return results
     finally:
         solver.close()
+        _release_fd()
 
 
 def _device_batch(fun, jac, X0, lb, ub, trf, use_jac, scaling, ftol, xtol, gtol, max_nfev, ctx):
