@@ -358,16 +358,20 @@ __global__ __launch_bounds__(QR_NT, (MAXT <= 2 ? 4 : 2)) void qr_panel_kernel(Qr
       const bool ok = !__any(bad) && (pmin >= CQR_PMIN);
       if (ok) {                                          // wave-uniform, identical in both waves
         const double inv_dj = gjj * dj;                  // sqrt(g_jj) = 1 / d_j
+        // R = R' D^-1 goes to this wave's LDS scratch (row-major) and leaves the registers:
+        // the LU below needs one row of it per step, the products need it as an operand
+        double* SR = (w == 0) ? SA : SB;
 #pragma unroll
-        for (int i = 0; i < TILE; ++i) col[i] *= inv_dj; // col[i] = R[i][j]   (R = R' D^-1)
+        for (int i = 0; i < TILE; ++i) SR[i * 16 + j] = col[i] * inv_dj;
         // LU of A_top - S R without pivoting, S_k = -sgn(pivot): ac -> [U' upper | Y_1 lower]
         double sgv = 1.0, pnv = 0.0;                     // lane k: S_k and 1 / U'[k][k]
 #pragma unroll
         for (int kk = 0; kk < TILE; ++kk) {
           double piv = read_lane(ac[kk], kk);
           const double sk = (piv >= 0.0) ? -1.0 : 1.0;
-          ac[kk] = fma(-sk, col[kk], ac[kk]);            // row k -= S_k R[k][:]
-          piv = fma(-sk, read_lane(col[kk], kk), piv);   // |piv| >= R[k][k] > 0
+          const double rk = SR[kk * 16 + j];             // R[k][j]
+          ac[kk] = fma(-sk, rk, ac[kk]);                 // row k -= S_k R[k][:]
+          piv = fma(-sk, read_lane(rk, kk), piv);        // |piv| >= R[k][k] > 0
           double pi = __builtin_amdgcn_rcp(piv);
           pi = pi * fma(-piv, pi, 2.0);
           pi = pi * fma(-piv, pi, 2.0);
@@ -380,6 +384,14 @@ __global__ __launch_bounds__(QR_NT, (MAXT <= 2 ? 4 : 2)) void qr_panel_kernel(Qr
           }
         }
         if (w == 0) {
+          // pivot tile of the panel: R_hh = S R on and above the diagonal, Y_1 below it
+          // (first: M below reuses the scratch that holds R)
+#pragma unroll
+          for (int i = 0; i < TILE; ++i) {
+            const double si = read_lane(sgv, i);
+            const double rij = SR[i * 16 + j];
+            if (laneq < TILE) P[j * LDP + base + i] = (i <= j) ? si * rij : ac[i];
+          }
           // M = U'^-1, column j (back substitution)
           double u[TILE];
 #pragma unroll
@@ -391,20 +403,13 @@ __global__ __launch_bounds__(QR_NT, (MAXT <= 2 ? 4 : 2)) void qr_panel_kernel(Qr
           }
 #pragma unroll
           for (int i = 0; i < TILE; ++i) Mbuf[i * 16 + j] = u[i];
-          // pivot tile of the panel: R_hh = S R on and above the diagonal, Y_1 below it
-#pragma unroll
-          for (int i = 0; i < TILE; ++i) {
-            const double si = read_lane(sgv, i);
-            if (laneq < TILE) P[j * LDP + base + i] = (i <= j) ? si * col[i] : ac[i];
-          }
         } else {
           // W = Y_1^T S R (MFMA): A operand E[m][k] = Y_1[k][m] S_k, B operand R
 #pragma unroll
           for (int i = 0; i < TILE; ++i) {
             const double si = read_lane(sgv, i);
             SA[j * 16 + i] = (i > j) ? ac[i] * si : ((i == j) ? si : 0.0);
-            SB[i * 16 + j] = col[i];
-          }
+          }                                              // (SB already holds R)
           v4d wacc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
           for (int s = 0; s < 4; ++s)
