@@ -125,6 +125,7 @@ __global__ __launch_bounds__(QR_NT, (MAXT <= 2 ? 4 : 2)) void qr_panel_kernel(Qr
   double* xch = Gs + 256;                   // [2][NW*16 + 16] per-column exchange
   double* taus = xch + 2 * (QR_NW * 16 + 16);  // [16]
   double* Tst = taus + 16;                  // [2][256] staged T_j (parity j & 1)
+  double* Wred2 = Tst + 512;                // [NW][256] second panel's partial W tiles (MAXT <= 6 only)
 
   const long slot = (long)b * gridDim.x + leaf;
   double* Rout = q.Rout + slot * (long)NPAD * NPAD;
@@ -185,7 +186,9 @@ __global__ __launch_bounds__(QR_NT, (MAXT <= 2 ? 4 : 2)) void qr_panel_kernel(Qr
   // factored without touching HBM for V at all.
   // (Small stacks — MAXT <= 4: the latency-bound [R D; E] / Newton systems — keep one
   // panel per pass: their V tiles are L2-resident and the pair costs two extra barriers.)
-  constexpr bool PAIR = MAXT >= 6;
+  constexpr bool PAIR = MAXT >= 4;
+  // a second reduction buffer (one barrier per reflector for BOTH panels) where LDS has room
+  constexpr bool DBUF = PAIR && MAXT <= 6;
   v4d pd[MAXT];                             // the pair's second panel
 #pragma unroll
   for (int i = 0; i < MAXT; ++i) pd[i] = v4d{0.0, 0.0, 0.0, 0.0};
@@ -242,10 +245,12 @@ __global__ __launch_bounds__(QR_NT, (MAXT <= 2 ? 4 : 2)) void qr_panel_kernel(Qr
     }
   };
   // cross-wave sum of the 16x16 partial products, then  -(T^T W)  (fixed order: deterministic)
-  auto reduce_w = [&](const v4d& part, const double* Tl) -> v4d {
+  auto reduce_put = [&](const v4d& part, double* Wb) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) Wred[w * 256 + g * 64 + lane] = part[g];
-    lds_barrier();
+    for (int g = 0; g < 4; ++g) Wb[w * 256 + g * 64 + lane] = part[g];
+  };
+  auto reduce_get = [&](const double* Wb, const double* Tl) -> v4d {
+    const double* Wred = Wb;
     v4d W = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int h = 0; h < QR_NW; h += 2) {      // two partials (8 values) in flight at a time
@@ -269,6 +274,11 @@ __global__ __launch_bounds__(QR_NT, (MAXT <= 2 ? 4 : 2)) void qr_panel_kernel(Qr
 #pragma unroll
     for (int g = 0; g < 4; ++g) W2[g] = -W2[g];
     return W2;
+  };
+  auto reduce_w = [&](const v4d& part, const double* Tl) -> v4d {
+    reduce_put(part, Wred);
+    lds_barrier();
+    return reduce_get(Wred, Tl);
   };
 
   // ---- Cholesky-QR + Householder reconstruction of one panel --------------------------------
@@ -551,11 +561,20 @@ __global__ __launch_bounds__(QR_NT, (MAXT <= 2 ? 4 : 2)) void qr_panel_kernel(Qr
           }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (wave 0: T_j has landed too)
-        const v4d W2 = reduce_w(acc, Tj);
-        v4d W2b = W2;
-        if (PAIR) {
-          lds_barrier();                        // Wred is rewritten for the second panel
-          W2b = reduce_w(acc2, Tj);
+        v4d W2, W2b;
+        if (DBUF) {                             // both panels' partials, ONE barrier
+          reduce_put(acc, Wred);
+          reduce_put(acc2, Wred2);
+          lds_barrier();
+          W2 = reduce_get(Wred, Tj);
+          W2b = reduce_get(Wred2, Tj);
+        } else {
+          W2 = reduce_w(acc, Tj);
+          W2b = W2;
+          if (PAIR) {
+            lds_barrier();                      // Wred is rewritten for the second panel
+            W2b = reduce_w(acc2, Tj);
+          }
         }
         asm volatile("" ::: "memory");
         if (w == 0 && j + 1 < k) glds_tile(T + (j + 1) * 256, Tst + ((j + 1) & 1) * 256, lane16);
@@ -905,7 +924,8 @@ __global__ __launch_bounds__(QR_NT, (MAXT <= 2 ? 4 : 2)) void qr_panel_kernel(Qr
 
 size_t qr_lds_bytes(int LDP, int maxt) {
   const size_t r0 = std::max((size_t)16 * LDP, (size_t)QR_NW * maxt * 256);
-  return sizeof(double) * (r0 + QR_NW * 256 + 256 + 2 * (QR_NW * 16 + 16) + 16 + 512);
+  const size_t second = (maxt >= 4 && maxt <= 6) ? (size_t)QR_NW * 256 : 0;   // Wred2
+  return sizeof(double) * (r0 + QR_NW * 256 + 256 + 2 * (QR_NW * 16 + 16) + 16 + 512 + second);
 }
 
 template <int MAXT, bool ST>
