@@ -104,13 +104,37 @@ __device__ double step_to_bound_dev(const StepCtx& c, const double* xs,
 __device__ void tri_matvec(const double* R, const double* dvec, int n, int ld, const double* svec,
                            double* u) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int i = w; i < n; i += NS_NW) {
-    const double* row = R + (long)i * ld;
-    double acc = 0.0;
-    // (R[i][j] * d[j]) * s[j]: the same roundings as a materialised R_h = R D
-    for (int j = i + lane; j < n; j += WAVE) acc = fma(row[j] * dvec[j], svec[j], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) u[i] = acc;
+  // Four rows per wave pass with unconditional (clamped) loads: R does not fit any cache for a
+  // whole batch, so the loads of a pass must be in flight together — one row at a time every
+  // iteration would pay a full memory round trip.  Per row the accumulation order is unchanged.
+  constexpr int RB = 4;
+  for (int i0 = w; i0 < n; i0 += NS_NW * RB) {
+    double acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = 0.0;
+    for (int jj = 0; i0 + lane + jj < n; jj += WAVE) {       // trip count of the longest row (i0)
+      double rv[RB];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int i = i0 + r * NS_NW;
+        const int ic = (i < n) ? i : n - 1;
+        const int j = ic + lane + jj;
+        rv[r] = R[(long)ic * ld + ((j < n) ? j : n - 1)];
+      }
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int i = i0 + r * NS_NW;
+        const int j = i + lane + jj;
+        // (R[i][j] * d[j]) * s[j]: the same roundings as a materialised R_h = R D
+        if (i < n && j < n) acc[r] = fma(rv[r] * dvec[j], svec[j], acc[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int i = i0 + r * NS_NW;
+      const double t = wave_sum(acc[r]);
+      if (lane == 0 && i < n) u[i] = t;
+    }
   }
   __syncthreads();
 }
