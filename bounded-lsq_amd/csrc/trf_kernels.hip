@@ -29,10 +29,21 @@ __global__ __launch_bounds__(NS_NT) void trf_prep_kernel(TrfState st, int jac_sc
   for (int j = tid; j < n; j += NS_NT) {
     // g_j = sum_{i<=j} R[i][j] c_i ; column norm of R for 'jac' scaling
     double gj = 0.0, nn = 0.0;
-    for (int i = 0; i <= j; ++i) {
-      const double rij = Rt[(long)i * ld + j];
-      gj = fma(rij, Rt[(long)i * ld + n], gj);
-      nn = fma(rij, rij, nn);
+    for (int i0 = 0; i0 <= j; i0 += 8) {      // 8 rows per pass, loads unconditional (clamped)
+      double rv[8], cv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = (i0 + u <= j) ? i0 + u : j;
+        rv[u] = Rt[(long)i * ld + j];
+        cv[u] = Rt[(long)i * ld + n];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (i0 + u <= j) {
+          gj = fma(rv[u], cv[u], gj);
+          nn = fma(rv[u], rv[u], nn);
+        }
+      }
     }
     double sc = st.scale[vo + j];
     if (jac_scaling == 1) {
