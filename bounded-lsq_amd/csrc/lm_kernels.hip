@@ -74,10 +74,25 @@ __global__ __launch_bounds__(TRI_NT) void lm_gate_kernel(LmState lm, int enable)
     const double s0 = 1.0 / sqrt((double)n);
     // s_max <= ||R||_F: an UPPER bound makes the gate more conservative, and costs one pass
     {
+      // one wave per row, lanes across the columns (coalesced), four rows per pass
       double fro = 0.0;
-      for (int i = tid; i < n; i += TRI_NT) {
-        const double* row = R + (long)i * ld;
-        for (int j = i; j < n; ++j) fro = fma(row[j], row[j], fro);
+      const int lane = tid & 63, wv = tid >> 6;
+      for (int i0 = wv; i0 < n; i0 += TRI_NW * 4) {
+        for (int jj = 0; i0 + lane + jj < n; jj += WAVE) {
+          double rv[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = i0 + r * TRI_NW;
+            const int ic = (i < n) ? i : n - 1;
+            const int j = ic + lane + jj;
+            rv[r] = R[(long)ic * ld + ((j < n) ? j : n - 1)];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = i0 + r * TRI_NW;
+            if (i < n && i + lane + jj < n) fro = fma(rv[r], rv[r], fro);
+          }
+        }
       }
       smax = sqrt(block_sum(fro, red));
     }
