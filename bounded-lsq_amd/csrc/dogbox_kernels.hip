@@ -46,10 +46,21 @@ __global__ __launch_bounds__(DG_NT) void dog_prep_kernel(DogState st, int jac_sc
 
   for (int j = tid; j < n; j += DG_NT) {
     double gj = 0.0, nn = 0.0;
-    for (int i = 0; i <= j; ++i) {
-      const double rij = Rt[(long)i * ld + j];
-      gj = fma(rij, Rt[(long)i * ld + n], gj);
-      nn = fma(rij, rij, nn);
+    for (int i0 = 0; i0 <= j; i0 += 8) {      // 8 rows per pass, loads unconditional (clamped)
+      double rv[8], cv[8];
+#pragma unroll
+      for (int u8 = 0; u8 < 8; ++u8) {
+        const int i = (i0 + u8 <= j) ? i0 + u8 : j;
+        rv[u8] = Rt[(long)i * ld + j];
+        cv[u8] = Rt[(long)i * ld + n];
+      }
+#pragma unroll
+      for (int u8 = 0; u8 < 8; ++u8) {
+        if (i0 + u8 <= j) {
+          gj = fma(rv[u8], cv[u8], gj);
+          nn = fma(rv[u8], rv[u8], nn);
+        }
+      }
     }
     double sc = st.scale[vo + j];
     if (jac_scaling == 1) {                                  // dogbox.py:141-144
@@ -127,7 +138,14 @@ __global__ __launch_bounds__(DG_NT) void dog_solve_kernel(DogState st, const int
   __syncthreads();
   for (int q = tid; q < nf; q += DG_NT) {
     double acc = 0.0;
-    for (int i = 0; i < nf; ++i) acc = fma(X[(long)i * ld + q], coef[i], acc);
+    for (int i0 = 0; i0 < nf; i0 += 8) {      // 8 rows per pass, loads in flight together
+      double xv[8];
+#pragma unroll
+      for (int u8 = 0; u8 < 8; ++u8) xv[u8] = X[(long)((i0 + u8 < nf) ? i0 + u8 : nf - 1) * ld + q];
+#pragma unroll
+      for (int u8 = 0; u8 < 8; ++u8)
+        if (i0 + u8 < nf) acc = fma(xv[u8], coef[i0 + u8], acc);
+    }
     st.newton[vo + q] = -acc;
   }
 }

@@ -230,7 +230,14 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     double pn = 0.0;
     for (int j = tid; j < n; j += NS_NT) {
       double acc = 0.0;
-      for (int i = 0; i < n; ++i) acc = fma(X[(long)i * ld + j], coef[i], acc);
+      for (int i0 = 0; i0 < n; i0 += 8) {     // 8 rows per pass, loads in flight together
+        double xv[8];
+#pragma unroll
+        for (int u8 = 0; u8 < 8; ++u8) xv[u8] = X[(long)((i0 + u8 < n) ? i0 + u8 : n - 1) * ld + j];
+#pragma unroll
+        for (int u8 = 0; u8 < 8; ++u8)
+          if (i0 + u8 < n) acc = fma(xv[u8], coef[i0 + u8], acc);
+      }
       ph[j] = -acc;
       pn += acc * acc;
     }
@@ -288,7 +295,14 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     double pn = 0.0;
     for (int j = tid; j < n; j += NS_NT) {
       double acc = 0.0;
-      for (int i = 0; i < n; ++i) acc = fma(X[(long)i * ld + j], coef[i], acc);
+      for (int i0 = 0; i0 < n; i0 += 8) {     // 8 rows per pass, loads in flight together
+        double xv[8];
+#pragma unroll
+        for (int u8 = 0; u8 < 8; ++u8) xv[u8] = X[(long)((i0 + u8 < n) ? i0 + u8 : n - 1) * ld + j];
+#pragma unroll
+        for (int u8 = 0; u8 < 8; ++u8)
+          if (i0 + u8 < n) acc = fma(xv[u8], coef[i0 + u8], acc);
+      }
       ph[j] = -acc;
       pn += acc * acc;
     }
