@@ -12,12 +12,33 @@ static constexpr int TRI_NW = TRI_NT / WAVE;
 // u = R s   (one wave per row, lanes stride the columns)
 __device__ __forceinline__ void tri_mv(const double* R, int n, int ld, const double* s, double* u) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int i = w; i < n; i += TRI_NW) {
-    const double* row = R + (long)i * ld;
-    double acc = 0.0;
-    for (int j = i + lane; j < n; j += WAVE) acc = fma(row[j], s[j], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) u[i] = acc;
+  constexpr int RB = 4;                     // rows per wave pass: their loads fly together
+  for (int i0 = w; i0 < n; i0 += TRI_NW * RB) {
+    double acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = 0.0;
+    for (int jj = 0; i0 + lane + jj < n; jj += WAVE) {
+      double rv[RB];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int i = i0 + r * TRI_NW;
+        const int ic = (i < n) ? i : n - 1;
+        const int j = ic + lane + jj;
+        rv[r] = R[(long)ic * ld + ((j < n) ? j : n - 1)];
+      }
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int i = i0 + r * TRI_NW;
+        const int j = i + lane + jj;
+        if (i < n && j < n) acc[r] = fma(rv[r], s[j], acc[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int i = i0 + r * TRI_NW;
+      const double t = wave_sum(acc[r]);
+      if (lane == 0 && i < n) u[i] = t;
+    }
   }
   __syncthreads();
 }
