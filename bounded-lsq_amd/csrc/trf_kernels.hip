@@ -115,10 +115,10 @@ __device__ double step_to_bound_dev(const StepCtx& c, const double* xs,
 __device__ void tri_matvec(const double* R, const double* dvec, int n, int ld, const double* svec,
                            double* u) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  // Four rows per wave pass with unconditional (clamped) loads: R does not fit any cache for a
+  // Eight rows per wave pass with unconditional (clamped) loads: R does not fit any cache for a
   // whole batch, so the loads of a pass must be in flight together — one row at a time every
   // iteration would pay a full memory round trip.  Per row the accumulation order is unchanged.
-  constexpr int RB = 4;
+  constexpr int RB = 8;
   for (int i0 = w; i0 < n; i0 += NS_NW * RB) {
     double acc[RB];
 #pragma unroll
