@@ -392,7 +392,7 @@ int trf_alloc_state(blsq_trf_plan* p) {
   p->out.info = p->o_info.as<int>();
   ALLOC(p->lm_sa, sizeof(double) * (size_t)B);
   ALLOC(p->lm_Xa, sizeof(double) * B * mat);
-  ALLOC(p->lm_ints, sizeof(int) * ((size_t)B * 7 + 4));
+  ALLOC(p->lm_ints, sizeof(int) * ((size_t)B * 9 + 4));
   ALLOC(p->lm_sc, sizeof(double) * (size_t)B * 16);
   ALLOC(p->lm_ph, sizeof(double) * vs);
   HIPCHK(ctx, hipMemsetAsync(p->lm_sa.p, 0, p->lm_sa.bytes, ctx->stream));
@@ -404,6 +404,7 @@ int trf_alloc_state(blsq_trf_plan* p) {
     int* ii = p->lm_ints.as<int>();
     lm.fast = ii; lm.ncols_jac = ii + B; lm.ncols_lm = ii + 2 * (size_t)B; lm.st = ii + 3 * (size_t)B;
     lm.active_count = ii + 7 * (size_t)B;
+    lm.active_list = ii + 7 * (size_t)B + 4; lm.round = 0;
     lm.sc = p->lm_sc.as<double>(); lm.ph = p->lm_ph.as<double>();
     // The SVD-free Newton iteration costs one small stacked QR per iteration.  Measured
     // (8192..16384 problems per launch, Delta mix 10/0.5; SVD-free vs Jacobi-SVD step-solves/s):
@@ -486,15 +487,17 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
     q.rowsA = aug_block_rows(p->n) + p->n;
     q.vdiag_row0 = aug_block_rows(p->n); q.vdiag = p->lm.sa;
     q.F = nullptr; q.strideF = 0; q.ncols_dev = p->lm.ncols_lm;
+    q.batch_list = p->lm.active_list + (size_t)(round & 1) * p->B;   // only the active problems
     q.rows_per_leaf = p->aug_RP; q.RP = p->aug_RP; q.LDP = p->aug_LDP;
     q.Rout = p->lm.Xa;
     q.stack_rows = aug_block_rows(p->n);
     ctx->begin(K_LM_QR);
-    e = launch_qr(q, 1, p->B, ctx->stream);
+    e = launch_qr(q, 1, active, ctx->stream);
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_qr(lm)");
     ctx->begin(K_LM_SOLVE);
-    e = launch_lm_update(p->lm, ctx->stream);
+    p->lm.round = round;
+    e = launch_lm_update(p->lm, active, ctx->stream);
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_lm_update");
     HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, p->lm.active_count, sizeof(int), hipMemcpyDeviceToHost,

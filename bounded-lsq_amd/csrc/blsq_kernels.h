@@ -15,6 +15,7 @@ struct QrArgs {
   const double* F;        // optional extra (last) column, problem b at F + b*strideF
   long strideF;
   const int* ncols_dev;   // optional per-problem N; nullptr -> N
+  const int* batch_list;  // optional compacted problem indices: workgroup y factors problem batch_list[y]
   int N;                  // columns to factor (incl. the rhs column if any)
   int rows_per_leaf;      // source rows per leaf (workgroup)
   int RP;                 // padded leaf rows (multiple of 16, >= NPAD)
@@ -111,11 +112,13 @@ struct LmState {
   int* st;                // [B][4]  it, phase, n_iter
   double* ph;             // [B][ld] p_h of the SVD-free path
   int* active_count;      // [1] problems that need another evaluation
+  int* active_list;       // [2][B] their indices, compacted (list r & 1 feeds evaluation r)
+  int round;              // evaluation number of this launch (host-set)
 };
 hipError_t launch_lm_gate(const LmState& lm, int enable, hipStream_t s);
 hipError_t launch_lm_start(const LmState& lm, const double* Delta, const double* alpha_in,
                            hipStream_t s);
-hipError_t launch_lm_update(const LmState& lm, hipStream_t s);
+hipError_t launch_lm_update(const LmState& lm, int active, hipStream_t s);   // grid = active problems of lm.round
 
 // -------------------------------------------------------------- dogbox ----
 struct DogState {

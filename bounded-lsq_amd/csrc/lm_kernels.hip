@@ -188,7 +188,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_start_kernel(LmState lm, const doub
     sc[SC_DELTA] = Delta;
     st[ST_IT] = 0; st[ST_PHASE] = LM_EVAL; st[ST_NITER] = 0;
     lm.sa[b] = sqrt(alpha); lm.ncols_lm[b] = n + 1;
-    atomicAdd(lm.active_count, 1);
+    lm.active_list[atomicAdd(lm.active_count, 1)] = b;          // list 0 feeds evaluation 0
   }
 }
 
@@ -205,7 +205,8 @@ hipError_t launch_lm_start(const LmState& lm, const double* Delta, const double*
 __global__ __launch_bounds__(TRI_NT) void lm_update_kernel(LmState lm) {
   extern __shared__ double sh[];
   __shared__ double red[32];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  // launched over the compacted list of evaluation lm.round; writes the next one
+  const int b = lm.active_list[(long)(lm.round & 1) * lm.B + blockIdx.x], tid = threadIdx.x;
   if (!lm.fast[b]) return;
   int* st = lm.st + (long)b * 4;
   const int phase = st[ST_PHASE];
@@ -272,14 +273,15 @@ __global__ __launch_bounds__(TRI_NT) void lm_update_kernel(LmState lm) {
     st[ST_IT] = it; st[ST_PHASE] = next_phase; st[ST_NITER] = n_iter;
     lm.sa[b] = sqrt(alpha);
     lm.ncols_lm[b] = (next_phase != LM_IDLE) ? n + 1 : 0;
-    if (next_phase != LM_IDLE) atomicAdd(lm.active_count, 1);
+    if (next_phase != LM_IDLE)
+      lm.active_list[(long)((lm.round + 1) & 1) * lm.B + atomicAdd(lm.active_count, 1)] = b;
   }
 }
 
-hipError_t launch_lm_update(const LmState& lm, hipStream_t s) {
+hipError_t launch_lm_update(const LmState& lm, int active, hipStream_t s) {
   const size_t lds = sizeof(double) * (3 + 32) * (size_t)lm.ld;
   { static std::atomic<size_t> granted[64]; hipError_t ge = grant_lds(lm_update_kernel, lds, granted); if (ge != hipSuccess) return ge; }
-  hipLaunchKernelGGL(lm_update_kernel, dim3(lm.B), dim3(TRI_NT), lds, s, lm);
+  hipLaunchKernelGGL(lm_update_kernel, dim3(active), dim3(TRI_NT), lds, s, lm);
   return hipGetLastError();
 }
 

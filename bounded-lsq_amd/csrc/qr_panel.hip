@@ -107,7 +107,10 @@ __global__ __launch_bounds__(QR_NT, (MAXT <= 2 ? 4 : 2)) void qr_panel_kernel(Qr
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id, in an SGPR
   const int leaf = blockIdx.x;
-  const int b = blockIdx.y;
+  // Masked launches over a sparse set of problems go through a compacted index list: a grid
+  // whose active workgroups alternate with idle ones lands them on half of the XCDs only
+  // (workgroups are dealt round-robin to the 8 XCDs).
+  const int b = q.batch_list ? q.batch_list[blockIdx.y] : (int)blockIdx.y;
   const int N = q.ncols_dev ? q.ncols_dev[b] : q.N;       // columns to factor
   const int RP = q.RP;
   const int LDP = q.LDP;

@@ -7,7 +7,10 @@ sys.path.insert(0, os.path.join(ROOT, "bounded-lsq_amd")); sys.path.insert(0, RO
 from bounded_lsq import TrfStepSolver, DogboxStepSolver, _abi, _synth
 
 ctx = _abi.Context(0)
-for kind, B, m, n in (("trf", 8192, 512, 64), ("dogbox", 8192, 512, 64), ("trf", 1024, 2048, 128)):
+SHAPES = [("trf", 8192, 512, 64), ("dogbox", 8192, 512, 64), ("trf", 1024, 2048, 128)]
+if len(sys.argv) > 1:                      # kind:B:m:n ...
+    SHAPES = [(a.split(":")[0],) + tuple(int(v) for v in a.split(":")[1:]) for a in sys.argv[1:]]
+for kind, B, m, n in SHAPES:
     P = _synth.dogbox_batch(5, B, m, n) if kind == "dogbox" else _synth.trf_batch(5, B, m, n)
     d = {k: ctx.to_device(P[k]) for k in P}
     if kind == "trf":
@@ -20,15 +23,19 @@ for kind, B, m, n in (("trf", 8192, 512, 64), ("dogbox", 8192, 512, 64), ("trf",
         dD = ctx.to_device(np.full(B, 0.02))
         def step():
             sol.factor_dev(d["J"], d["f"], d["x"], d["lb"], d["ub"], d["scale"], d["on_bound"]); sol.step_dev(dD)
+    ctx.cqr_stats(reset=True)
     step(); ctx.sync()
+    print("   panels (Cholesky-QR fast path, Householder column loop) in one step-solve batch:", ctx.cqr_stats())
     ctx.timing(True); ctx.timing_reset()
     t0 = time.perf_counter()
     K = 5
     for _ in range(K): step()
     ctx.sync(); el = time.perf_counter() - t0
     tm = ctx.timing_read(); ctx.timing(False)
-    print("%-6s B=%d %dx%d: %.0f step-solves/s  (%.2f ms/step)  kernels ms/step: %s" % (
-        kind, B, m, n, B * K / el, 1e3 * el / K,
+    gbs = B * m * (n + 1) * 8 * K / el / 1e9
+    tfs = B * (2.0 * m * n * n - 2.0 * n ** 3 / 3) * K / el / 1e12
+    print("%-6s B=%d %dx%d: %.0f step-solves/s  (%.2f ms/step; J read at %.0f GB/s, QR %.1f TF/s)  kernels ms/step: %s" % (
+        kind, B, m, n, B * K / el, 1e3 * el / K, gbs, tfs,
         {k: round(v[0] / K, 3) for k, v in tm.items() if v[1]}))
     sol.close()
     for p in d.values(): ctx.free(p)
