@@ -40,6 +40,15 @@ def alg_flops_trf(m, n):    # R-SVD count + GEMV terms
     return 2 * (m + n) * n * n + 11 * n ** 3 + 6 * (m + n) * n
 
 
+def leaf_flops_trf(m, n, rows_per_leaf=1024):
+    """Flops of the dominant kernel's OWN work: Householder QR of the [J f] row blocks
+    (2 r N^2 - 2/3 N^3 per r x N leaf, N = n + 1), nothing else of the step-solve."""
+    N = n + 1
+    nleaf = max(1, -(-m // rows_per_leaf))
+    r = -(-m // nleaf)
+    return nleaf * (2.0 * r * N * N - 2.0 * N ** 3 / 3.0)
+
+
 def measured_traffic(kernel, m, n, B):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary
     (profiles/hbm_traffic_latest.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes,
@@ -160,7 +169,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="problems per GPU")
+    ap.add_argument("--batch", type=int, default=512,
+                    help="problems per GPU (512: two waves of 256 CUs; the n-space kernels run one workgroup per problem)")
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -281,6 +291,11 @@ def main():
                 "traffic": measured_traffic(dom, m, n, B),
                 "kernel": dom, "kernel_ms_per_step": per_step_ms[dom],
                 "alg_flops_per_solve": alg_flops_trf(m, n),
+                # the same launch priced with the leaf kernel's own flops only (stricter figure)
+                "kernel_own_flops_per_solve": leaf_flops_trf(m, n) if dom == "qr_leaf" else None,
+                "kernel_own_frac": (leaf_flops_trf(m, n) * B / (dom_avg_ms * dom_launches_per_step
+                                                                * 1e-3) / 1e12 / PEAK_FP64_TFLOPS)
+                if dom == "qr_leaf" else None,
                 "alg_bytes_per_solve": alg_bytes_trf(m, n),
                 "whole_step_tflops": flops / (ms_per_step * 1e-3) / 1e12 * 1.0,
                 "whole_step_hbm_gbs": byts / (ms_per_step * 1e-3) / 1e9,
