@@ -390,12 +390,14 @@ __global__ __launch_bounds__(QR_NT, (MAXT <= 2 ? 4 : 2)) void qr_panel_kernel(Qr
           pi = pi * fma(-piv, pi, 2.0);
           sgv = (j == kk) ? sk : sgv;
           pnv = (j == kk) ? pi : pnv;
+          // columns right of kk take the update; column kk keeps its raw entries (scaled by its
+          // own 1 / pivot after the loop), columns left of it already hold Y_1
+          const double ukp = (j > kk) ? ac[kk] * pi : 0.0;
 #pragma unroll
-          for (int i = kk + 1; i < TILE; ++i) {
-            const double lik = read_lane(ac[i], kk) * pi;
-            ac[i] = (j == kk) ? lik : ((j > kk) ? fma(-lik, ac[kk], ac[i]) : ac[i]);
-          }
+          for (int i = kk + 1; i < TILE; ++i) ac[i] = fma(-read_lane(ac[i], kk), ukp, ac[i]);
         }
+#pragma unroll
+        for (int i = 1; i < TILE; ++i) ac[i] = (i > j) ? ac[i] * pnv : ac[i];
         if (w == 0) {
           // pivot tile of the panel: R_hh = S R on and above the diagonal, Y_1 below it
           // (first: M below reuses the scratch that holds R)
