@@ -59,6 +59,7 @@ SIGNATURES = {
     "blsq_tsqr_local_dev": (C.c_int, [vp, vp, vp, vp]),
     "blsq_tsqr_combine_dev": (C.c_int, [vp] + [vp] * 5 + [C.c_int]),
     "blsq_debug_cqr_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
+    "blsq_debug_gram_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
     "blsq_outer_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "blsq_outer_destroy": (C.c_int, [vp]),
     "blsq_outer_buffers": (C.c_int, [vp] + [C.POINTER(vp)] * 6),
@@ -168,6 +169,12 @@ class Context:
         """-> (panels on the Cholesky-QR fast path, panels on the Householder column loop)."""
         out = (C.c_uint64 * 2)()
         self.check(self.lib.blsq_debug_cqr_stats(self.h, out, 1 if reset else 0), "cqr_stats")
+        return int(out[0]), int(out[1])
+
+    def gram_stats(self, reset=False):
+        """-> (problems factored by the normal-equations fast path, problems handed to the QR tree)."""
+        out = (C.c_uint64 * 2)()
+        self.check(self.lib.blsq_debug_gram_stats(self.h, out, 1 if reset else 0), "gram_stats")
         return int(out[0]), int(out[1])
 
     # ---- timing ------------------------------------------------------------

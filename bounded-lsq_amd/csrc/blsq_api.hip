@@ -20,9 +20,9 @@ namespace {
 constexpr int RMAX = QR_MAX_TILES * 16;   // rows a workgroup can stage (qr_panel.hip): 1024
 
 enum Slot { K_QR_LEAF = 0, K_QR_MERGE, K_PREP, K_QR_AUG, K_JACOBI, K_STEP, K_LM_GATE, K_LM_QR, K_LM_SOLVE,
-            K_NSLOT };
+            K_GRAM, K_GRAM_CHOL, K_GRAM_GATE, K_NSLOT };
 const char* kSlotNames[K_NSLOT] = {"qr_leaf", "qr_merge", "prep", "qr_aug", "jacobi_svd", "step",
-                                   "lm_gate", "lm_qr", "lm_solve"};
+                                   "lm_gate", "lm_qr", "lm_solve", "gram", "gram_chol", "gram_gate"};
 
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
 // rows of the stacked systems [R D; E] / [R_aug; sqrt(alpha) I]: two blocks of
@@ -47,6 +47,7 @@ struct blsq_ctx {
   std::vector<Pending> pending;
   std::vector<hipEvent_t> pool;
   int* pinned = nullptr;            // 4 pinned host ints: device -> host counters without staging
+  long long gram_fast = 0, gram_fallback = 0;   // problems factored by the normal equations / handed to the QR tree
 
   int fail(hipError_t e, const char* where) {
     err = std::string(where) + ": " + hipGetErrorString(e);
@@ -116,6 +117,10 @@ struct QrTree {
   int B = 0, m = 0, n = 0, N = 0, NPAD = 0, NP = 0;
   std::vector<Level> levels;        // levels.back().nleaf == 1
   DevBuf V, T;                      // scratch shared by all QR launches of the plan
+  // normal-equations fast path (gram_kernels.hip); problems that fail its gate use the levels
+  bool gram = false;
+  int gram_nchunk = 1;
+  DevBuf gram_part, gram_dsc, gram_ints;   // partial Grams, column scales, [B] fallback mask + count
 
   // rows: source rows per problem at level 0
   int build(blsq_ctx* ctx, int B_, int rows, int n_, size_t extra_rp_rows) {
@@ -158,11 +163,62 @@ struct QrTree {
     if (e != hipSuccess) return ctx->fail(e, "hipMalloc(V scratch)");
     e = T.alloc(sizeof(double) * max_slots * NP * 256);
     if (e != hipSuccess) return ctx->fail(e, "hipMalloc(T scratch)");
+    {
+      const char* env = getenv("BLSQ_GRAM");
+      gram = gram_supported(rows, n) && !(env && env[0] == '0');
+    }
+    if (gram) {
+      gram_nchunk = gram_chunks(B, rows);
+      if (gram_nchunk > 1) {
+        e = gram_part.alloc(sizeof(double) * (size_t)B * gram_nchunk * NPAD * NPAD);
+        if (e != hipSuccess) return ctx->fail(e, "hipMalloc(partial Grams)");
+      }
+      e = gram_dsc.alloc(sizeof(double) * (size_t)B * NPAD);
+      if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Gram scales)");
+      e = gram_ints.alloc(sizeof(int) * ((size_t)B + 4));
+      if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Gram mask)");
+    }
     return 0;
   }
   void release() {
     for (auto& L : levels) L.R.release();
     V.release(); T.release();
+    gram_part.release(); gram_dsc.release(); gram_ints.release();
+  }
+  // [J f] -> triangle by the normal equations where the conditioning gate allows it.
+  // Returns the number of problems left for the Householder tree in *nfallback; their indices
+  // are flagged in the fallback mask (n + 1 / 0 per problem).
+  int run_gram(blsq_ctx* ctx, const double* dJ, const double* df, int ldJ, const int* mask,
+               int* nfallback) {
+    int* fb = gram_ints.as<int>();
+    int* cnt = fb + B;
+    HIPCHK(ctx, hipMemsetAsync(cnt, 0, sizeof(int), ctx->stream));
+    double* Rf = levels.back().R.as<double>();
+    GramArgs g{};
+    g.J = dJ; g.strideJ = (long)m * ldJ; g.ldJ = ldJ; g.F = df; g.strideF = m;
+    g.m = m; g.n = n; g.NPAD = NPAD; g.mask = mask;
+    g.G = gram_nchunk > 1 ? gram_part.as<double>() : Rf;
+    ctx->begin(K_GRAM);
+    hipError_t e = launch_gram(g, gram_nchunk, B, ctx->stream);
+    if (e == hipSuccess && gram_nchunk > 1)
+      e = launch_gram_reduce(gram_part.as<double>(), gram_nchunk, NPAD, Rf, mask, B, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_gram");
+    GramCholArgs c{};
+    c.G = Rf; c.NPAD = NPAD; c.n = n; c.mask = mask; c.fb_mask = fb; c.fail_count = cnt;
+    c.dsc = gram_dsc.as<double>();
+    ctx->begin(K_GRAM_CHOL);
+    e = launch_gram_chol(c, B, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol");
+    ctx->begin(K_GRAM_GATE);
+    e = launch_gram_gate(c, B, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_gram_gate");
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 1, cnt, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *nfallback = ctx->pinned[1];
+    return 0;
   }
   const double* Rfinal() const { return levels.back().R.as<double>(); }
 
@@ -177,6 +233,15 @@ struct QrTree {
   // triangles of the previous run stay in place (outer driver: only fresh Jacobians are factored)
   int run(blsq_ctx* ctx, const double* dJ, const double* df, int ldJ,
           const int* ncols_mask = nullptr) {
+    if (gram && df != nullptr) {
+      int nfb = 0;
+      int rc = run_gram(ctx, dJ, df, ldJ, ncols_mask, &nfb);
+      if (rc) return rc;
+      ctx->gram_fallback += nfb;
+      ctx->gram_fast += B - nfb;            // (masked problems count as fast: diagnostics only)
+      if (nfb == 0) return 0;
+      ncols_mask = gram_ints.as<int>();     // only the problems the gate rejected
+    }
     for (size_t l = 0; l < levels.size(); ++l) {
       const Level& L = levels[l];
       QrArgs q = base_args();
@@ -1372,6 +1437,15 @@ extern "C" int blsq_fd_assemble_dev(blsq_ctx* ctx, int B, int m, int n, int meth
   hipError_t e = launch_fd_assemble(B, m, n, method, dx, dh, done_sided, df0, dF, dJ, dmask,
                                     ctx->stream);
   if (e != hipSuccess) return ctx->fail(e, "launch_fd_assemble");
+  return 0;
+}
+
+extern "C" int blsq_debug_gram_stats(blsq_ctx* ctx, uint64_t* out2, int reset) {
+  if (!ctx) return -1;
+  if (!out2) return ctx->bad(2, "out is NULL");
+  out2[0] = (uint64_t)ctx->gram_fast;
+  out2[1] = (uint64_t)ctx->gram_fallback;
+  if (reset) { ctx->gram_fast = 0; ctx->gram_fallback = 0; }
   return 0;
 }
 

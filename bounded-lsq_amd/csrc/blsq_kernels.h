@@ -49,6 +49,35 @@ void set_qr_debug_buffer(double* p);
 // panels factored by the Cholesky-QR fast path [0] / the Householder column loop [1] so far
 hipError_t qr_cqr_stats(unsigned long long out[2], int reset, hipStream_t st);
 
+// ------------------------------------------------- normal-equations fast path ----
+// gram_kernels.hip: G = [J f]^T [J f] by MFMA, equilibrated blocked Cholesky in place in the
+// triangle slot, conditioning gate; problems that fail it get fb_mask[b] = n + 1 and are
+// factored by the Householder tree instead.
+struct GramArgs {
+  const double* J; long strideJ; int ldJ;
+  const double* F; long strideF;
+  int m, n;               // rows / columns of J
+  int NPAD;               // row stride (and row count) of each G slot
+  double* G;              // [B][chunks][NPAD*NPAD] upper tile blocks
+  const int* mask;        // optional: problems with mask[b] <= 1 are skipped
+  int rows_per_chunk;     // set by launch_gram
+};
+struct GramCholArgs {
+  double* G;              // [B][NPAD*NPAD] in: Gram, out: [R | Q^T f] (upper), zeros elsewhere
+  int NPAD, n;
+  const int* mask;        // optional, as above
+  int* fb_mask;           // [B] out: n + 1 if the problem needs the Householder tree, else 0
+  int* fail_count;        // [1] number of such problems (caller zeroes it)
+  double* dsc;            // [B][NPAD] out: column scales 1 / ||J_j||
+};
+bool gram_supported(int m, int n);
+int gram_chunks(int B, int m);
+hipError_t launch_gram(const GramArgs& a, int chunks, int B, hipStream_t s);
+hipError_t launch_gram_reduce(const double* Gpart, int chunks, int NPAD, double* Gout,
+                              const int* mask, int B, hipStream_t s);
+hipError_t launch_gram_chol(const GramCholArgs& a, int B, hipStream_t s);
+hipError_t launch_gram_gate(const GramCholArgs& a, int B, hipStream_t s);
+
 // ------------------------------------------------------------- Jacobi -----
 // One-sided Jacobi on the ROWS of the n x (n+1) array [R | c] (row stride ld):
 // U^T [R | c] = [S V^T | U^T c].  In place.

@@ -1,0 +1,420 @@
+// Normal-equations fast path of the Jacobian factorisation (north_star: "MFMA ... for the
+// tall-skinny J^T J"; reference call sites: trf.py:244-252 / dogbox.py:197 need R and Q^T f of
+// [J f] only through R^T R and R^T (Q^T f)).
+//
+//   G = [J f]^T [J f]            one streaming pass over J, FP64 MFMA, upper tile blocks only
+//   C = D G D,  D = diag(1/||J_j||)                    (unit diagonal: column equilibration)
+//   C = R'^T R'                  blocked Cholesky, 16x16 tiles, MFMA Schur updates
+//   [R z; 0 rho] = R' D^-1       the same triangle the Householder TSQR tree produces (up to row
+//                                signs, which nothing downstream depends on)
+//
+// Half the flops of Householder QR, no reflector traffic, no per-panel latency chain — but the
+// error of R grows with kappa(J D)^2 instead of kappa(J D).  The path is therefore GATED per
+// problem: every Cholesky pivot of the equilibrated Gram and an inverse-power estimate of
+// sigma_min(R') must clear GRAM_SMIN (kappa(J D) <= sqrt(n) / GRAM_SMIN), otherwise the problem is
+// handed to the Householder tree (QrTree::run) through a launch mask, exactly as before.
+// Non-finite input, zero columns, rank deficiency and m < n all fail the gate by construction.
+#include <atomic>
+
+#include "blsq_device.h"
+#include "blsq_kernels.h"
+#include "tri_ops.h"
+
+namespace blsq {
+
+static constexpr int GR_NT = 512;
+static constexpr int GR_NW = GR_NT / WAVE;
+static constexpr int GR_RC = 32;          // rows per staged chunk (8 MFMA k-steps)
+static constexpr double GRAM_SMIN = 0.2;  // lower limit for the pivots / sigma_min estimate of R'
+
+template <class K>
+static hipError_t gram_grant_lds(K kernel, size_t bytes, std::atomic<size_t>* granted_dev) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::atomic<size_t>& granted = granted_dev[dev & 63];
+  if (bytes <= granted.load(std::memory_order_acquire)) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)bytes);
+  if (e == hipSuccess) granted.store(bytes, std::memory_order_release);
+  return e;
+}
+
+__device__ __forceinline__ v4d gmfma(double a, double b, v4d c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+__host__ __device__ inline int gram_ldx(int NT) { return NT * 16 + ((NT & 1) ? 0 : 16); }
+
+// ---- G = [J f]^T [J f] ---------------------------------------------------------------------
+// One workgroup per (row chunk, problem).  The chunk streams through LDS 32 rows at a time
+// (double-buffered, next rows prefetched into registers during the MFMA burst); the NT (NT+1)/2
+// upper 16x16 output tiles are dealt to the 8 waves in contiguous runs of the row-major tile
+// order and stay in accumulators for the whole pass.  Both MFMA operands of tile (i, j) are the
+// same fragment pattern X[4 s + lr][16 c + lc] (c = i for A, c = j for B), read from LDS; the LDS
+// row stride is an odd multiple of 16 doubles so the two rows a half-wave reads hit disjoint banks.
+template <int SLOTS>
+__global__ __launch_bounds__(GR_NT, (SLOTS <= 4 ? 4 : 2)) void gram_kernel(GramArgs a) {
+  extern __shared__ double lds[];
+  const int b = blockIdx.y;
+  if (a.mask && a.mask[b] <= 1) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane >> 4, lc = lane & 15;
+  const int n = a.n, N = n + 1, NT = (N + 15) / 16;
+  const int LDX = gram_ldx(NT);
+  const int ntile = NT * (NT + 1) / 2;
+  const int per = (ntile + GR_NW - 1) / GR_NW;
+  // rows of this chunk
+  const int r_lo = blockIdx.x * a.rows_per_chunk;
+  int r_hi = r_lo + a.rows_per_chunk;
+  if (r_hi > a.m) r_hi = a.m;
+  const int m = r_hi;                                   // exclusive row limit
+  const double* Jb = a.J + (long)b * a.strideJ;
+  const double* Fb = a.F + (long)b * a.strideF;
+
+  // tile table (wave-uniform): slot t -> (ti, tj); idle slots recompute tile (0, 0) and are
+  // not stored (no branch inside the MFMA loop)
+  int ti[SLOTS], tj[SLOTS];
+  bool tv[SLOTS];
+  {
+    int i = 0, rem = w * per;
+    while (i < NT && rem >= NT - i) { rem -= NT - i; ++i; }
+    int j = i + rem;
+#pragma unroll
+    for (int t = 0; t < SLOTS; ++t) {
+      const bool valid = (t < per) && (i < NT);
+      tv[t] = valid;
+      ti[t] = valid ? 16 * i : 0;
+      tj[t] = valid ? 16 * j : 0;
+      ++j;
+      if (j >= NT) { ++i; j = i; }
+    }
+  }
+
+  constexpr int RR = GR_RC / GR_NW;                     // rows per wave per chunk
+  constexpr int NCB = 5;                                // 64-column blocks (LDX <= 320)
+  double pre[RR][NCB], fpre[RR];
+  auto issue = [&](int row0) {
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) {
+      const int row = row0 + w + GR_NW * rr;
+      const int rc = row < m ? row : m - 1;
+      fpre[rr] = Fb[rc];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int col = lane + 64 * cb;
+        const int cc = col < n ? col : n - 1;
+        pre[rr][cb] = (64 * cb < n) ? __builtin_nontemporal_load(Jb + (long)rc * a.ldJ + cc) : 0.0;
+      }
+    }
+  };
+  auto commit = [&](int row0, double* X) {
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) {
+      const int row = row0 + w + GR_NW * rr;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int col = lane + 64 * cb;
+        double val = 0.0;
+        if (row < m) val = (col < n) ? pre[rr][cb] : ((col == n) ? fpre[rr] : 0.0);
+        if (col < LDX) X[(w + GR_NW * rr) * LDX + col] = val;
+      }
+    }
+  };
+
+  v4d acc[SLOTS];
+#pragma unroll
+  for (int t = 0; t < SLOTS; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+
+  double* X0 = lds;
+  double* X1 = lds + GR_RC * LDX;
+  if (r_lo < m) {
+    issue(r_lo);
+    commit(r_lo, X0);
+  }
+  __syncthreads();
+  int cidx = 0;
+  for (int row0 = r_lo; row0 < m; row0 += GR_RC, ++cidx) {
+    const bool more = row0 + GR_RC < m;
+    if (more) issue(row0 + GR_RC);
+    const double* X = (cidx & 1) ? X1 : X0;
+#pragma unroll
+    for (int s = 0; s < GR_RC / 4; ++s) {
+      const double* xr = X + (4 * s + lr) * LDX + lc;
+#pragma unroll
+      for (int t = 0; t < SLOTS; ++t) acc[t] = gmfma(xr[ti[t]], xr[tj[t]], acc[t]);
+    }
+    if (more) commit(row0 + GR_RC, (cidx & 1) ? X0 : X1);
+    __syncthreads();
+  }
+
+  double* G = a.G + ((long)b * gridDim.x + blockIdx.x) * (long)a.NPAD * a.NPAD;
+#pragma unroll
+  for (int t = 0; t < SLOTS; ++t) {
+    if (tv[t]) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        G[(long)(ti[t] + lr + 4 * g) * a.NPAD + tj[t] + lc] = acc[t][g];
+    }
+  }
+}
+
+// partial Grams of the row chunks -> the triangle slot (fixed order: deterministic)
+__global__ void gram_reduce_kernel(const double* Gpart, int chunks, int NPAD, double* Gout,
+                                   const int* mask) {
+  const int b = blockIdx.y;
+  if (mask && mask[b] <= 1) return;
+  const long sz = (long)NPAD * NPAD;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= sz) return;
+  const int r = (int)(idx / NPAD), c = (int)(idx % NPAD);
+  if ((r >> 4) > (c >> 4)) return;                      // lower tiles are never written
+  const double* src = Gpart + (long)b * chunks * sz + idx;
+  double s = 0.0;
+  for (int k = 0; k < chunks; ++k) s += src[(long)k * sz];
+  Gout[(long)b * sz + idx] = s;
+}
+
+// ---- equilibrated blocked Cholesky, in place in the triangle slot -------------------------------
+// Row block kb of R' :  S_j = C_{kb,j} - sum_{k<kb} R'_{k,kb}^T R'_{k,j}   (MFMA, operands from the
+// rows already written),  R'_{kb,kb} = chol(S_kb) and its inverse on wave 0 (lane j owns column
+// j, broadcasts by v_readlane),  R'_{kb,j} = R'_{kb,kb}^-T S_j  (MFMA; the accumulator layout of S is
+// the B-operand layout).  What is stored is R = R' D^-1; operands are re-scaled on the fly.
+__global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
+  extern __shared__ double sh[];
+  __shared__ double red[32];
+  __shared__ double pminsh;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane >> 4, lc = lane & 15;
+  const int n = a.n, N = n + 1, NPAD = a.NPAD, NT = NPAD / 16;
+  if (a.mask && a.mask[b] <= 1) {
+    if (tid == 0) a.fb_mask[b] = 0;
+    return;
+  }
+  double* Gb = a.G + (long)b * NPAD * NPAD;
+  double* dl = sh;                 // [NPAD] 1 / ||J_j||
+  double* sq = dl + NPAD;          // [NPAD] ||J_j||
+  double* Dt = sq + NPAD;          // [256]  diagonal tile (row-major)
+  double* Ri = Dt + 256;           // [256]  its inverse
+  // 0. column scales from the diagonal
+  int bad = 0;
+  for (int j = tid; j < NPAD; j += GR_NT) {
+    const double g = Gb[(long)j * NPAD + j];
+    const bool okc = (g > 0.0) && is_finite(g);
+    if (j < n && !okc) bad = 1;
+    double d = 1.0, s = 1.0;
+    if (j < N && okc) {
+      d = __builtin_amdgcn_rsq(g);
+      d = d * fma(-0.5 * g * d, d, 1.5);
+      d = d * fma(-0.5 * g * d, d, 1.5);
+      s = g * d;
+    }
+    dl[j] = d; sq[j] = s;
+    a.dsc[(long)b * NPAD + j] = d;
+  }
+  // strictly lower tiles are part of the triangle's image: zero
+  for (int r = 16 + w; r < NPAD; r += GR_NW) {
+    const int cend = r & ~15;
+    for (int c = lane; c < cend; c += WAVE) Gb[(long)r * NPAD + c] = 0.0;
+  }
+  bad = block_or(bad, red);
+  if (tid == 0) pminsh = 1.0;
+  __syncthreads();
+  if (bad) {                                            // uniform: hand the problem to the QR tree
+    if (tid == 0) { a.fb_mask[b] = N; atomicAdd(a.fail_count, 1); }
+    return;
+  }
+
+  for (int kb = 0; kb < NT; ++kb) {
+    // ---- A. Schur complements of this row block (tile j = kb + w + 8 u) ----
+    v4d S[3];
+    const double dk = dl[16 * kb + lc];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int j = kb + w + GR_NW * u;
+      S[u] = v4d{0.0, 0.0, 0.0, 0.0};
+      if (j < NT) {
+        const double dj = dl[16 * j + lc];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * kb + lr + 4 * g;
+          S[u][g] = Gb[(long)row * NPAD + 16 * j + lc] * dl[row] * dj;
+        }
+        for (int k = 0; k < kb; ++k) {
+          double av[4], bv[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const long ro = (long)(16 * k + 4 * s + lr) * NPAD;
+            av[s] = Gb[ro + 16 * kb + lc];
+            bv[s] = Gb[ro + 16 * j + lc];
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) S[u] = gmfma(-(av[s] * dk), bv[s] * dj, S[u]);
+        }
+      }
+    }
+    if (w == 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) Dt[(lr + 4 * g) * 16 + lc] = S[0][g];
+    }
+    __syncthreads();
+    // ---- B. wave 0: Cholesky of the diagonal tile and its inverse ----
+    if (w == 0) {
+      const int jc = lc;
+      double col[TILE];
+#pragma unroll
+      for (int i = 0; i < TILE; ++i) col[i] = Dt[i * 16 + jc];
+      double pmin = pminsh;
+      double pnv = 0.0;                                 // lane k: 1 / R'[k][k]
+#pragma unroll
+      for (int kk = 0; kk < TILE; ++kk) {
+        const double d = read_lane(col[kk], kk);
+        const bool live = (16 * kb + kk) < n;           // the rhs / padding columns are not gated
+        if (live && !(d >= pmin)) pmin = d;             // also catches NaN
+        const bool pos = d > 1e-300;
+        const double ds = pos ? d : 1.0;
+        double ri = __builtin_amdgcn_rsq(ds);
+        ri = ri * fma(-0.5 * ds * ri, ri, 1.5);
+        ri = ri * fma(-0.5 * ds * ri, ri, 1.5);
+        if (!pos) ri = 0.0;                             // zero row (rho = 0, padding)
+        const double rkj = col[kk] * ri;
+        col[kk] = (jc >= kk) ? rkj : 0.0;
+        pnv = (jc == kk) ? ri : pnv;
+#pragma unroll
+        for (int i = kk + 1; i < TILE; ++i) col[i] = fma(-read_lane(rkj, i), rkj, col[i]);
+      }
+      // inverse of the upper triangle, column jc (back substitution)
+      double uu[TILE];
+#pragma unroll
+      for (int i = TILE - 1; i >= 0; --i) {
+        double acc = (i == jc) ? 1.0 : 0.0;
+#pragma unroll
+        for (int l = i + 1; l < TILE; ++l) acc = fma(-read_lane(col[i], l), uu[l], acc);
+        uu[i] = acc * read_lane(pnv, i);
+      }
+      if (lane < TILE) {
+#pragma unroll
+        for (int i = 0; i < TILE; ++i) { Dt[i * 16 + jc] = col[i]; Ri[i * 16 + jc] = uu[i]; }
+      }
+      if (lane == 0) pminsh = pmin;
+    }
+    __syncthreads();
+    // ---- C. R'_{kb,j} = R'_{kb,kb}^-T S_j, stored as R = R' D^-1 ----
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int j = kb + w + GR_NW * u;
+      if (j < NT) {
+        v4d X = {0.0, 0.0, 0.0, 0.0};
+        if (j == kb) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) X[g] = Dt[(lr + 4 * g) * 16 + lc];
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) X = gmfma(Ri[(4 * s + lr) * 16 + lc], S[u][s], X);
+        }
+        const double sj = sq[16 * j + lc];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * kb + lr + 4 * g;
+          const int colg = 16 * j + lc;
+          double val = X[g] * sj;
+          if (row >= n || row > colg || colg > n) val = 0.0;
+          Gb[(long)row * NPAD + colg] = val;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const bool fail = !(pminsh >= GRAM_SMIN * GRAM_SMIN);
+    a.fb_mask[b] = fail ? N : 0;
+    if (fail) atomicAdd(a.fail_count, 1);
+  }
+}
+
+// ---- conditioning gate: inverse power iteration on R' = R D ---------------------------------
+__global__ __launch_bounds__(TRI_NT) void gram_gate_kernel(GramCholArgs a) {
+  extern __shared__ double sh[];
+  __shared__ double red[32];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (a.mask && a.mask[b] <= 1) return;
+  if (a.fb_mask[b] != 0) return;                        // already failed on a pivot
+  const int n = a.n, ld = a.NPAD;
+  const double* R = a.G + (long)b * ld * ld;
+  const double* d = a.dsc + (long)b * ld;
+  double* v = sh;
+  double* invd = v + ld;
+  double* pfbuf = invd + ld;
+  tri_invdiag(R, n, ld, invd);
+  const double s0 = 1.0 / sqrt((double)n);
+  for (int i = tid; i < n; i += TRI_NT) v[i] = (i % 3 == 0) ? s0 : -0.5 * s0;
+  __syncthreads();
+  double smin = 0.0;
+  for (int it = 0; it < 3; ++it) {
+    // v <- R'^-1 R'^-T v  with  R' = R D:  R'^-T y = R^-T (y / d),  R'^-1 y = (R^-1 y) / d
+    for (int i = tid; i < n; i += TRI_NT) v[i] = v[i] / d[i];
+    __syncthreads();
+    tri_solve_upper_t_pf(R, n, ld, invd, v, pfbuf);
+    tri_solve_upper_pf(R, n, ld, invd, v, pfbuf);
+    for (int i = tid; i < n; i += TRI_NT) v[i] = v[i] / d[i];
+    __syncthreads();
+    const double nv = sqrt(tri_dot(v, v, n, red));
+    smin = (nv > 0.0 && is_finite(nv)) ? 1.0 / sqrt(nv) : 0.0;
+    const double inv = (nv > 0.0 && is_finite(nv)) ? 1.0 / nv : 0.0;
+    for (int i = tid; i < n; i += TRI_NT) v[i] *= inv;
+    __syncthreads();
+  }
+  if (tid == 0 && !(smin >= GRAM_SMIN)) {
+    a.fb_mask[b] = n + 1;
+    atomicAdd(a.fail_count, 1);
+  }
+}
+
+bool gram_supported(int m, int n) {
+  const int NT = (n + 1 + 15) / 16;
+  return NT <= 17 && m >= n && n >= 1;
+}
+int gram_chunks(int B, int m) {
+  int c = (512 + B - 1) / B;
+  const int cap = m / 512;
+  if (c > cap) c = cap;
+  return c < 1 ? 1 : c;
+}
+
+hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s) {
+  GramArgs a = a_in;
+  const int NT = (a.n + 1 + 15) / 16;
+  a.rows_per_chunk = ((a.m + chunks - 1) / chunks + GR_RC - 1) / GR_RC * GR_RC;
+  const size_t lds = sizeof(double) * 2 * GR_RC * (size_t)gram_ldx(NT);
+  const int ntile = NT * (NT + 1) / 2;
+  if ((ntile + GR_NW - 1) / GR_NW <= 4) {
+    { static std::atomic<size_t> granted[64]; hipError_t ge = gram_grant_lds(gram_kernel<4>, lds, granted); if (ge != hipSuccess) return ge; }
+    hipLaunchKernelGGL(gram_kernel<4>, dim3(chunks, B), dim3(GR_NT), lds, s, a);
+  } else {
+    { static std::atomic<size_t> granted[64]; hipError_t ge = gram_grant_lds(gram_kernel<20>, lds, granted); if (ge != hipSuccess) return ge; }
+    hipLaunchKernelGGL(gram_kernel<20>, dim3(chunks, B), dim3(GR_NT), lds, s, a);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_gram_reduce(const double* Gpart, int chunks, int NPAD, double* Gout,
+                              const int* mask, int B, hipStream_t s) {
+  const long sz = (long)NPAD * NPAD;
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)((sz + 255) / 256), B), dim3(256), 0, s,
+                     Gpart, chunks, NPAD, Gout, mask);
+  return hipGetLastError();
+}
+hipError_t launch_gram_chol(const GramCholArgs& a, int B, hipStream_t s) {
+  const size_t lds = sizeof(double) * (2 * (size_t)a.NPAD + 512);
+  hipLaunchKernelGGL(gram_chol_kernel, dim3(B), dim3(GR_NT), lds, s, a);
+  return hipGetLastError();
+}
+hipError_t launch_gram_gate(const GramCholArgs& a, int B, hipStream_t s) {
+  const size_t lds = sizeof(double) * (2 + 32) * (size_t)a.NPAD;
+  { static std::atomic<size_t> granted[64]; hipError_t ge = gram_grant_lds(gram_gate_kernel, lds, granted); if (ge != hipSuccess) return ge; }
+  hipLaunchKernelGGL(gram_gate_kernel, dim3(B), dim3(TRI_NT), lds, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace blsq

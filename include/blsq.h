@@ -167,6 +167,10 @@ int blsq_tsqr_combine_dev(blsq_trf_plan* plan, const double* dtri_stack /*nranks
  * reconstruction fast path (out[0]) and by the exact Householder column loop (out[1]: partial
  * last panels and panels whose scaled Gram has a small pivot) since the last reset. */
 int blsq_debug_cqr_stats(blsq_ctx* ctx, uint64_t out[2], int reset);
+/* Diagnostics of the factorisation front end: out[0] = problems factored by the
+ * normal-equations fast path (Gram + equilibrated Cholesky, conditioning-gated), out[1] =
+ * problems the gate handed to the Householder TSQR tree, since the last reset. */
+int blsq_debug_gram_stats(blsq_ctx* ctx, uint64_t out[2], int reset);
 
 /* ---- batched outer trust-region drivers, device-resident ------------------
  * Replaces, for B problems of one shape advancing in lock-step, the Python loops around the

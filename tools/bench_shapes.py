@@ -23,9 +23,10 @@ for kind, B, m, n in SHAPES:
         dD = ctx.to_device(np.full(B, 0.02))
         def step():
             sol.factor_dev(d["J"], d["f"], d["x"], d["lb"], d["ub"], d["scale"], d["on_bound"]); sol.step_dev(dD)
-    ctx.cqr_stats(reset=True)
+    ctx.cqr_stats(reset=True); ctx.gram_stats(reset=True)
     step(); ctx.sync()
-    print("   panels (Cholesky-QR fast path, Householder column loop) in one step-solve batch:", ctx.cqr_stats())
+    print("   one step-solve batch: problems (normal-equations path, QR tree) =", ctx.gram_stats(),
+          " QR panels (Cholesky-QR, Householder column loop) =", ctx.cqr_stats())
     ctx.timing(True); ctx.timing_reset()
     t0 = time.perf_counter()
     K = 5
