@@ -43,6 +43,15 @@ __device__ __forceinline__ v4d gmfma(double a, double b, v4d c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// LDS byte address of a pointer into the dynamic LDS array, and an explicit 8-byte LDS read whose
+// completion the CALLER waits for (counted s_waitcnt lgkmcnt)
+__device__ __forceinline__ unsigned lds_addr(const double* p) {
+  return (unsigned)(unsigned long)(lptr_t*)p;
+}
+__device__ __forceinline__ void lds_read64(double& dst, unsigned byte_addr) {
+  asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(byte_addr));
+}
+
 __host__ __device__ inline int gram_ldx(int NT) { return NT * 16 + ((NT & 1) ? 0 : 16); }
 
 // ---- G = [J f]^T [J f] ---------------------------------------------------------------------
@@ -52,8 +61,8 @@ __host__ __device__ inline int gram_ldx(int NT) { return NT * 16 + ((NT & 1) ? 0
 // order and stay in accumulators for the whole pass.  Both MFMA operands of tile (i, j) are the
 // same fragment pattern X[4 s + lr][16 c + lc] (c = i for A, c = j for B), read from LDS; the LDS
 // row stride is an odd multiple of 16 doubles so the two rows a half-wave reads hit disjoint banks.
-template <int SLOTS>
-__global__ __launch_bounds__(GR_NT, (SLOTS <= 4 ? 4 : 2)) void gram_kernel(GramArgs a) {
+template <int SLOTS, int NCB>
+__global__ __launch_bounds__(GR_NT, (SLOTS <= 8 ? 4 : 2)) void gram_kernel(GramArgs a) {
   extern __shared__ double lds[];
   const int b = blockIdx.y;
   if (a.mask && a.mask[b] <= 1) return;
@@ -91,34 +100,36 @@ __global__ __launch_bounds__(GR_NT, (SLOTS <= 4 ? 4 : 2)) void gram_kernel(GramA
     }
   }
 
-  constexpr int RR = GR_RC / GR_NW;                     // rows per wave per chunk
-  constexpr int NCB = 5;                                // 64-column blocks (LDX <= 320)
-  double pre[RR][NCB], fpre[RR];
-  auto issue = [&](int row0) {
+  // Staging: wave w owns rows w, w + 8, w + 16, w + 24 of a chunk, lanes run along the row (NCB
+  // blocks of 64 columns of J; the rhs f is column n, written by lane 0).  The rows of the NEXT
+  // chunk are prefetched into registers in two halves, each behind half of the MFMA burst.
+  constexpr int HR = GR_RC / GR_NW / 2;                 // rows per wave per half chunk
+  double pre[HR][NCB], fpre[HR];
+  auto issue = [&](int row0, int h) {
 #pragma unroll
-    for (int rr = 0; rr < RR; ++rr) {
-      const int row = row0 + w + GR_NW * rr;
+    for (int rr = 0; rr < HR; ++rr) {
+      const int row = row0 + w + GR_NW * (HR * h + rr);
       const int rc = row < m ? row : m - 1;
       fpre[rr] = Fb[rc];
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
         const int col = lane + 64 * cb;
         const int cc = col < n ? col : n - 1;
-        pre[rr][cb] = (64 * cb < n) ? __builtin_nontemporal_load(Jb + (long)rc * a.ldJ + cc) : 0.0;
+        pre[rr][cb] = __builtin_nontemporal_load(Jb + (long)rc * a.ldJ + cc);
       }
     }
   };
-  auto commit = [&](int row0, double* X) {
+  auto commit = [&](int row0, int h, double* X) {
 #pragma unroll
-    for (int rr = 0; rr < RR; ++rr) {
-      const int row = row0 + w + GR_NW * rr;
+    for (int rr = 0; rr < HR; ++rr) {
+      const int lrow = w + GR_NW * (HR * h + rr);
+      const bool in = row0 + lrow < m;
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
         const int col = lane + 64 * cb;
-        double val = 0.0;
-        if (row < m) val = (col < n) ? pre[rr][cb] : ((col == n) ? fpre[rr] : 0.0);
-        if (col < LDX) X[(w + GR_NW * rr) * LDX + col] = val;
+        if (col < n) X[lrow * LDX + col] = in ? pre[rr][cb] : 0.0;
       }
+      if (lane == 0) X[lrow * LDX + n] = in ? fpre[rr] : 0.0;
     }
   };
 
@@ -128,23 +139,61 @@ __global__ __launch_bounds__(GR_NT, (SLOTS <= 4 ? 4 : 2)) void gram_kernel(GramA
 
   double* X0 = lds;
   double* X1 = lds + GR_RC * LDX;
+  // padding columns (n, LDX) of both buffers are zero for the whole pass
+  for (int idx = tid; idx < 2 * GR_RC * (LDX - N); idx += GR_NT) {
+    const int r = idx / (LDX - N), c = idx - r * (LDX - N);
+    lds[r * LDX + N + c] = 0.0;
+  }
   if (r_lo < m) {
-    issue(r_lo);
-    commit(r_lo, X0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { issue(r_lo, h); commit(r_lo, h, X0); }
   }
   __syncthreads();
   int cidx = 0;
   for (int row0 = r_lo; row0 < m; row0 += GR_RC, ++cidx) {
     const bool more = row0 + GR_RC < m;
-    if (more) issue(row0 + GR_RC);
     const double* X = (cidx & 1) ? X1 : X0;
+    double* Xn = (cidx & 1) ? X0 : X1;
+    const unsigned xb = lds_addr(X) + 8u * (unsigned)(lr * LDX + lc);
 #pragma unroll
-    for (int s = 0; s < GR_RC / 4; ++s) {
-      const double* xr = X + (4 * s + lr) * LDX + lc;
+    for (int h = 0; h < 2; ++h) {
+#if !defined(GRAM_EXP) || (GRAM_EXP != 2 && GRAM_EXP != 3)
+      if (more) issue(row0 + GR_RC, h);
+#endif
+      // Operand fragments are fetched TWO MFMAs ahead of their use: the LDS round trip under
+      // load is longer than one MFMA of each of the SIMD's two waves.  The reads and the counted
+      // waits are explicit (the compiler would otherwise fold the stages back into one register
+      // set and wait for every read right before its MFMA).
+      constexpr int KS = GR_RC / 4 / 2;                 // k-steps per half
+      constexpr int TOT = KS * SLOTS;
+      double fa[3], fb[3];
+      auto fetch = [&](int q) {
+        const unsigned so = 8u * (unsigned)((KS * h + q / SLOTS) * 4 * LDX);
+#if defined(GRAM_EXP) && (GRAM_EXP == 1 || GRAM_EXP == 3)
+        fa[q % 3] = (double)so; fb[q % 3] = (double)xb;
+#else
+        lds_read64(fa[q % 3], xb + so + 8u * (unsigned)ti[q % SLOTS]);
+        lds_read64(fb[q % 3], xb + so + 8u * (unsigned)tj[q % SLOTS]);
+#endif
+      };
+      fetch(0);
+      fetch(1);
 #pragma unroll
-      for (int t = 0; t < SLOTS; ++t) acc[t] = gmfma(xr[ti[t]], xr[tj[t]], acc[t]);
+      for (int q = 0; q < TOT; ++q) {
+        if (q + 2 < TOT) {
+          fetch(q + 2);
+          asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[q % 3]), "+v"(fb[q % 3]));
+        } else if (q + 1 < TOT) {
+          asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[q % 3]), "+v"(fb[q % 3]));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[q % 3]), "+v"(fb[q % 3]));
+        }
+        acc[q % SLOTS] = gmfma(fa[q % 3], fb[q % 3], acc[q % SLOTS]);
+      }
+#if !defined(GRAM_EXP) || (GRAM_EXP != 2 && GRAM_EXP != 3)
+      if (more) commit(row0 + GR_RC, h, Xn);
+#endif
     }
-    if (more) commit(row0 + GR_RC, (cidx & 1) ? X0 : X1);
     __syncthreads();
   }
 
@@ -389,13 +438,25 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s) {
   a.rows_per_chunk = ((a.m + chunks - 1) / chunks + GR_RC - 1) / GR_RC * GR_RC;
   const size_t lds = sizeof(double) * 2 * GR_RC * (size_t)gram_ldx(NT);
   const int ntile = NT * (NT + 1) / 2;
-  if ((ntile + GR_NW - 1) / GR_NW <= 4) {
-    { static std::atomic<size_t> granted[64]; hipError_t ge = gram_grant_lds(gram_kernel<4>, lds, granted); if (ge != hipSuccess) return ge; }
-    hipLaunchKernelGGL(gram_kernel<4>, dim3(chunks, B), dim3(GR_NT), lds, s, a);
+#define BLSQ_GRAM_LAUNCH(SL, CB)                                                              \
+  do {                                                                                        \
+    static std::atomic<size_t> granted[64];                                                   \
+    hipError_t ge = gram_grant_lds(gram_kernel<SL, CB>, lds, granted);                        \
+    if (ge != hipSuccess) return ge;                                                          \
+    hipLaunchKernelGGL((gram_kernel<SL, CB>), dim3(chunks, B), dim3(GR_NT), lds, s, a);       \
+  } while (0)
+  const int ncb = (a.n + 63) / 64;
+  const int per = (ntile + GR_NW - 1) / GR_NW;          // tile slots a wave needs
+  if (per <= 4) {                                       // n <= 111
+    if (ncb <= 1) BLSQ_GRAM_LAUNCH(4, 1); else BLSQ_GRAM_LAUNCH(4, 2);
+  } else if (per <= 8) {                                // n <= 159
+    if (ncb <= 2) BLSQ_GRAM_LAUNCH(8, 2); else BLSQ_GRAM_LAUNCH(8, 3);
+  } else if (per <= 12) {                               // n <= 207
+    if (ncb <= 3) BLSQ_GRAM_LAUNCH(12, 3); else BLSQ_GRAM_LAUNCH(12, 4);
   } else {
-    { static std::atomic<size_t> granted[64]; hipError_t ge = gram_grant_lds(gram_kernel<20>, lds, granted); if (ge != hipSuccess) return ge; }
-    hipLaunchKernelGGL(gram_kernel<20>, dim3(chunks, B), dim3(GR_NT), lds, s, a);
+    if (ncb <= 4) BLSQ_GRAM_LAUNCH(20, 4); else BLSQ_GRAM_LAUNCH(20, 5);
   }
+#undef BLSQ_GRAM_LAUNCH
   return hipGetLastError();
 }
 hipError_t launch_gram_reduce(const double* Gpart, int chunks, int NPAD, double* Gout,

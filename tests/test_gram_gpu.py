@@ -1,0 +1,191 @@
+"""Normal-equations fast path of the factorisation (gram_kernels.hip) and its conditioning gate.
+
+The step must match the CPU oracle to 1e-10 / bit-exact masks WHICHEVER path factors a problem;
+the diagnostic counter (blsq_debug_gram_stats) shows which one ran.  Columns that all share a common
+component with cosine rho give an equilibrated Gram with sigma_min(R') = sqrt(1 - rho): the gate
+(pivots and inverse-power estimate >= 0.2) passes up to rho ~ 0.96 and must reject beyond."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-10
+
+
+def rel(a, b):
+    a = np.asarray(a, float); b = np.asarray(b, float)
+    den = np.linalg.norm(b)
+    return np.linalg.norm(a - b) / (den if den > 0 else 1.0)
+
+
+@pytest.fixture(scope="module")
+def bl():
+    import bounded_lsq
+    return bounded_lsq
+
+
+def _equicorrelated(B, m, n, rho, seed):
+    rng = np.random.default_rng(seed)
+    Z = rng.standard_normal((B, m, n))
+    common = rng.standard_normal((B, m, 1))
+    rho = np.broadcast_to(np.asarray(rho, float).reshape(-1, 1, 1), (B, 1, 1))
+    return np.sqrt(1 - rho) * Z + np.sqrt(rho) * common
+
+
+def _check(bl, P, Delta, kind="trf"):
+    from oracle import blsq_oracle as orc
+    from bounded_lsq import _abi
+    B, m, n = P["J"].shape
+    ctx = _abi.Context(0)
+    worst = 0.0
+    if kind == "trf":
+        sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
+        ctx.gram_stats(reset=True)
+        sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+        stats = ctx.gram_stats()
+        S = sol.step(Delta, np.zeros(B))
+        for b in range(B):
+            _, So = orc.trf_step_solve(P["J"][b], P["f"][b], P["x"][b], P["lb"][b], P["ub"][b],
+                                       P["scale"][b], Delta[b], 0.0)
+            e = rel(S.step[b], So.step)
+            assert e < RTOL, (b, e, stats)
+            np.testing.assert_array_equal(S.hits[b], So.hits)
+            worst = max(worst, e)
+    else:
+        sol = bl.DogboxStepSolver(B, m, n, ctx=ctx)
+        ctx.gram_stats(reset=True)
+        sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"], P["on_bound"])
+        stats = ctx.gram_stats()
+        S = sol.step(Delta)
+        for b in range(B):
+            _, So = orc.dogbox_step_solve(P["J"][b], P["f"][b], P["x"][b], P["lb"][b], P["ub"][b],
+                                          P["scale"][b], P["on_bound"][b], Delta[b])
+            e = rel(S.step[b], So.step)
+            assert e < RTOL, (b, e, stats)
+            np.testing.assert_array_equal(S.on_bound_new[b], So.on_bound_new)
+            worst = max(worst, e)
+    sol.close(); ctx.close()
+    return stats, worst
+
+
+@pytest.mark.parametrize("B,m,n", [(6, 512, 64), (3, 2000, 256), (4, 1500, 128), (5, 300, 16),
+                                   (3, 700, 100), (2, 4096, 200), (3, 900, 271)])
+def test_well_conditioned_batches_take_the_fast_path(bl, B, m, n):
+    from bounded_lsq import _synth
+    P = _synth.trf_batch(77 + n, B, m, n)
+    stats, _ = _check(bl, P, np.where(np.arange(B) % 2 == 0, 10.0, 0.5))
+    assert stats == (B, 0)
+
+
+@pytest.mark.parametrize("n", [48, 256])
+@pytest.mark.parametrize("rho", [0.5, 0.9, 0.94, 0.955, 0.965, 0.98, 0.999, 1 - 1e-8])
+def test_gate_around_its_threshold(bl, rho, n):
+    """sigma_min(R') = sqrt(1 - rho): 0.71, 0.32, 0.245, 0.21 | 0.187, 0.14, 0.03, 1e-4."""
+    from bounded_lsq import _synth
+    B, m = 3, 2048
+    P = _synth.trf_batch(31, B, m, n)
+    P["J"] = _equicorrelated(B, m, n, rho, 5)
+    stats, worst = _check(bl, P, np.array([10.0, 0.5, 2.0]))
+    if rho <= 0.9:
+        assert stats == (B, 0), stats                   # clearly inside: fast path
+    if rho >= 0.98:
+        assert stats == (0, B), stats                   # clearly outside: Householder tree
+
+
+def test_mixed_batch_splits_between_the_paths(bl):
+    from bounded_lsq import _synth
+    B, m, n = 8, 1024, 96
+    P = _synth.trf_batch(8, B, m, n)
+    rho = np.where(np.arange(B) % 2 == 0, 0.3, 0.9999)
+    P["J"] = _equicorrelated(B, m, n, rho, 3)
+    stats, _ = _check(bl, P, np.full(B, 1.0))
+    assert stats == (B // 2, B // 2)
+
+
+def test_rank_deficient_zero_and_nonfinite_columns_go_to_the_tree(bl):
+    """(The reference's answer for a rank-deficient J is decided by rounding noise in the null
+    space — tests/test_hip_parity.py KNIFE_EDGE — so only the routing is asserted here; parity of
+    rank-deficient fixtures is covered by the golden tests, which run with the front end on.)"""
+    from bounded_lsq import _synth, _abi
+    B, m, n = 4, 600, 40
+    P = _synth.trf_batch(4, B, m, n)
+    P["J"][0][:, 7] = 0.0                               # zero column
+    P["J"][1][:, 9] = P["J"][1][:, 3]                   # duplicate column
+    P["J"][2][:, 11] = 2.0 * P["J"][2][:, 0] - P["J"][2][:, 5]   # dependent column
+    ctx = _abi.Context(0)
+    sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
+    ctx.gram_stats(reset=True)
+    sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+    assert ctx.gram_stats() == (1, 3)
+    S = sol.step(np.full(B, 0.7), np.zeros(B))
+    assert np.all(np.isfinite(S.step))
+    sol.close()
+    sol = bl.TrfStepSolver(1, m, n, ctx=ctx)
+    J = P["J"][3:4].copy(); J[0, 5, 5] = np.nan
+    ctx.gram_stats(reset=True)
+    sol.factor(J, P["f"][3:4], P["x"][3:4], P["lb"][3:4], P["ub"][3:4], P["scale"][3:4])
+    assert ctx.gram_stats() == (0, 1)                   # non-finite input never passes the gate
+    sol.close(); ctx.close()
+
+
+def test_wide_and_square_problems(bl):
+    from bounded_lsq import _synth
+    for (B, m, n) in [(3, 64, 64), (2, 40, 64), (3, 17, 16)]:
+        P = _synth.trf_batch(12, B, m, n)
+        _check(bl, P, np.full(B, 0.9))
+
+
+def test_dogbox_uses_the_same_front_end(bl):
+    from bounded_lsq import _synth
+    B, m, n = 6, 800, 72
+    P = _synth.dogbox_batch(21, B, m, n)
+    stats, _ = _check(bl, P, np.full(B, 0.05), kind="dogbox")
+    assert stats == (B, 0)
+    P["J"] = _equicorrelated(B, m, n, 0.9999, 2)
+    stats, _ = _check(bl, P, np.full(B, 0.05), kind="dogbox")
+    assert stats == (0, B)
+
+
+def test_env_switch_disables_the_fast_path(bl, monkeypatch):
+    from bounded_lsq import _synth
+    monkeypatch.setenv("BLSQ_GRAM", "0")
+    P = _synth.trf_batch(5, 3, 400, 32)
+    stats, _ = _check(bl, P, np.full(3, 0.9))
+    assert stats == (0, 0)                              # the front end never ran
+
+
+def test_single_tall_problem_row_chunks(bl):
+    """B = 1: the Gram is accumulated by many workgroups over row chunks and reduced."""
+    from bounded_lsq import _synth
+    P = _synth.trf_batch(9, 1, 40000, 64)
+    stats, _ = _check(bl, P, np.array([0.8]))
+    assert stats == (1, 0)
+
+
+def test_badly_scaled_columns_are_equilibrated(bl, monkeypatch):
+    """Column norms spread over many orders of magnitude: the equilibrated Gram is as well
+    conditioned as the normalised columns, so the fast path is taken and is as accurate as the
+    Householder tree.  (At a spread of 1e+-6, cond(J) ~ 1e11, the reference's own SVD answer moves
+    by ~1e-10 — both paths then differ from the oracle by the same amount, and from each other by
+    far less.)"""
+    from bounded_lsq import _synth, _abi
+    B, m, n = 3, 1000, 60
+    P = _synth.trf_batch(15, B, m, n)
+    rng = np.random.default_rng(0)
+    J0 = P["J"]
+    P["J"] = J0 * 10.0 ** rng.uniform(-3, 3, size=(B, 1, n))
+    stats, _ = _check(bl, P, np.full(B, 0.5))
+    assert stats == (B, 0)
+    P["J"] = J0 * 10.0 ** rng.uniform(-6, 6, size=(B, 1, n))
+    steps = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("BLSQ_GRAM", mode)
+        ctx = _abi.Context(0)
+        sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
+        ctx.gram_stats(reset=True)
+        sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+        assert ctx.gram_stats() == ((B, 0) if mode == "1" else (0, 0))
+        steps[mode] = sol.step(np.full(B, 0.5), np.zeros(B)).step.copy()
+        sol.close(); ctx.close()
+    for b in range(B):
+        assert rel(steps["1"][b], steps["0"][b]) < 1e-11

@@ -37,6 +37,16 @@ def bl():
 TRF_CASES = load_npz("trf_small.npz") + load_npz("trf_large.npz")
 
 
+@pytest.fixture(params=["gram_front_end", "qr_tree_only"], autouse=True)
+def fact_path(request, monkeypatch):
+    """Every test of this file runs twice: with the normal-equations front end of the
+    factorisation (Gram + gated Cholesky; ill-conditioned problems still reach the Householder
+    tree through its gate) and with the front end switched off, so the TSQR tree keeps its full
+    coverage."""
+    monkeypatch.setenv("BLSQ_GRAM", "1" if request.param == "gram_front_end" else "0")
+    return request.param
+
+
 @pytest.fixture(params=["svd_free", "svd_only"])
 def tr_path(request, monkeypatch):
     """Both trust-region paths: the SVD-free one (QR of [R; sqrt(alpha) I], taken when the
