@@ -28,6 +28,17 @@ def collect(d, counter):
     return out
 
 
+def slot_of(kernel):
+    """bench.py timing slot of a kernel name (the dominant ones only)."""
+    if kernel is None:
+        return None
+    if "gram_kernel" in kernel:
+        return "gram"
+    if "qr_panel_kernel<8, false>" in kernel:
+        return "qr_leaf"
+    return kernel
+
+
 def main():
     fdir, wdir, outp, m, n, B = sys.argv[1:7]
     fetch, write = collect(fdir, "FETCH_SIZE"), collect(wdir, "WRITE_SIZE")
@@ -47,7 +58,7 @@ def main():
         "note": "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads 1/2 of a wide coalesced stream; "
                 "hbm_bytes = 2*FETCH + WRITE as the guide prescribes",
         "config": {"m": int(m), "n": int(n), "batch": int(B)},
-        "dominant": {"slot": "qr_leaf", "kernel": dom,
+        "dominant": {"slot": slot_of(dom), "kernel": dom,
                      "hbm_bytes_per_launch": kernels[dom]["hbm_bytes_per_launch"] if dom else None},
         "kernels": kernels,
     }
