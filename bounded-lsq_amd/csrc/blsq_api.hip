@@ -20,9 +20,10 @@ namespace {
 constexpr int RMAX = QR_MAX_TILES * 16;   // rows a workgroup can stage (qr_panel.hip): 1024
 
 enum Slot { K_QR_LEAF = 0, K_QR_MERGE, K_PREP, K_QR_AUG, K_JACOBI, K_STEP, K_LM_GATE, K_LM_QR, K_LM_SOLVE,
-            K_GRAM, K_GRAM_CHOL, K_GRAM_GATE, K_NSLOT };
+            K_GRAM, K_GRAM_CHOL, K_GRAM_GATE, K_AUG_CHOL, K_LM_CHOL, K_NSLOT };
 const char* kSlotNames[K_NSLOT] = {"qr_leaf", "qr_merge", "prep", "qr_aug", "jacobi_svd", "step",
-                                   "lm_gate", "lm_qr", "lm_solve", "gram", "gram_chol", "gram_gate"};
+                                   "lm_gate", "lm_qr", "lm_solve", "gram", "gram_chol", "gram_gate",
+                                   "aug_chol", "lm_chol"};
 
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
 // rows of the stacked systems [R D; E] / [R_aug; sqrt(alpha) I]: two blocks of
@@ -121,6 +122,9 @@ struct QrTree {
   bool gram = false;
   int gram_nchunk = 1;
   DevBuf gram_part, gram_dsc, gram_ints;   // partial Grams, column scales, [B] fallback mask + count
+  DevBuf gram_keep;                 // [B][NPAD*NPAD] the Grams themselves (kept: the trust-region
+                                    // systems are diagonal modifications of them)
+  bool all_gram = false;            // every problem's current triangle came from its Gram
 
   // rows: source rows per problem at level 0
   int build(blsq_ctx* ctx, int B_, int rows, int n_, size_t extra_rp_rows) {
@@ -175,6 +179,8 @@ struct QrTree {
       }
       e = gram_dsc.alloc(sizeof(double) * (size_t)B * NPAD);
       if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Gram scales)");
+      e = gram_keep.alloc(sizeof(double) * (size_t)B * NPAD * NPAD);
+      if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Grams)");
       e = gram_ints.alloc(sizeof(int) * ((size_t)B + 4));
       if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Gram mask)");
     }
@@ -183,7 +189,7 @@ struct QrTree {
   void release() {
     for (auto& L : levels) L.R.release();
     V.release(); T.release();
-    gram_part.release(); gram_dsc.release(); gram_ints.release();
+    gram_part.release(); gram_dsc.release(); gram_ints.release(); gram_keep.release();
   }
   // [J f] -> triangle by the normal equations where the conditioning gate allows it.
   // Returns the number of problems left for the Householder tree in *nfallback; their indices
@@ -197,15 +203,16 @@ struct QrTree {
     GramArgs g{};
     g.J = dJ; g.strideJ = (long)m * ldJ; g.ldJ = ldJ; g.F = df; g.strideF = m;
     g.m = m; g.n = n; g.NPAD = NPAD; g.mask = mask;
-    g.G = gram_nchunk > 1 ? gram_part.as<double>() : Rf;
+    double* Gk = gram_keep.as<double>();
+    g.G = gram_nchunk > 1 ? gram_part.as<double>() : Gk;
     ctx->begin(K_GRAM);
     hipError_t e = launch_gram(g, gram_nchunk, B, ctx->stream);
     if (e == hipSuccess && gram_nchunk > 1)
-      e = launch_gram_reduce(gram_part.as<double>(), gram_nchunk, NPAD, Rf, mask, B, ctx->stream);
+      e = launch_gram_reduce(gram_part.as<double>(), gram_nchunk, NPAD, Gk, mask, B, ctx->stream);
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_gram");
     GramCholArgs c{};
-    c.G = Rf; c.NPAD = NPAD; c.n = n; c.mask = mask; c.fb_mask = fb; c.fail_count = cnt;
+    c.Gsrc = Gk; c.G = Rf; c.NPAD = NPAD; c.n = n; c.mask = mask; c.fb_mask = fb; c.fail_count = cnt;
     c.dsc = gram_dsc.as<double>();
     ctx->begin(K_GRAM_CHOL);
     e = launch_gram_chol(c, B, ctx->stream);
@@ -239,9 +246,12 @@ struct QrTree {
       if (rc) return rc;
       ctx->gram_fallback += nfb;
       ctx->gram_fast += B - nfb;            // (masked problems count as fast: diagnostics only)
+      // a masked call refreshes some problems only: the others keep their earlier path
+      all_gram = (nfb == 0) && (ncols_mask == nullptr || all_gram);
       if (nfb == 0) return 0;
       ncols_mask = gram_ints.as<int>();     // only the problems the gate rejected
     }
+    else all_gram = false;
     for (size_t l = 0; l < levels.size(); ++l) {
       const Level& L = levels[l];
       QrArgs q = base_args();
@@ -272,6 +282,7 @@ struct blsq_trf_plan {
   blsq_ctx* ctx = nullptr;
   int B = 0, m = 0, n = 0, ld = 0;
   QrTree tree;
+  bool aug_from_gram = false;       // the augmented / Newton triangles come from the Grams (all problems)
   // TSQR (multi-rank) extras
   int nranks = 1, m_total = 0;
   DevBuf Rcomb;                     // [1][NPAD*NPAD] merged triangle
@@ -499,6 +510,18 @@ int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode) {
   hipError_t e = launch_trf_prep(p->st, scale_mode, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_trf_prep");
+  p->aug_from_gram = p->tree.all_gram && Rt == p->tree.Rfinal();
+  if (p->aug_from_gram) {
+    // every triangle came from its Gram G: the triangle of [R D | c; E | 0] is the Cholesky
+    // factor of D G D + E^2 (gram_kernels.hip; no new gate needed, see there)
+    GramCholArgs c{};
+    c.Gsrc = p->tree.gram_keep.as<double>(); c.G = p->st.X; c.NPAD = p->ld; c.n = p->n;
+    c.colscale = p->st.d; c.diag_vec = p->st.ediag; c.stride_vec = p->ld;
+    ctx->begin(K_AUG_CHOL);
+    e = launch_gram_chol(c, p->B, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(aug)");
+  } else {
   QrArgs q = p->tree.base_args();
   // source = R read in place, columns scaled by d on the fly, on top of the VIRTUAL block
   // E = diag(ediag): [R D | c ; E | 0] is never written to memory
@@ -514,6 +537,7 @@ int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode) {
   e = launch_qr(q, 1, p->B, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_qr(aug)");
+  }
   // rank gate: clearly full-rank problems skip the SVD (lm_kernels.hip)
   ctx->begin(K_LM_GATE);
   e = launch_lm_gate(p->lm, p->lm_enable, ctx->stream);
@@ -546,6 +570,17 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
   active = ctx->pinned[0];
   for (int round = 0; round < 12 && active > 0; ++round) {
     HIPCHK(ctx, hipMemsetAsync(p->lm.active_count, 0, sizeof(int), ctx->stream));
+    if (p->aug_from_gram) {
+      // R_alpha = chol(D G D + E^2 + alpha I) straight from the Gram, active problems only
+      GramCholArgs c{};
+      c.Gsrc = p->tree.gram_keep.as<double>(); c.G = p->lm.Xa; c.NPAD = p->ld; c.n = p->n;
+      c.colscale = p->st.d; c.diag_vec = p->st.ediag; c.diag_sqrt = p->lm.sa; c.stride_vec = p->ld;
+      c.batch_list = p->lm.active_list + (size_t)(round & 1) * p->B;
+      ctx->begin(K_LM_CHOL);
+      e = launch_gram_chol(c, active, ctx->stream);
+      ctx->end();
+      if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(lm)");
+    } else {
     // source = [R_aug | c_aug] read in place, stacked on a VIRTUAL sqrt(alpha) I block
     QrArgs q = p->tree.base_args();
     q.A = p->lm.Raug; q.strideA = (long)p->ld * p->ld; q.ldA = p->ld;
@@ -560,6 +595,7 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
     e = launch_qr(q, 1, active, ctx->stream);
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_qr(lm)");
+    }
     ctx->begin(K_LM_SOLVE);
     p->lm.round = round;
     e = launch_lm_update(p->lm, active, ctx->stream);

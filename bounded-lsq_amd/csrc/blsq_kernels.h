@@ -63,12 +63,20 @@ struct GramArgs {
   int rows_per_chunk;     // set by launch_gram
 };
 struct GramCholArgs {
-  double* G;              // [B][NPAD*NPAD] in: Gram, out: [R | Q^T f] (upper), zeros elsewhere
+  const double* Gsrc;     // [B][NPAD*NPAD] Gram (upper tile blocks); may alias G (in place)
+  double* G;              // [B][NPAD*NPAD] out: [R | Q^T f] (upper), zeros elsewhere
   int NPAD, n;
+  // optional diagonal modification  H = D Gsrc D + diag(diag_vec^2 + diag_sqrt[b]^2)  on the first
+  // n columns (D = diag(colscale)): the trust-region systems of TRF
+  const double* colscale;    // [B][stride_vec]
+  const double* diag_vec;    // [B][stride_vec]
+  const double* diag_sqrt;   // [B]
+  long stride_vec;
+  const int* batch_list;  // optional compacted problem indices (grid = their number)
   const int* mask;        // optional, as above
-  int* fb_mask;           // [B] out: n + 1 if the problem needs the Householder tree, else 0
+  int* fb_mask;           // optional [B] out: n + 1 if the problem needs the Householder tree, else 0
   int* fail_count;        // [1] number of such problems (caller zeroes it)
-  double* dsc;            // [B][NPAD] out: column scales 1 / ||J_j||
+  double* dsc;            // optional [B][NPAD] out: column scales 1 / ||J_j||
 };
 bool gram_supported(int m, int n);
 int gram_chunks(int B, int m);

@@ -229,28 +229,43 @@ __global__ void gram_reduce_kernel(const double* Gpart, int chunks, int NPAD, do
 // rows already written),  R'_{kb,kb} = chol(S_kb) and its inverse on wave 0 (lane j owns column
 // j, broadcasts by v_readlane),  R'_{kb,j} = R'_{kb,kb}^-T S_j  (MFMA; the accumulator layout of S is
 // the B-operand layout).  What is stored is R = R' D^-1; operands are re-scaled on the fly.
+//
+// The same kernel factors the diagonally modified Grams of the trust-region systems (TRF):
+//     H = D G D + diag(e^2) (+ alpha I on the first n columns),    D = diag(colscale, 1)
+// whose Cholesky factor is the triangle of [R D | c; E | 0] (and of [R_aug; sqrt(alpha) I]).  With
+// C = equil(G):  equil(H) = Theta^1/2 C Theta^1/2 + (I - Theta),  0 < Theta <= I diagonal, so its
+// extreme eigenvalues lie inside those of C: a problem that passed the gate on C needs no new one.
 __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
   extern __shared__ double sh[];
   __shared__ double red[32];
   __shared__ double pminsh;
-  const int b = blockIdx.x;
+  const int b = a.batch_list ? a.batch_list[blockIdx.x] : (int)blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane >> 4, lc = lane & 15;
   const int n = a.n, N = n + 1, NPAD = a.NPAD, NT = NPAD / 16;
   if (a.mask && a.mask[b] <= 1) {
-    if (tid == 0) a.fb_mask[b] = 0;
+    if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
     return;
   }
-  double* Gb = a.G + (long)b * NPAD * NPAD;
-  double* dl = sh;                 // [NPAD] 1 / ||J_j||
-  double* sq = dl + NPAD;          // [NPAD] ||J_j||
-  double* Dt = sq + NPAD;          // [256]  diagonal tile (row-major)
+  const double* Gs = a.Gsrc + (long)b * NPAD * NPAD;    // source Gram (may alias the output)
+  double* Gb = a.G + (long)b * NPAD * NPAD;             // output triangle
+  double* dl = sh;                 // [NPAD] equilibration 1 / sqrt(h_jj)
+  double* sq = dl + NPAD;          // [NPAD] sqrt(h_jj)
+  double* sc = sq + NPAD;          // [NPAD] colscale_j * dl_j  (scale applied to source entries)
+  double* Dt = sc + NPAD;          // [256]  diagonal tile (row-major)
   double* Ri = Dt + 256;           // [256]  its inverse
-  // 0. column scales from the diagonal
+  double* td = Ri + 256;           // [NPAD] (e_j^2 + alpha) * dl_j^2  (added to the diagonal of C)
+  const double* csv = a.colscale ? a.colscale + (long)b * a.stride_vec : nullptr;
+  const double* edv = a.diag_vec ? a.diag_vec + (long)b * a.stride_vec : nullptr;
+  const double sa = a.diag_sqrt ? a.diag_sqrt[b] : 0.0;
+  // 0. column scales from the diagonal of H
   int bad = 0;
   for (int j = tid; j < NPAD; j += GR_NT) {
-    const double g = Gb[(long)j * NPAD + j];
+    const double cs = (csv && j < n) ? csv[j] : 1.0;
+    const double ej = (edv && j < n) ? edv[j] : 0.0;
+    const double add = (j < n) ? fma(ej, ej, sa * sa) : 0.0;
+    const double g = fma(Gs[(long)j * NPAD + j] * cs, cs, add);
     const bool okc = (g > 0.0) && is_finite(g);
     if (j < n && !okc) bad = 1;
     double d = 1.0, s = 1.0;
@@ -260,8 +275,8 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
       d = d * fma(-0.5 * g * d, d, 1.5);
       s = g * d;
     }
-    dl[j] = d; sq[j] = s;
-    a.dsc[(long)b * NPAD + j] = d;
+    dl[j] = d; sq[j] = s; sc[j] = cs * d; td[j] = add * d * d;
+    if (a.dsc) a.dsc[(long)b * NPAD + j] = d;
   }
   // strictly lower tiles are part of the triangle's image: zero
   for (int r = 16 + w; r < NPAD; r += GR_NW) {
@@ -272,7 +287,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
   if (tid == 0) pminsh = 1.0;
   __syncthreads();
   if (bad) {                                            // uniform: hand the problem to the QR tree
-    if (tid == 0) { a.fb_mask[b] = N; atomicAdd(a.fail_count, 1); }
+    if (tid == 0 && a.fb_mask) { a.fb_mask[b] = N; atomicAdd(a.fail_count, 1); }
     return;
   }
 
@@ -286,10 +301,13 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
       S[u] = v4d{0.0, 0.0, 0.0, 0.0};
       if (j < NT) {
         const double dj = dl[16 * j + lc];
+        const double scj = sc[16 * j + lc];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int row = 16 * kb + lr + 4 * g;
-          S[u][g] = Gb[(long)row * NPAD + 16 * j + lc] * dl[row] * dj;
+          double v = Gs[(long)row * NPAD + 16 * j + lc] * sc[row] * scj;
+          if (j == kb && lr + 4 * g == lc) v += td[row];
+          S[u][g] = v;
         }
         for (int k = 0; k < kb; ++k) {
           double av[4], bv[4];
@@ -376,7 +394,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
     }
     __syncthreads();
   }
-  if (tid == 0) {
+  if (tid == 0 && a.fb_mask) {
     const bool fail = !(pminsh >= GRAM_SMIN * GRAM_SMIN);
     a.fb_mask[b] = fail ? N : 0;
     if (fail) atomicAdd(a.fail_count, 1);
@@ -467,7 +485,7 @@ hipError_t launch_gram_reduce(const double* Gpart, int chunks, int NPAD, double*
   return hipGetLastError();
 }
 hipError_t launch_gram_chol(const GramCholArgs& a, int B, hipStream_t s) {
-  const size_t lds = sizeof(double) * (2 * (size_t)a.NPAD + 512);
+  const size_t lds = sizeof(double) * (4 * (size_t)a.NPAD + 512);
   hipLaunchKernelGGL(gram_chol_kernel, dim3(B), dim3(GR_NT), lds, s, a);
   return hipGetLastError();
 }

@@ -403,7 +403,7 @@ def _correlated_batch(B, m, n, rho, seed):
 
 
 @pytest.mark.parametrize("rho", [0.0, 0.5, 0.9, 0.99, 1 - 1e-6, 1 - 1e-12])
-def test_correlated_panels_fast_path_and_fallback(bl, rho):
+def test_correlated_panels_fast_path_and_fallback(bl, rho, fact_path):
     """Panels from well conditioned (Cholesky-QR + Householder reconstruction) to numerically
     dependent (exact Householder column loop): the step matches the oracle either way, and the
     diagnostic counters show which path ran."""
@@ -419,9 +419,10 @@ def test_correlated_panels_fast_path_and_fallback(bl, rho):
     sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
     fast, slow = ctx.cqr_stats()
     S = sol.step(Delta, np.zeros(B))
-    assert fast + slow > 0
-    if rho <= 0.5:
-        assert fast > 0                      # well conditioned panels take the fast path
+    if fact_path == "qr_tree_only":          # (with the Gram front end a well conditioned
+        assert fast + slow > 0               #  problem may never reach the QR kernel at all)
+        if rho <= 0.5:
+            assert fast > 0                  # well conditioned panels take the fast path
     if rho >= 1 - 1e-6:
         assert slow > 0                      # numerically dependent columns must not
     for b in range(B):
