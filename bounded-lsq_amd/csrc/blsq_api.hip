@@ -124,7 +124,11 @@ struct QrTree {
   DevBuf gram_part, gram_dsc, gram_ints;   // partial Grams, column scales, [B] fallback mask + count
   DevBuf gram_keep;                 // [B][NPAD*NPAD] the Grams themselves (kept: the trust-region
                                     // systems are diagonal modifications of them)
-  bool all_gram = false;            // every problem's current triangle came from its Gram
+  // per-problem path of the CURRENT triangles: gram_path()[b] = n + 1 (Householder tree) or 0 (Gram).
+  // any_gram / any_qr: whether a problem of either kind can exist (host-side upper bounds)
+  bool any_gram = false, any_qr = true;
+  bool path_valid = false;          // gram_path() describes the current triangles
+  const int* gram_path() const { return gram ? gram_ints.as<int>() + B + 4 : nullptr; }
 
   // rows: source rows per problem at level 0
   int build(blsq_ctx* ctx, int B_, int rows, int n_, size_t extra_rp_rows) {
@@ -181,8 +185,10 @@ struct QrTree {
       if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Gram scales)");
       e = gram_keep.alloc(sizeof(double) * (size_t)B * NPAD * NPAD);
       if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Grams)");
-      e = gram_ints.alloc(sizeof(int) * ((size_t)B + 4));
+      e = gram_ints.alloc(sizeof(int) * (2 * (size_t)B + 4));     // launch mask, count, path
       if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Gram mask)");
+      e = hipMemsetAsync(gram_ints.p, 0xFF, gram_ints.bytes, ctx->stream);   // path: all QR until factored
+      if (e != hipSuccess) return ctx->fail(e, "hipMemsetAsync(Gram mask)");
     }
     return 0;
   }
@@ -213,6 +219,7 @@ struct QrTree {
     if (e != hipSuccess) return ctx->fail(e, "launch_gram");
     GramCholArgs c{};
     c.Gsrc = Gk; c.G = Rf; c.NPAD = NPAD; c.n = n; c.mask = mask; c.fb_mask = fb; c.fail_count = cnt;
+    c.path_out = fb + B + 4;
     c.dsc = gram_dsc.as<double>();
     ctx->begin(K_GRAM_CHOL);
     e = launch_gram_chol(c, B, ctx->stream);
@@ -247,11 +254,13 @@ struct QrTree {
       ctx->gram_fallback += nfb;
       ctx->gram_fast += B - nfb;            // (masked problems count as fast: diagnostics only)
       // a masked call refreshes some problems only: the others keep their earlier path
-      all_gram = (nfb == 0) && (ncols_mask == nullptr || all_gram);
+      if (ncols_mask == nullptr || !path_valid) { any_qr = nfb > 0 || ncols_mask != nullptr; any_gram = nfb < B; }
+      else { any_qr = any_qr || nfb > 0; any_gram = true; }
+      path_valid = true;
       if (nfb == 0) return 0;
       ncols_mask = gram_ints.as<int>();     // only the problems the gate rejected
     }
-    else all_gram = false;
+    else { any_gram = false; any_qr = true; path_valid = false; }
     for (size_t l = 0; l < levels.size(); ++l) {
       const Level& L = levels[l];
       QrArgs q = base_args();
@@ -282,7 +291,10 @@ struct blsq_trf_plan {
   blsq_ctx* ctx = nullptr;
   int B = 0, m = 0, n = 0, ld = 0;
   QrTree tree;
-  bool aug_from_gram = false;       // the augmented / Newton triangles come from the Grams (all problems)
+  // which kernels factor the augmented / Newton systems of the current triangles (per problem:
+  // `path`, see trf_after_triangle)
+  const int* path = nullptr;
+  bool use_chol = false, use_qr = true;
   // TSQR (multi-rank) extras
   int nranks = 1, m_total = 0;
   DevBuf Rcomb;                     // [1][NPAD*NPAD] merged triangle
@@ -510,19 +522,27 @@ int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode) {
   hipError_t e = launch_trf_prep(p->st, scale_mode, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_trf_prep");
-  p->aug_from_gram = p->tree.all_gram && Rt == p->tree.Rfinal();
-  if (p->aug_from_gram) {
-    // every triangle came from its Gram G: the triangle of [R D | c; E | 0] is the Cholesky
-    // factor of D G D + E^2 (gram_kernels.hip; no new gate needed, see there)
+  // Per problem: a triangle that came from its Gram G gets the triangle of [R D | c; E | 0] as the
+  // Cholesky factor of D G D + E^2 (gram_kernels.hip; no new gate needed, see there); a triangle
+  // from the Householder tree gets the stacked QR.  The choice depends on the problem alone.
+  const bool own = (Rt == p->tree.Rfinal()) && p->tree.gram && p->tree.path_valid;
+  p->path = own ? p->tree.gram_path() : nullptr;
+  p->use_chol = own && p->tree.any_gram;
+  p->use_qr = !own || p->tree.any_qr;
+  p->lm.path = p->path;
+  if (p->use_chol) {
     GramCholArgs c{};
     c.Gsrc = p->tree.gram_keep.as<double>(); c.G = p->st.X; c.NPAD = p->ld; c.n = p->n;
     c.colscale = p->st.d; c.diag_vec = p->st.ediag; c.stride_vec = p->ld;
+    c.skip_path = p->path;
     ctx->begin(K_AUG_CHOL);
     e = launch_gram_chol(c, p->B, ctx->stream);
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(aug)");
-  } else {
+  }
+  if (p->use_qr) {
   QrArgs q = p->tree.base_args();
+  q.ncols_dev = p->path;                // (nullptr: all problems)
   // source = R read in place, columns scaled by d on the fly, on top of the VIRTUAL block
   // E = diag(ediag): [R D | c ; E | 0] is never written to memory
   q.A = Rt; q.strideA = (long)p->ld * p->ld; q.ldA = p->ld;
@@ -570,17 +590,19 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
   active = ctx->pinned[0];
   for (int round = 0; round < 12 && active > 0; ++round) {
     HIPCHK(ctx, hipMemsetAsync(p->lm.active_count, 0, sizeof(int), ctx->stream));
-    if (p->aug_from_gram) {
-      // R_alpha = chol(D G D + E^2 + alpha I) straight from the Gram, active problems only
+    if (p->use_chol) {
+      // R_alpha = chol(D G D + E^2 + alpha I) straight from the Gram, active Gram-path problems
       GramCholArgs c{};
       c.Gsrc = p->tree.gram_keep.as<double>(); c.G = p->lm.Xa; c.NPAD = p->ld; c.n = p->n;
       c.colscale = p->st.d; c.diag_vec = p->st.ediag; c.diag_sqrt = p->lm.sa; c.stride_vec = p->ld;
       c.batch_list = p->lm.active_list + (size_t)(round & 1) * p->B;
+      c.skip_path = p->path;
       ctx->begin(K_LM_CHOL);
       e = launch_gram_chol(c, active, ctx->stream);
       ctx->end();
       if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(lm)");
-    } else {
+    }
+    if (p->use_qr) {
     // source = [R_aug | c_aug] read in place, stacked on a VIRTUAL sqrt(alpha) I block
     QrArgs q = p->tree.base_args();
     q.A = p->lm.Raug; q.strideA = (long)p->ld * p->ld; q.ldA = p->ld;

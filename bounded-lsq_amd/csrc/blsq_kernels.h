@@ -73,6 +73,8 @@ struct GramCholArgs {
   const double* diag_sqrt;   // [B]
   long stride_vec;
   const int* batch_list;  // optional compacted problem indices (grid = their number)
+  const int* skip_path;   // optional [B]: problems with skip_path[b] != 0 are skipped (they are on the QR path)
+  int* path_out;          // optional [B] out (refreshed problems only): n + 1 = Householder tree, 0 = Gram
   const int* mask;        // optional, as above
   int* fb_mask;           // optional [B] out: n + 1 if the problem needs the Householder tree, else 0
   int* fail_count;        // [1] number of such problems (caller zeroes it)
@@ -150,6 +152,8 @@ struct LmState {
   double* ph;             // [B][ld] p_h of the SVD-free path
   int* active_count;      // [1] problems that need another evaluation
   int* active_list;       // [2][B] their indices, compacted (list r & 1 feeds evaluation r)
+  const int* path;        // optional [B]: != 0 -> the problem's Newton systems are factored by QR,
+                          // 0 -> by Cholesky of the modified Gram (nullptr: QR for all)
   int round;              // evaluation number of this launch (host-set)
 };
 hipError_t launch_lm_gate(const LmState& lm, int enable, hipStream_t s);

@@ -25,7 +25,7 @@ namespace blsq {
 static constexpr int GR_NT = 512;
 static constexpr int GR_NW = GR_NT / WAVE;
 static constexpr int GR_RC = 32;          // rows per staged chunk (8 MFMA k-steps)
-static constexpr double GRAM_SMIN = 0.2;  // lower limit for the pivots / sigma_min estimate of R'
+static constexpr double GRAM_SMIN = 0.1;  // lower limit for the pivots / sigma_min estimate of R'
 
 template <class K>
 static hipError_t gram_grant_lds(K kernel, size_t bytes, std::atomic<size_t>* granted_dev) {
@@ -248,6 +248,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
     if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
     return;
   }
+  if (a.skip_path && a.skip_path[b] != 0) return;
   const double* Gs = a.Gsrc + (long)b * NPAD * NPAD;    // source Gram (may alias the output)
   double* Gb = a.G + (long)b * NPAD * NPAD;             // output triangle
   double* dl = sh;                 // [NPAD] equilibration 1 / sqrt(h_jj)
@@ -287,7 +288,10 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
   if (tid == 0) pminsh = 1.0;
   __syncthreads();
   if (bad) {                                            // uniform: hand the problem to the QR tree
-    if (tid == 0 && a.fb_mask) { a.fb_mask[b] = N; atomicAdd(a.fail_count, 1); }
+    if (tid == 0 && a.fb_mask) {
+      a.fb_mask[b] = N; atomicAdd(a.fail_count, 1);
+      if (a.path_out) a.path_out[b] = N;
+    }
     return;
   }
 
@@ -397,6 +401,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
   if (tid == 0 && a.fb_mask) {
     const bool fail = !(pminsh >= GRAM_SMIN * GRAM_SMIN);
     a.fb_mask[b] = fail ? N : 0;
+    if (a.path_out) a.path_out[b] = fail ? N : 0;
     if (fail) atomicAdd(a.fail_count, 1);
   }
 }
@@ -435,6 +440,7 @@ __global__ __launch_bounds__(TRI_NT) void gram_gate_kernel(GramCholArgs a) {
   }
   if (tid == 0 && !(smin >= GRAM_SMIN)) {
     a.fb_mask[b] = n + 1;
+    if (a.path_out) a.path_out[b] = n + 1;
     atomicAdd(a.fail_count, 1);
   }
 }
@@ -443,17 +449,19 @@ bool gram_supported(int m, int n) {
   const int NT = (n + 1 + 15) / 16;
   return NT <= 17 && m >= n && n >= 1;
 }
+// Row chunks of GRAM_CHUNK_ROWS rows whatever the batch size: the summation order of a problem's
+// Gram (and so every bit of its result) does not depend on how many problems share the launch.
+static constexpr int GRAM_CHUNK_ROWS = 2048;
 int gram_chunks(int B, int m) {
-  int c = (512 + B - 1) / B;
-  const int cap = m / 512;
-  if (c > cap) c = cap;
+  (void)B;
+  const int c = (m + GRAM_CHUNK_ROWS - 1) / GRAM_CHUNK_ROWS;
   return c < 1 ? 1 : c;
 }
 
 hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s) {
   GramArgs a = a_in;
   const int NT = (a.n + 1 + 15) / 16;
-  a.rows_per_chunk = ((a.m + chunks - 1) / chunks + GR_RC - 1) / GR_RC * GR_RC;
+  a.rows_per_chunk = chunks > 1 ? GRAM_CHUNK_ROWS : a.m;
   const size_t lds = sizeof(double) * 2 * GR_RC * (size_t)gram_ldx(NT);
   const int ntile = NT * (NT + 1) / 2;
 #define BLSQ_GRAM_LAUNCH(SL, CB)                                                              \

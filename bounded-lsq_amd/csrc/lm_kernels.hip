@@ -187,7 +187,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_start_kernel(LmState lm, const doub
     sc[SC_ALPHA] = alpha; sc[SC_LO] = lo; sc[SC_HI] = hi; sc[SC_PHI] = phi; sc[SC_DPHI] = dphi;
     sc[SC_DELTA] = Delta;
     st[ST_IT] = 0; st[ST_PHASE] = LM_EVAL; st[ST_NITER] = 0;
-    lm.sa[b] = sqrt(alpha); lm.ncols_lm[b] = n + 1;
+    lm.sa[b] = sqrt(alpha); lm.ncols_lm[b] = (!lm.path || lm.path[b] != 0) ? n + 1 : 0;   // QR launch mask
     lm.active_list[atomicAdd(lm.active_count, 1)] = b;          // list 0 feeds evaluation 0
   }
 }
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_update_kernel(LmState lm) {
     sc[SC_ALPHA] = alpha; sc[SC_LO] = lo; sc[SC_HI] = hi; sc[SC_PHI] = phi; sc[SC_DPHI] = dphi;
     st[ST_IT] = it; st[ST_PHASE] = next_phase; st[ST_NITER] = n_iter;
     lm.sa[b] = sqrt(alpha);
-    lm.ncols_lm[b] = (next_phase != LM_IDLE) ? n + 1 : 0;
+    lm.ncols_lm[b] = (next_phase != LM_IDLE && (!lm.path || lm.path[b] != 0)) ? n + 1 : 0;
     if (next_phase != LM_IDLE)
       lm.active_list[(long)((lm.round + 1) & 1) * lm.B + atomicAdd(lm.active_count, 1)] = b;
   }
