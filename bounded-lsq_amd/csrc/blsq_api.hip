@@ -1013,15 +1013,34 @@ int dog_after_triangle(blsq_dogbox_plan* p, int scale_mode) {
   hipError_t e = launch_dog_prep(p->st, scale_mode, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_dog_prep");
+  // triangle of [R[:, free] | c]: for a problem on the Gram path it is the Cholesky factor of the
+  // principal sub-matrix G[free ++ rhs, free ++ rhs] (a principal sub-matrix of the equilibrated
+  // Gram is at least as well conditioned: no new gate); the others take the QR of the compacted
+  // columns.  Per problem, as in TRF.
+  const bool own = p->tree.gram && p->tree.path_valid;
+  const int* path = own ? p->tree.gram_path() : nullptr;
+  if (own && p->tree.any_gram) {
+    GramCholArgs c{};
+    c.Gsrc = p->tree.gram_keep.as<double>(); c.G = p->st.X; c.NPAD = p->ld; c.n = p->n;
+    c.ncols_dev = p->st.ncols; c.gather = p->st.free_idx; c.stride_vec = p->ld;
+    c.skip_path = path;
+    ctx->begin(K_AUG_CHOL);
+    e = launch_gram_chol(c, p->B, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(free block)");
+  }
+  if (!own || p->tree.any_qr) {
   QrArgs q = p->tree.base_args();
   q.A = p->st.S; q.strideA = (long)p->ld * p->ld; q.ldA = p->ld; q.rowsA = p->n;
   q.F = nullptr; q.strideF = 0; q.ncols_dev = p->st.ncols;
+  q.require_path = path;
   q.rows_per_leaf = p->ld; q.RP = p->ld;
   q.Rout = p->st.X;
   ctx->begin(K_QR_AUG);
   e = launch_qr(q, 1, p->B, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_qr(free block)");
+  }
   int* gfast = p->gate_ints.as<int>();
   int* gmask = gfast + p->B;
   ctx->begin(K_LM_GATE);

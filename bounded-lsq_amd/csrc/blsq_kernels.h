@@ -16,6 +16,7 @@ struct QrArgs {
   long strideF;
   const int* ncols_dev;   // optional per-problem N; nullptr -> N
   const int* batch_list;  // optional compacted problem indices: workgroup y factors problem batch_list[y]
+  const int* require_path;  // optional [B]: problems with require_path[b] == 0 are skipped (they took the Gram path)
   int N;                  // columns to factor (incl. the rhs column if any)
   int rows_per_leaf;      // source rows per leaf (workgroup)
   int RP;                 // padded leaf rows (multiple of 16, >= NPAD)
@@ -73,6 +74,10 @@ struct GramCholArgs {
   const double* diag_sqrt;   // [B]
   long stride_vec;
   const int* batch_list;  // optional compacted problem indices (grid = their number)
+  // optional principal sub-matrix (dogbox: free columns ++ rhs): H = Gsrc[idx, idx] with
+  // idx = gather[b][0 .. N_b-2] ++ [n], N_b = ncols_dev[b] (0: nothing to do); gather is increasing
+  const int* ncols_dev;   // [B]
+  const int* gather;      // [B][stride_vec]
   const int* skip_path;   // optional [B]: problems with skip_path[b] != 0 are skipped (they are on the QR path)
   int* path_out;          // optional [B] out (refreshed problems only): n + 1 = Householder tree, 0 = Gram
   const int* mask;        // optional, as above

@@ -243,12 +243,20 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane >> 4, lc = lane & 15;
-  const int n = a.n, N = n + 1, NPAD = a.NPAD, NT = NPAD / 16;
+  const int NPAD = a.NPAD;
   if (a.mask && a.mask[b] <= 1) {
     if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
     return;
   }
   if (a.skip_path && a.skip_path[b] != 0) return;
+  // columns of this problem: all n (+ rhs), or the gathered free columns (+ rhs)
+  const int N = a.ncols_dev ? a.ncols_dev[b] : a.n + 1;
+  if (N <= 1) return;
+  const int n = N - 1;
+  const int NT = (N + 15) / 16;
+  const int* gidx = a.gather ? a.gather + (long)b * a.stride_vec : nullptr;
+  // source row / column of H's index i  (the rhs is the source's column a.n)
+  auto src = [&](int i) -> int { return gidx ? (i < n ? gidx[i] : a.n) : i; };
   const double* Gs = a.Gsrc + (long)b * NPAD * NPAD;    // source Gram (may alias the output)
   double* Gb = a.G + (long)b * NPAD * NPAD;             // output triangle
   double* dl = sh;                 // [NPAD] equilibration 1 / sqrt(h_jj)
@@ -266,7 +274,8 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
     const double cs = (csv && j < n) ? csv[j] : 1.0;
     const double ej = (edv && j < n) ? edv[j] : 0.0;
     const double add = (j < n) ? fma(ej, ej, sa * sa) : 0.0;
-    const double g = fma(Gs[(long)j * NPAD + j] * cs, cs, add);
+    const int sj_ = (j < N) ? src(j) : j;
+    const double g = (j < N) ? fma(Gs[(long)sj_ * NPAD + sj_] * cs, cs, add) : 0.0;
     const bool okc = (g > 0.0) && is_finite(g);
     if (j < n && !okc) bad = 1;
     double d = 1.0, s = 1.0;
@@ -309,7 +318,13 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int row = 16 * kb + lr + 4 * g;
-          double v = Gs[(long)row * NPAD + 16 * j + lc] * sc[row] * scj;
+          const int col = 16 * j + lc;
+          double v = 0.0;
+          if (row < N && col < N) {
+            int sr_ = src(row), sc_ = src(col);
+            if (sr_ > sc_) { const int t_ = sr_; sr_ = sc_; sc_ = t_; }   // symmetric: stay in the upper tiles
+            v = Gs[(long)sr_ * NPAD + sc_] * sc[row] * scj;
+          }
           if (j == kb && lr + 4 * g == lc) v += td[row];
           S[u][g] = v;
         }
@@ -397,6 +412,12 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
       }
     }
     __syncthreads();
+  }
+  if (16 * NT < NPAD) {                                  // sub-matrix: the rest of the slot is zero
+    for (int r = w; r < NPAD; r += GR_NW) {
+      const int c0 = (r < 16 * NT) ? 16 * NT : (r & ~15);
+      for (int c = c0 + lane; c < NPAD; c += WAVE) Gb[(long)r * NPAD + c] = 0.0;
+    }
   }
   if (tid == 0 && a.fb_mask) {
     const bool fail = !(pminsh >= GRAM_SMIN * GRAM_SMIN);
