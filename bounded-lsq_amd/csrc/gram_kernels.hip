@@ -15,6 +15,7 @@
 // handed to the Householder tree (QrTree::run) through a launch mask, exactly as before.
 // Non-finite input, zero columns, rank deficiency and m < n all fail the gate by construction.
 #include <atomic>
+#include <stdlib.h>
 
 #include "blsq_device.h"
 #include "blsq_kernels.h"
@@ -204,6 +205,81 @@ __global__ __launch_bounds__(GR_NT, (SLOTS <= 8 ? 4 : 2)) void gram_kernel(GramA
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         G[(long)(ti[t] + lr + 4 * g) * a.NPAD + tj[t] + lc] = acc[t][g];
+    }
+  }
+}
+
+// ---- narrow problems (NT <= 5 column tiles): no LDS staging ------------------------------------
+// The MFMA operand fragment of column tile c at k-step s is X[4 s + lr][16 c + lc]: 16 lanes read
+// 128 contiguous bytes of a row — a coalesced global load straight into the operand register.
+// So with few column tiles every wave takes its own k-steps (4 rows each, wave w: k-steps w, w + 8,
+// ...) for ALL output tiles, loads the NT fragments of several k-steps ahead, and never meets the
+// other waves until the final, fixed-order reduction of the eight partial Grams through LDS.
+template <int NTT>
+__global__ __launch_bounds__(GR_NT, (NTT <= 2 ? 4 : 2)) void gram_direct_kernel(GramArgs a) {
+  constexpr int NTILE = NTT * (NTT + 1) / 2;
+  constexpr int KU = (NTT <= 2) ? 8 : 4;                // k-steps in flight per wave
+  extern __shared__ double lds[];                       // [GR_NW][256]
+  const int b = blockIdx.y;
+  if (a.mask && a.mask[b] <= 1) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane >> 4, lc = lane & 15;
+  const int n = a.n;
+  const int r_lo = blockIdx.x * a.rows_per_chunk;
+  int r_hi = r_lo + a.rows_per_chunk;
+  if (r_hi > a.m) r_hi = a.m;
+  const double* Jb = a.J + (long)b * a.strideJ;
+  const double* Fb = a.F + (long)b * a.strideF;
+  v4d acc[NTILE];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+  const int last = r_hi > r_lo ? r_hi - 1 : r_lo;
+  for (int r0 = r_lo + 4 * w; r0 < r_hi; r0 += 4 * GR_NW * KU) {
+    double fr[KU][NTT];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int row = r0 + 4 * GR_NW * u + lr;
+      const int rc = row < r_hi ? row : last;
+#pragma unroll
+      for (int c = 0; c < NTT; ++c) {
+        const int col = 16 * c + lc;
+        // (clamped unconditional loads, select afterwards; the rhs f is column n)
+        const double* ptr = (col < n) ? Jb + (long)rc * a.ldJ + col : Fb + rc;
+        const double v = __builtin_nontemporal_load(ptr);
+        fr[u][c] = (row < r_hi && col <= n) ? v : 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      int t = 0;
+#pragma unroll
+      for (int i = 0; i < NTT; ++i)
+#pragma unroll
+        for (int j = i; j < NTT; ++j, ++t) acc[t] = gmfma(fr[u][i], fr[u][j], acc[t]);
+    }
+  }
+  // cross-wave reduction, tile by tile through a 16 KB LDS buffer (fixed order: deterministic)
+  double* G = a.G + ((long)b * gridDim.x + blockIdx.x) * (long)a.NPAD * a.NPAD;
+  const int NT = (n + 1 + 15) / 16;
+  {
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < NTT; ++i) {
+#pragma unroll
+      for (int j = i; j < NTT; ++j, ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) lds[w * 256 + g * 64 + lane] = acc[t][g];
+        __syncthreads();
+        if (tid < 256 && j < NT) {
+          double sum = 0.0;
+#pragma unroll
+          for (int ww = 0; ww < GR_NW; ++ww) sum += lds[ww * 256 + tid];
+          const int g = tid >> 6, ln = tid & 63;
+          G[(long)(16 * i + (ln >> 4) + 4 * g) * a.NPAD + 16 * j + (ln & 15)] = sum;
+        }
+        __syncthreads();
+      }
     }
   }
 }
@@ -492,6 +568,27 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s) {
     if (ge != hipSuccess) return ge;                                                          \
     hipLaunchKernelGGL((gram_kernel<SL, CB>), dim3(chunks, B), dim3(GR_NT), lds, s, a);       \
   } while (0)
+#define BLSQ_GRAM_DIRECT(NTT)                                                                 \
+  do {                                                                                        \
+    const size_t dl_ = sizeof(double) * GR_NW * 256;                                          \
+    static std::atomic<size_t> granted[64];                                                   \
+    hipError_t ge = gram_grant_lds(gram_direct_kernel<NTT>, dl_, granted);                    \
+    if (ge != hipSuccess) return ge;                                                          \
+    hipLaunchKernelGGL((gram_direct_kernel<NTT>), dim3(chunks, B), dim3(GR_NT), dl_, s, a);   \
+    return hipGetLastError();                                                                 \
+  } while (0)
+  {
+    const char* env = getenv("BLSQ_GRAM_DIRECT_MAX_NT");     // tuning / tests: 0 disables
+    const int dmax = env ? atoi(env) : 4;                      // measured: direct wins up to 4 column tiles (n <= 62)
+    if (NT <= dmax) {
+      if (NT <= 1) BLSQ_GRAM_DIRECT(1);
+      else if (NT == 2) BLSQ_GRAM_DIRECT(2);
+      else if (NT == 3) BLSQ_GRAM_DIRECT(3);
+      else if (NT == 4) BLSQ_GRAM_DIRECT(4);
+      else if (NT == 5) BLSQ_GRAM_DIRECT(5);
+    }
+  }
+#undef BLSQ_GRAM_DIRECT
   const int ncb = (a.n + 63) / 64;
   const int per = (ntile + GR_NW - 1) / GR_NW;          // tile slots a wave needs
   if (per <= 4) {                                       // n <= 111
