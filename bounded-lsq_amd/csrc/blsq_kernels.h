@@ -74,6 +74,7 @@ struct GramCholArgs {
   const double* diag_sqrt;   // [B]
   long stride_vec;
   const int* batch_list;  // optional compacted problem indices (grid = their number)
+  int count;              // problems of this launch (set by launch_gram_chol)
   // optional principal sub-matrix (dogbox: free columns ++ rhs): H = Gsrc[idx, idx] with
   // idx = gather[b][0 .. N_b-2] ++ [n], N_b = ncols_dev[b] (0: nothing to do); gather is increasing
   const int* ncols_dev;   // [B]

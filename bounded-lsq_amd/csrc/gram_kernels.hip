@@ -311,13 +311,31 @@ __global__ void gram_reduce_kernel(const double* Gpart, int chunks, int NPAD, do
 // whose Cholesky factor is the triangle of [R D | c; E | 0] (and of [R_aug; sqrt(alpha) I]).  With
 // C = equil(G):  equil(H) = Theta^1/2 C Theta^1/2 + (I - Theta),  0 < Theta <= I diagonal, so its
 // extreme eigenvalues lie inside those of C: a problem that passed the gate on C needs no new one.
+// NWP waves work on one problem: 8 (a whole workgroup; any size) or 1 (N <= 80: eight problems per
+// workgroup, no workgroup barrier at all — the 16x16 chain of one problem overlaps the MFMAs of
+// the others on the same SIMD, and sixteen instead of two problems are resident per CU).
+template <int NWP>
 __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
-  extern __shared__ double sh[];
+  constexpr int PT = WAVE * NWP;                        // threads per problem
+  constexpr int UMAX = (NWP == 8) ? 3 : 5;              // tiles of a row block per wave
+  constexpr int PPW = GR_NW / NWP;                      // problems per workgroup
+  extern __shared__ double sh_all[];
   __shared__ double red[32];
-  __shared__ double pminsh;
-  const int b = a.batch_list ? a.batch_list[blockIdx.x] : (int)blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __shared__ double pmin_all[GR_NW];
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int pslot = wv / NWP;                           // problem slot inside the workgroup
+  const int pidx = (int)blockIdx.x * PPW + pslot;
+  if (pidx >= a.count) return;                          // (NWP == 1 only: wave-uniform)
+  const int b = a.batch_list ? a.batch_list[pidx] : pidx;
+  const int tid = (int)threadIdx.x % PT, lane = tid & 63;
+  const int w = wv % NWP;
+  double* sh = sh_all + (size_t)pslot * (4 * (size_t)a.NPAD + 512);
+  double& pminsh = pmin_all[pslot];
+  // synchronisation among the threads of one problem
+  auto psync = [&]() {
+    if (NWP == 8) __syncthreads();
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // one wave: program order
+  };
   const int lr = lane >> 4, lc = lane & 15;
   const int NPAD = a.NPAD;
   if (a.mask && a.mask[b] <= 1) {
@@ -346,7 +364,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
   const double sa = a.diag_sqrt ? a.diag_sqrt[b] : 0.0;
   // 0. column scales from the diagonal of H
   int bad = 0;
-  for (int j = tid; j < NPAD; j += GR_NT) {
+  for (int j = tid; j < NPAD; j += PT) {
     const double cs = (csv && j < n) ? csv[j] : 1.0;
     const double ej = (edv && j < n) ? edv[j] : 0.0;
     const double add = (j < n) ? fma(ej, ej, sa * sa) : 0.0;
@@ -365,13 +383,13 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
     if (a.dsc) a.dsc[(long)b * NPAD + j] = d;
   }
   // strictly lower tiles are part of the triangle's image: zero
-  for (int r = 16 + w; r < NPAD; r += GR_NW) {
+  for (int r = 16 + w; r < NPAD; r += NWP) {
     const int cend = r & ~15;
     for (int c = lane; c < cend; c += WAVE) Gb[(long)r * NPAD + c] = 0.0;
   }
-  bad = block_or(bad, red);
+  if (NWP == 8) bad = block_or(bad, red); else bad = __any(bad);
   if (tid == 0) pminsh = 1.0;
-  __syncthreads();
+  psync();
   if (bad) {                                            // uniform: hand the problem to the QR tree
     if (tid == 0 && a.fb_mask) {
       a.fb_mask[b] = N; atomicAdd(a.fail_count, 1);
@@ -382,11 +400,11 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
 
   for (int kb = 0; kb < NT; ++kb) {
     // ---- A. Schur complements of this row block (tile j = kb + w + 8 u) ----
-    v4d S[3];
+    v4d S[UMAX];
     const double dk = dl[16 * kb + lc];
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int j = kb + w + GR_NW * u;
+    for (int u = 0; u < UMAX; ++u) {
+      const int j = kb + w + NWP * u;
       S[u] = v4d{0.0, 0.0, 0.0, 0.0};
       if (j < NT) {
         const double dj = dl[16 * j + lc];
@@ -421,7 +439,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) Dt[(lr + 4 * g) * 16 + lc] = S[0][g];
     }
-    __syncthreads();
+    psync();
     // ---- B. wave 0: Cholesky of the diagonal tile and its inverse ----
     if (w == 0) {
       const int jc = lc;
@@ -462,11 +480,11 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
       }
       if (lane == 0) pminsh = pmin;
     }
-    __syncthreads();
+    psync();
     // ---- C. R'_{kb,j} = R'_{kb,kb}^-T S_j, stored as R = R' D^-1 ----
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int j = kb + w + GR_NW * u;
+    for (int u = 0; u < UMAX; ++u) {
+      const int j = kb + w + NWP * u;
       if (j < NT) {
         v4d X = {0.0, 0.0, 0.0, 0.0};
         if (j == kb) {
@@ -487,10 +505,10 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
         }
       }
     }
-    __syncthreads();
+    psync();
   }
   if (16 * NT < NPAD) {                                  // sub-matrix: the rest of the slot is zero
-    for (int r = w; r < NPAD; r += GR_NW) {
+    for (int r = w; r < NPAD; r += NWP) {
       const int c0 = (r < 16 * NT) ? 16 * NT : (r & ~15);
       for (int c = c0 + lane; c < NPAD; c += WAVE) Gb[(long)r * NPAD + c] = 0.0;
     }
@@ -610,9 +628,16 @@ hipError_t launch_gram_reduce(const double* Gpart, int chunks, int NPAD, double*
                      Gpart, chunks, NPAD, Gout, mask);
   return hipGetLastError();
 }
-hipError_t launch_gram_chol(const GramCholArgs& a, int B, hipStream_t s) {
-  const size_t lds = sizeof(double) * (4 * (size_t)a.NPAD + 512);
-  hipLaunchKernelGGL(gram_chol_kernel, dim3(B), dim3(GR_NT), lds, s, a);
+hipError_t launch_gram_chol(const GramCholArgs& a_in, int B, hipStream_t s) {
+  GramCholArgs a = a_in;
+  a.count = B;
+  const size_t per = sizeof(double) * (4 * (size_t)a.NPAD + 512);
+  if (a.NPAD <= 80) {                                   // one wave per problem, eight per workgroup
+    hipLaunchKernelGGL(gram_chol_kernel<1>, dim3((B + GR_NW - 1) / GR_NW), dim3(GR_NT), per * GR_NW,
+                       s, a);
+  } else {
+    hipLaunchKernelGGL(gram_chol_kernel<8>, dim3(B), dim3(GR_NT), per, s, a);
+  }
   return hipGetLastError();
 }
 hipError_t launch_gram_gate(const GramCholArgs& a, int B, hipStream_t s) {
