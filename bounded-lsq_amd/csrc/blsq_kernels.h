@@ -62,6 +62,7 @@ struct GramArgs {
   double* G;              // [B][chunks][NPAD*NPAD] upper tile blocks
   const int* mask;        // optional: problems with mask[b] <= 1 are skipped
   int rows_per_chunk;     // set by launch_gram
+  int rhs_valu;           // set by launch_gram: J^T f / f^T f accumulated by the vector ALUs
 };
 struct GramCholArgs {
   const double* Gsrc;     // [B][NPAD*NPAD] Gram (upper tile blocks); may alias G (in place)

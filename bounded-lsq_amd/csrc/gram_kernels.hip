@@ -72,7 +72,12 @@ __global__ __launch_bounds__(GR_NT, (SLOTS <= 8 ? 4 : 2)) void gram_kernel(GramA
   const int lr = lane >> 4, lc = lane & 15;
   const int n = a.n, N = n + 1, NT = (N + 15) / 16;
   const int LDX = gram_ldx(NT);
-  const int ntile = NT * (NT + 1) / 2;
+  // The MFMA tiles cover J^T J only.  The rhs column (J^T f, f^T f) would cost a whole tile column
+  // — 17 of 153 tiles at n = 256 — for one useful column per tile; it is accumulated beside the
+  // MFMA stream by the vector ALUs from the same staged rows instead (32 FMAs per thread and chunk).
+  // (Only where that saves a tile slot per wave — a.rhs_valu, decided by launch_gram.)
+  const int NTJ = a.rhs_valu ? (n + 15) / 16 : NT;
+  const int ntile = NTJ * (NTJ + 1) / 2;
   const int per = (ntile + GR_NW - 1) / GR_NW;
   // rows of this chunk
   const int r_lo = blockIdx.x * a.rows_per_chunk;
@@ -88,16 +93,16 @@ __global__ __launch_bounds__(GR_NT, (SLOTS <= 8 ? 4 : 2)) void gram_kernel(GramA
   bool tv[SLOTS];
   {
     int i = 0, rem = w * per;
-    while (i < NT && rem >= NT - i) { rem -= NT - i; ++i; }
+    while (i < NTJ && rem >= NTJ - i) { rem -= NTJ - i; ++i; }
     int j = i + rem;
 #pragma unroll
     for (int t = 0; t < SLOTS; ++t) {
-      const bool valid = (t < per) && (i < NT);
+      const bool valid = (t < per) && (i < NTJ);
       tv[t] = valid;
       ti[t] = valid ? 16 * i : 0;
       tj[t] = valid ? 16 * j : 0;
       ++j;
-      if (j >= NT) { ++i; j = i; }
+      if (j >= NTJ) { ++i; j = i; }
     }
   }
 
@@ -138,6 +143,7 @@ __global__ __launch_bounds__(GR_NT, (SLOTS <= 8 ? 4 : 2)) void gram_kernel(GramA
 #pragma unroll
   for (int t = 0; t < SLOTS; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
 
+  double gf0 = 0.0, gf1 = 0.0;                          // partial (J^T f)_c / f^T f of this thread
   double* X0 = lds;
   double* X1 = lds + GR_RC * LDX;
   // padding columns (n, LDX) of both buffers are zero for the whole pass
@@ -156,6 +162,21 @@ __global__ __launch_bounds__(GR_NT, (SLOTS <= 8 ? 4 : 2)) void gram_kernel(GramA
     const double* X = (cidx & 1) ? X1 : X0;
     double* Xn = (cidx & 1) ? X0 : X1;
     const unsigned xb = lds_addr(X) + 8u * (unsigned)(lr * LDX + lc);
+    // rhs column: thread t owns column t & 255 over half of the chunk's rows; columns 256..n (and
+    // f^T f when n >= 256) go to the first threads over all rows
+    if (a.rhs_valu) {
+      const int c0 = tid & 255, h0 = (tid >> 8) * (GR_RC / 2);
+      if (c0 <= n) {
+#pragma unroll
+        for (int r = 0; r < GR_RC / 2; ++r)
+          gf0 = fma(X[(h0 + r) * LDX + c0], X[(h0 + r) * LDX + n], gf0);
+      }
+      const int c1 = 256 + tid;
+      if (c1 <= n) {
+#pragma unroll
+        for (int r = 0; r < GR_RC; ++r) gf1 = fma(X[r * LDX + c1], X[r * LDX + n], gf1);
+      }
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #if !defined(GRAM_EXP) || (GRAM_EXP != 2 && GRAM_EXP != 3)
@@ -206,6 +227,17 @@ __global__ __launch_bounds__(GR_NT, (SLOTS <= 8 ? 4 : 2)) void gram_kernel(GramA
       for (int g = 0; g < 4; ++g)
         G[(long)(ti[t] + lr + 4 * g) * a.NPAD + tj[t] + lc] = acc[t][g];
     }
+  }
+  if (!a.rhs_valu) return;
+  // rhs column of the Gram: the two row halves of a column, summed in a fixed order
+  lds[tid] = gf0;                                       // (the last chunk's barrier is behind us)
+  __syncthreads();
+  if (tid < 256 && tid <= n) G[(long)tid * a.NPAD + n] = lds[tid] + lds[tid + 256];
+  if (256 + tid <= n) G[(long)(256 + tid) * a.NPAD + n] = gf1;
+  // the rest of the rhs tile column of the slot: padding columns (n, 16 NT) stay zero
+  for (int e = tid; e < a.NPAD * (16 * NT - N); e += GR_NT) {
+    const int r = e / (16 * NT - N), c = N + e % (16 * NT - N);
+    if ((r >> 4) <= (c >> 4)) G[(long)r * a.NPAD + c] = 0.0;
   }
 }
 
@@ -578,7 +610,15 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s) {
   const int NT = (a.n + 1 + 15) / 16;
   a.rows_per_chunk = chunks > 1 ? GRAM_CHUNK_ROWS : a.m;
   const size_t lds = sizeof(double) * 2 * GR_RC * (size_t)gram_ldx(NT);
-  const int ntile = NT * (NT + 1) / 2;
+  // slot variant a wave needs for `nt` column tiles
+  auto slots_for = [](int nt) {
+    const int per_ = (nt * (nt + 1) / 2 + GR_NW - 1) / GR_NW;
+    return per_ <= 4 ? 4 : per_ <= 8 ? 8 : per_ <= 12 ? 12 : per_ <= 17 ? 17 : 20;
+  };
+  // the rhs column goes to the vector ALUs where that saves tile slots (n = 256: 20 -> 17)
+  a.rhs_valu = slots_for((a.n + 15) / 16) < slots_for(NT) ? 1 : 0;
+  const int NTJ = a.rhs_valu ? (a.n + 15) / 16 : NT;
+  const int ntile = NTJ * (NTJ + 1) / 2;
 #define BLSQ_GRAM_LAUNCH(SL, CB)                                                              \
   do {                                                                                        \
     static std::atomic<size_t> granted[64];                                                   \
@@ -615,6 +655,8 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s) {
     if (ncb <= 2) BLSQ_GRAM_LAUNCH(8, 2); else BLSQ_GRAM_LAUNCH(8, 3);
   } else if (per <= 12) {                               // n <= 207
     if (ncb <= 3) BLSQ_GRAM_LAUNCH(12, 3); else BLSQ_GRAM_LAUNCH(12, 4);
+  } else if (per <= 17) {                               // n <= 256
+    BLSQ_GRAM_LAUNCH(17, 4);
   } else {
     if (ncb <= 4) BLSQ_GRAM_LAUNCH(20, 4); else BLSQ_GRAM_LAUNCH(20, 5);
   }

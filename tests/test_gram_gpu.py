@@ -69,7 +69,11 @@ def _check(bl, P, Delta, kind="trf"):
 
 
 @pytest.mark.parametrize("B,m,n", [(6, 512, 64), (3, 2000, 256), (4, 1500, 128), (5, 300, 16),
-                                   (3, 700, 100), (2, 4096, 200), (3, 900, 271)])
+                                   (3, 700, 100), (2, 4096, 200), (3, 900, 271),
+                                   # n % 16 == 0 where the rhs column leaves the MFMA tiles
+                                   (2, 1000, 112), (2, 2100, 160), (2, 3000, 208), (2, 5000, 256),
+                                   # narrow: direct-from-global kernel, 1..4 column tiles
+                                   (4, 3000, 7), (4, 5000, 31), (3, 2500, 47), (3, 2200, 62)])
 def test_well_conditioned_batches_take_the_fast_path(bl, B, m, n):
     from bounded_lsq import _synth
     P = _synth.trf_batch(77 + n, B, m, n)
