@@ -553,6 +553,229 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
   }
 }
 
+// ---- right-looking variant: the whole (scaled) matrix lives in accumulators ----------------------
+// The NT (NT + 1) / 2 <= 153 upper tiles are dealt CYCLICALLY (row-major tile q -> wave q % 8, slot
+// q / 8) so that the shrinking trailing matrix stays balanced, and never leave the registers until
+// their row block is final.  Per row block kb: the diagonal tile goes through LDS to wave 0 for the
+// 16x16 Cholesky + inverse, the owners of the tiles (kb, j) solve them by MFMA and publish them in an
+// LDS row buffer, and every wave updates its own trailing tiles from that buffer — no global-memory
+// round trip inside the factorisation (the left-looking kernel above re-reads finished rows from L2).
+// Same arguments, same outputs, same gate bookkeeping as gram_chol_kernel.
+template <int SL>
+__global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) {
+  extern __shared__ double sh[];
+  __shared__ double red[32];
+  __shared__ double pminsh;
+  const int pidx = (int)blockIdx.x;
+  const int b = a.batch_list ? a.batch_list[pidx] : pidx;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane >> 4, lc = lane & 15;
+  const int NPAD = a.NPAD;
+  if (a.mask && a.mask[b] <= 1) {
+    if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
+    return;
+  }
+  if (a.skip_path && a.skip_path[b] != 0) return;
+  const int N = a.ncols_dev ? a.ncols_dev[b] : a.n + 1;
+  if (N <= 1) return;
+  const int n = N - 1;
+  const int NT = (N + 15) / 16;
+  const int* gidx = a.gather ? a.gather + (long)b * a.stride_vec : nullptr;
+  auto src = [&](int i) -> int { return gidx ? (i < n ? gidx[i] : a.n) : i; };
+  const double* Gs = a.Gsrc + (long)b * NPAD * NPAD;
+  double* Gb = a.G + (long)b * NPAD * NPAD;
+  double* dl = sh;                 // [NPAD]
+  double* sq = dl + NPAD;          // [NPAD]
+  double* sc = sq + NPAD;          // [NPAD]
+  double* td = sc + NPAD;          // [NPAD]
+  double* Dt = td + NPAD;          // [256]
+  double* Ri = Dt + 256;           // [256]
+  double* Rrow = Ri + 256;         // [NT][256] finished tiles of the current row block
+  const double* csv = a.colscale ? a.colscale + (long)b * a.stride_vec : nullptr;
+  const double* edv = a.diag_vec ? a.diag_vec + (long)b * a.stride_vec : nullptr;
+  const double sa = a.diag_sqrt ? a.diag_sqrt[b] : 0.0;
+  int bad = 0;
+  for (int j = tid; j < NPAD; j += GR_NT) {
+    const double cs = (csv && j < n) ? csv[j] : 1.0;
+    const double ej = (edv && j < n) ? edv[j] : 0.0;
+    const double add = (j < n) ? fma(ej, ej, sa * sa) : 0.0;
+    const int sj_ = (j < N) ? src(j) : j;
+    const double g = (j < N) ? fma(Gs[(long)sj_ * NPAD + sj_] * cs, cs, add) : 0.0;
+    const bool okc = (g > 0.0) && is_finite(g);
+    if (j < n && !okc) bad = 1;
+    double d = 1.0, s = 1.0;
+    if (j < N && okc) {
+      d = __builtin_amdgcn_rsq(g);
+      d = d * fma(-0.5 * g * d, d, 1.5);
+      d = d * fma(-0.5 * g * d, d, 1.5);
+      s = g * d;
+    }
+    dl[j] = d; sq[j] = s; sc[j] = cs * d; td[j] = add * d * d;
+    if (a.dsc) a.dsc[(long)b * NPAD + j] = d;
+  }
+  bad = block_or(bad, red);
+  if (tid == 0) pminsh = 1.0;
+  __syncthreads();
+  if (bad) {
+    if (tid == 0 && a.fb_mask) {
+      a.fb_mask[b] = N; atomicAdd(a.fail_count, 1);
+      if (a.path_out) a.path_out[b] = N;
+    }
+    return;
+  }
+  // ROLES: wave 0 only runs the 16x16 chains (its registers hold the column / inverse vectors, no
+  // tiles); waves 1..7 own the tiles.  Both loops pass the same three barriers per row block.
+  constexpr int NWK = GR_NW - 1;                        // worker waves
+  const int ntile = NT * (NT + 1) / 2;
+  if (w == 0) {
+    __syncthreads();                                    // (workers: all source reads done)
+    // zeros outside the factor (strictly lower tiles, everything beyond 16 NT in the sub-matrix
+    // use): written by this wave while the workers update, 16 rows per row block
+    auto zero_rows = [&](int r0, int r1) {
+      for (int r = r0; r < r1; ++r) {
+        const int cend = (r < 16 * NT) ? (r & ~15) : NPAD;
+        for (int c = lane; c < cend; c += WAVE) Gb[(long)r * NPAD + c] = 0.0;
+        if (r < 16 * NT)
+          for (int c = 16 * NT + lane; c < NPAD; c += WAVE) Gb[(long)r * NPAD + c] = 0.0;
+      }
+    };
+    double pmin = 1.0;
+    for (int kb = 0; kb < NT; ++kb) {
+      __syncthreads();                                  // a. diagonal tile is in Dt
+      const int jc = lc;
+      double col[TILE];
+#pragma unroll
+      for (int i = 0; i < TILE; ++i) col[i] = Dt[i * 16 + jc];
+      double pnv = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < TILE; ++kk) {
+        const double d = read_lane(col[kk], kk);
+        const bool live = (16 * kb + kk) < n;
+        if (live && !(d >= pmin)) pmin = d;
+        const bool pos = d > 1e-300;
+        const double ds = pos ? d : 1.0;
+        double ri = __builtin_amdgcn_rsq(ds);
+        ri = ri * fma(-0.5 * ds * ri, ri, 1.5);
+        ri = ri * fma(-0.5 * ds * ri, ri, 1.5);
+        if (!pos) ri = 0.0;
+        const double rkj = col[kk] * ri;
+        col[kk] = (jc >= kk) ? rkj : 0.0;
+        pnv = (jc == kk) ? ri : pnv;
+#pragma unroll
+        for (int i = kk + 1; i < TILE; ++i) col[i] = fma(-read_lane(rkj, i), rkj, col[i]);
+      }
+      double uu[TILE];
+#pragma unroll
+      for (int i = TILE - 1; i >= 0; --i) {
+        double ac_ = (i == jc) ? 1.0 : 0.0;
+#pragma unroll
+        for (int l = i + 1; l < TILE; ++l) ac_ = fma(-read_lane(col[i], l), uu[l], ac_);
+        uu[i] = ac_ * read_lane(pnv, i);
+      }
+      if (lane < TILE) {
+#pragma unroll
+        for (int i = 0; i < TILE; ++i) { Dt[i * 16 + jc] = col[i]; Ri[i * 16 + jc] = uu[i]; }
+      }
+      __syncthreads();                                  // b. R'_kk and its inverse are in LDS
+      __syncthreads();                                  // c. (workers published the row block)
+      zero_rows(16 * kb, 16 * kb + 16);
+    }
+    zero_rows(16 * NT, NPAD);
+    if (lane == 0) pminsh = pmin;
+  } else {
+    // tile table (cyclic over the worker waves: the shrinking trailing matrix stays balanced) and
+    // the scaled source tiles -> accumulators; the source may alias the output, so everything is
+    // read before anything is written
+    const int ww = w - 1;
+    int ti[SL], tj[SL];
+    v4d acc[SL];
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+      int q = ww + NWK * t;
+      const bool valid = q < ntile;
+      int i = 0;
+      while (valid && q >= NT - i) { q -= NT - i; ++i; }
+      ti[t] = valid ? i : -1;
+      tj[t] = valid ? i + q : -1;
+      acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+      if (valid) {
+        const int j = tj[t];
+        const double scj = sc[16 * j + lc];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * i + lr + 4 * g, col = 16 * j + lc;
+          double v = 0.0;
+          if (row < N && col < N) {
+            int sr_ = src(row), sc_ = src(col);
+            if (sr_ > sc_) { const int t_ = sr_; sr_ = sc_; sc_ = t_; }
+            v = Gs[(unsigned)(sr_ * NPAD + sc_)] * sc[row] * scj;
+          }
+          if (j == i && lr + 4 * g == lc) v += td[row];
+          acc[t][g] = v;
+        }
+      }
+    }
+    __syncthreads();                                    // all source reads done before the first store
+    for (int kb = 0; kb < NT; ++kb) {
+      // a. the diagonal tile -> LDS
+#pragma unroll
+      for (int t = 0; t < SL; ++t) {
+        if (ti[t] == kb && tj[t] == kb) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) Dt[(lr + 4 * g) * 16 + lc] = acc[t][g];
+        }
+      }
+      __syncthreads();
+      __syncthreads();                                  // b. wave 0 finished the chain
+      // c. the row block: R'_{kb,j} = R'_{kb,kb}^-T S_j -> LDS row buffer and (unscaled) to memory
+#pragma unroll
+      for (int t = 0; t < SL; ++t) {
+        if (ti[t] == kb) {
+          const int j = tj[t];
+          v4d X = {0.0, 0.0, 0.0, 0.0};
+          if (j == kb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) X[g] = Dt[(lr + 4 * g) * 16 + lc];
+          } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) X = gmfma(Ri[(4 * s + lr) * 16 + lc], acc[t][s], X);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) Rrow[j * 256 + (lr + 4 * g) * 16 + lc] = X[g];
+          }
+          const double sj = sq[16 * j + lc];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row = 16 * kb + lr + 4 * g;
+            const int colg = 16 * j + lc;
+            double val = X[g] * sj;
+            if (row >= n || row > colg || colg > n) val = 0.0;
+            Gb[(unsigned)(row * NPAD + colg)] = val;
+          }
+        }
+      }
+      __syncthreads();
+      // d. trailing update of this wave's tiles
+#pragma unroll
+      for (int t = 0; t < SL; ++t) {
+        if (ti[t] > kb) {
+          const double* Ra = Rrow + ti[t] * 256 + lr * 16 + lc;
+          const double* Rb = Rrow + tj[t] * 256 + lr * 16 + lc;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[t] = gmfma(-Ra[64 * s], Rb[64 * s], acc[t]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0 && a.fb_mask) {
+    const bool fail = !(pminsh >= GRAM_SMIN * GRAM_SMIN);
+    a.fb_mask[b] = fail ? N : 0;
+    if (a.path_out) a.path_out[b] = fail ? N : 0;
+    if (fail) atomicAdd(a.fail_count, 1);
+  }
+}
+
 // ---- conditioning gate: inverse power iteration on R' = R D ---------------------------------
 __global__ __launch_bounds__(TRI_NT) void gram_gate_kernel(GramCholArgs a) {
   extern __shared__ double sh[];
@@ -678,7 +901,22 @@ hipError_t launch_gram_chol(const GramCholArgs& a_in, int B, hipStream_t s) {
     hipLaunchKernelGGL(gram_chol_kernel<1>, dim3((B + GR_NW - 1) / GR_NW), dim3(GR_NT), per * GR_NW,
                        s, a);
   } else {
-    hipLaunchKernelGGL(gram_chol_kernel<8>, dim3(B), dim3(GR_NT), per, s, a);
+    // Right-looking register variant: 0.22 ms per problem on a CU of its own against 0.27 ms for
+    // the left-looking kernel, but one workgroup per CU instead of two — so it serves the launches
+    // that cannot fill the CUs twice anyway (the Newton rounds), the left-looking one the rest.
+    // BLSQ_CHOL_RL = 0 / 1 forces either.
+    static const int rl_env = [] { const char* e = getenv("BLSQ_CHOL_RL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    constexpr int ncu = 256;                           // MI355X: 8 XCDs x 32 CUs
+    const bool rl = rl_env >= 0 ? rl_env != 0 : B <= ncu;
+    if (rl) {
+      const size_t lds = per + sizeof(double) * 256 * (size_t)(a.NPAD / 16);
+      static std::atomic<size_t> granted[64];
+      hipError_t ge = gram_grant_lds(gram_chol_rl_kernel<22>, lds, granted);
+      if (ge != hipSuccess) return ge;
+      hipLaunchKernelGGL(gram_chol_rl_kernel<22>, dim3(B), dim3(GR_NT), lds, s, a);
+    } else {
+      hipLaunchKernelGGL(gram_chol_kernel<8>, dim3(B), dim3(GR_NT), per, s, a);
+    }
   }
   return hipGetLastError();
 }
