@@ -566,6 +566,7 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
   extern __shared__ double sh[];
   __shared__ double red[32];
   __shared__ double pminsh;
+  __shared__ int flagsh;                                // last diagonal tile handed to wave 0
   const int pidx = (int)blockIdx.x;
   const int b = a.batch_list ? a.batch_list[pidx] : pidx;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -615,7 +616,7 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
     if (a.dsc) a.dsc[(long)b * NPAD + j] = d;
   }
   bad = block_or(bad, red);
-  if (tid == 0) pminsh = 1.0;
+  if (tid == 0) { pminsh = 1.0; flagsh = 0; }
   __syncthreads();
   if (bad) {
     if (tid == 0 && a.fb_mask) {
@@ -625,24 +626,31 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
     return;
   }
   // ROLES: wave 0 only runs the 16x16 chains (its registers hold the column / inverse vectors, no
-  // tiles); waves 1..7 own the tiles.  Both loops pass the same three barriers per row block.
+  // tiles); waves 1..7 own the tiles.  LOOKAHEAD: in the trailing update of row block kb the owner
+  // of the next diagonal tile updates it first, puts it into LDS and raises a flag; wave 0 starts
+  // the chain of block kb + 1 on that flag while the other tiles are still being updated.  Both
+  // loops pass the same two barriers per row block.
   constexpr int NWK = GR_NW - 1;                        // worker waves
   const int ntile = NT * (NT + 1) / 2;
+  // zeros outside the factor: strictly lower tiles, and everything beyond 16 NT (sub-matrix use)
+  auto zero_fill = [&]() {
+    for (int r = w; r < NPAD; r += GR_NW) {
+      const int cend = (r < 16 * NT) ? (r & ~15) : NPAD;
+      for (int c = lane; c < cend; c += WAVE) Gb[(unsigned)(r * NPAD + c)] = 0.0;
+      if (r < 16 * NT)
+        for (int c = 16 * NT + lane; c < NPAD; c += WAVE) Gb[(unsigned)(r * NPAD + c)] = 0.0;
+    }
+  };
   if (w == 0) {
-    __syncthreads();                                    // (workers: all source reads done)
-    // zeros outside the factor (strictly lower tiles, everything beyond 16 NT in the sub-matrix
-    // use): written by this wave while the workers update, 16 rows per row block
-    auto zero_rows = [&](int r0, int r1) {
-      for (int r = r0; r < r1; ++r) {
-        const int cend = (r < 16 * NT) ? (r & ~15) : NPAD;
-        for (int c = lane; c < cend; c += WAVE) Gb[(long)r * NPAD + c] = 0.0;
-        if (r < 16 * NT)
-          for (int c = 16 * NT + lane; c < NPAD; c += WAVE) Gb[(long)r * NPAD + c] = 0.0;
-      }
-    };
+    __syncthreads();                                    // X: workers have read the source, Dt holds tile (0, 0)
+    zero_fill();
     double pmin = 1.0;
     for (int kb = 0; kb < NT; ++kb) {
-      __syncthreads();                                  // a. diagonal tile is in Dt
+      if (kb > 0) {                                     // wait for the updated diagonal tile kb
+        while (__hip_atomic_load(&flagsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < kb)
+          __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+      }
       const int jc = lc;
       double col[TILE];
 #pragma unroll
@@ -677,11 +685,9 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
 #pragma unroll
         for (int i = 0; i < TILE; ++i) { Dt[i * 16 + jc] = col[i]; Ri[i * 16 + jc] = uu[i]; }
       }
-      __syncthreads();                                  // b. R'_kk and its inverse are in LDS
-      __syncthreads();                                  // c. (workers published the row block)
-      zero_rows(16 * kb, 16 * kb + 16);
+      __syncthreads();                                  // B: R'_kk and its inverse are in LDS
+      __syncthreads();                                  // C: (workers published the row block)
     }
-    zero_rows(16 * NT, NPAD);
     if (lane == 0) pminsh = pmin;
   } else {
     // tile table (cyclic over the worker waves: the shrinking trailing matrix stays balanced) and
@@ -714,20 +720,16 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
           if (j == i && lr + 4 * g == lc) v += td[row];
           acc[t][g] = v;
         }
-      }
-    }
-    __syncthreads();                                    // all source reads done before the first store
-    for (int kb = 0; kb < NT; ++kb) {
-      // a. the diagonal tile -> LDS
-#pragma unroll
-      for (int t = 0; t < SL; ++t) {
-        if (ti[t] == kb && tj[t] == kb) {
+        if (i == 0 && j == 0) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) Dt[(lr + 4 * g) * 16 + lc] = acc[t][g];
         }
       }
-      __syncthreads();
-      __syncthreads();                                  // b. wave 0 finished the chain
+    }
+    __syncthreads();                                    // X: all source reads done before the first store
+    zero_fill();
+    for (int kb = 0; kb < NT; ++kb) {
+      __syncthreads();                                  // B: wave 0 finished the chain of block kb
       // c. the row block: R'_{kb,j} = R'_{kb,kb}^-T S_j -> LDS row buffer and (unscaled) to memory
 #pragma unroll
       for (int t = 0; t < SL; ++t) {
@@ -754,11 +756,23 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
           }
         }
       }
-      __syncthreads();
-      // d. trailing update of this wave's tiles
+      __syncthreads();                                  // C: the row block is in the LDS buffer
+      // d. trailing update: the next diagonal tile first (-> LDS, flag for wave 0), then the rest
 #pragma unroll
       for (int t = 0; t < SL; ++t) {
-        if (ti[t] > kb) {
+        if (ti[t] == kb + 1 && tj[t] == kb + 1) {
+          const double* Ra = Rrow + ti[t] * 256 + lr * 16 + lc;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[t] = gmfma(-Ra[64 * s], Ra[64 * s], acc[t]);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) Dt[(lr + 4 * g) * 16 + lc] = acc[t][g];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_store(&flagsh, kb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < SL; ++t) {
+        if (ti[t] > kb && !(ti[t] == kb + 1 && tj[t] == kb + 1)) {
           const double* Ra = Rrow + ti[t] * 256 + lr * 16 + lc;
           const double* Rb = Rrow + tj[t] * 256 + lr * 16 + lc;
 #pragma unroll
