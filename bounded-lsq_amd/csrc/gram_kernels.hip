@@ -480,6 +480,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
       for (int i = 0; i < TILE; ++i) col[i] = Dt[i * 16 + jc];
       double pmin = pminsh;
       double pnv = 0.0;                                 // lane k: 1 / R'[k][k]
+      double yy[TILE];
 #pragma unroll
       for (int kk = 0; kk < TILE; ++kk) {
         const double d = read_lane(col[kk], kk);
@@ -496,19 +497,20 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
         pnv = (jc == kk) ? ri : pnv;
 #pragma unroll
         for (int i = kk + 1; i < TILE; ++i) col[i] = fma(-read_lane(rkj, i), rkj, col[i]);
-      }
-      // inverse of the upper triangle, column jc (back substitution)
-      double uu[TILE];
+        // the inverse rides along: Y = R'^-T by forward substitution, row kk as soon as row kk of
+        // R' exists (lane c holds column c of Y = row c of R'^-1) — its sums are independent of the
+        // next pivot's rsq chain, so the two latency chains overlap instead of running back to back
+        double ay0 = (jc == kk) ? 1.0 : 0.0, ay1 = 0.0;
 #pragma unroll
-      for (int i = TILE - 1; i >= 0; --i) {
-        double acc = (i == jc) ? 1.0 : 0.0;
-#pragma unroll
-        for (int l = i + 1; l < TILE; ++l) acc = fma(-read_lane(col[i], l), uu[l], acc);
-        uu[i] = acc * read_lane(pnv, i);
+        for (int p = 0; p < kk; p += 2) {
+          ay0 = fma(-read_lane(col[p], kk), yy[p], ay0);
+          if (p + 1 < kk) ay1 = fma(-read_lane(col[p + 1], kk), yy[p + 1], ay1);
+        }
+        yy[kk] = (jc <= kk) ? (ay0 + ay1) * ri : 0.0;
       }
       if (lane < TILE) {
 #pragma unroll
-        for (int i = 0; i < TILE; ++i) { Dt[i * 16 + jc] = col[i]; Ri[i * 16 + jc] = uu[i]; }
+        for (int i = 0; i < TILE; ++i) { Dt[i * 16 + jc] = col[i]; Ri[jc * 16 + i] = yy[i]; }
       }
       if (lane == 0) pminsh = pmin;
     }
@@ -656,6 +658,7 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
 #pragma unroll
       for (int i = 0; i < TILE; ++i) col[i] = Dt[i * 16 + jc];
       double pnv = 0.0;
+      double yy[TILE];
 #pragma unroll
       for (int kk = 0; kk < TILE; ++kk) {
         const double d = read_lane(col[kk], kk);
@@ -672,18 +675,20 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
         pnv = (jc == kk) ? ri : pnv;
 #pragma unroll
         for (int i = kk + 1; i < TILE; ++i) col[i] = fma(-read_lane(rkj, i), rkj, col[i]);
-      }
-      double uu[TILE];
+        // the inverse rides along: Y = R'^-T by forward substitution, row kk as soon as row kk of
+        // R' exists (lane c holds column c of Y = row c of R'^-1) — its sums are independent of the
+        // next pivot's rsq chain, so the two latency chains overlap instead of running back to back
+        double ay0 = (jc == kk) ? 1.0 : 0.0, ay1 = 0.0;
 #pragma unroll
-      for (int i = TILE - 1; i >= 0; --i) {
-        double ac_ = (i == jc) ? 1.0 : 0.0;
-#pragma unroll
-        for (int l = i + 1; l < TILE; ++l) ac_ = fma(-read_lane(col[i], l), uu[l], ac_);
-        uu[i] = ac_ * read_lane(pnv, i);
+        for (int p = 0; p < kk; p += 2) {
+          ay0 = fma(-read_lane(col[p], kk), yy[p], ay0);
+          if (p + 1 < kk) ay1 = fma(-read_lane(col[p + 1], kk), yy[p + 1], ay1);
+        }
+        yy[kk] = (jc <= kk) ? (ay0 + ay1) * ri : 0.0;
       }
       if (lane < TILE) {
 #pragma unroll
-        for (int i = 0; i < TILE; ++i) { Dt[i * 16 + jc] = col[i]; Ri[i * 16 + jc] = uu[i]; }
+        for (int i = 0; i < TILE; ++i) { Dt[i * 16 + jc] = col[i]; Ri[jc * 16 + i] = yy[i]; }
       }
       __syncthreads();                                  // B: R'_kk and its inverse are in LDS
       __syncthreads();                                  // C: (workers published the row block)
