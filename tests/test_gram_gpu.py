@@ -122,6 +122,33 @@ def test_logspaced_spectrum_across_the_gate(bl, kappa):
         assert worst < 1e-12
 
 
+@pytest.mark.parametrize("n,s_", [(32, 0.95), (64, 0.97), (128, 0.992)])
+def test_kahan_matrix_pivots_pass_but_sigma_min_does_not(bl, n, s_):
+    """Adversarial for a pivot-only gate: J = Q K with K the n x n Kahan matrix (unit columns after
+    equilibration, every Cholesky pivot s^k stays above the gate's 0.1, yet sigma_min is orders of
+    magnitude smaller).  The inverse-power estimate must send it to the Householder tree, and the
+    step must match the oracle."""
+    from bounded_lsq import _synth
+    B, m = 2, 1024
+    c_ = np.sqrt(1 - s_ ** 2)
+    K = np.zeros((n, n))
+    for i in range(n):
+        K[i, i] = s_ ** i
+        K[i, i + 1:] = -c_ * s_ ** i
+    Kn = K / np.linalg.norm(K, axis=0)
+    assert np.min(np.abs(np.diag(np.linalg.qr(Kn)[1]))) > 0.1          # pivots of the unit-column matrix
+    assert np.linalg.svd(Kn, compute_uv=False)[-1] < 0.02             # ... but a tiny sigma_min
+    rng = np.random.default_rng(3)
+    P = _synth.trf_batch(23, B, m, n)
+    J = np.empty((B, m, n))
+    for b in range(B):
+        Q, _ = np.linalg.qr(rng.standard_normal((m, n)))
+        J[b] = Q @ K
+    P["J"] = J
+    stats, _ = _check(bl, P, np.array([10.0, 0.5]))
+    assert stats == (0, B), stats
+
+
 def test_mixed_batch_splits_between_the_paths(bl):
     from bounded_lsq import _synth
     B, m, n = 8, 1024, 96
