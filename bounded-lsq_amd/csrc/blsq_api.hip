@@ -295,6 +295,7 @@ struct blsq_trf_plan {
   // `path`, see trf_after_triangle)
   const int* path = nullptr;
   bool use_chol = false, use_qr = true;
+  DevBuf aug_colinfo;               // [B][2] column-norm summary of R_aug (Gram-path problems)
   // TSQR (multi-rank) extras
   int nranks = 1, m_total = 0;
   DevBuf Rcomb;                     // [1][NPAD*NPAD] merged triangle
@@ -481,6 +482,7 @@ int trf_alloc_state(blsq_trf_plan* p) {
   ALLOC(p->lm_sa, sizeof(double) * (size_t)B);
   ALLOC(p->lm_Xa, sizeof(double) * B * mat);
   ALLOC(p->lm_ints, sizeof(int) * ((size_t)B * 9 + 4));
+  ALLOC(p->aug_colinfo, sizeof(double) * (size_t)B * 2);
   ALLOC(p->lm_sc, sizeof(double) * (size_t)B * 16);
   ALLOC(p->lm_ph, sizeof(double) * vs);
   HIPCHK(ctx, hipMemsetAsync(p->lm_sa.p, 0, p->lm_sa.bytes, ctx->stream));
@@ -530,11 +532,13 @@ int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode) {
   p->use_chol = own && p->tree.any_gram;
   p->use_qr = !own || p->tree.any_qr;
   p->lm.path = p->path;
+  p->lm.colinfo = p->use_chol ? p->aug_colinfo.as<double>() : nullptr;
   if (p->use_chol) {
     GramCholArgs c{};
     c.Gsrc = p->tree.gram_keep.as<double>(); c.G = p->st.X; c.NPAD = p->ld; c.n = p->n;
     c.colscale = p->st.d; c.diag_vec = p->st.ediag; c.stride_vec = p->ld;
     c.skip_path = p->path;
+    c.colinfo = p->aug_colinfo.as<double>();
     ctx->begin(K_AUG_CHOL);
     e = launch_gram_chol(c, p->B, ctx->stream);
     ctx->end();
@@ -661,7 +665,7 @@ extern "C" int blsq_trf_plan_destroy(blsq_trf_plan* p) {
   p->o_info.release(); p->in_J.release(); p->in_f.release(); p->in_vec.release();
   p->in_scal.release();
   p->lm_sa.release(); p->lm_Xa.release(); p->lm_ints.release(); p->lm_sc.release();
-  p->lm_ph.release();
+  p->lm_ph.release(); p->aug_colinfo.release();
   delete p;
   return 0;
 }

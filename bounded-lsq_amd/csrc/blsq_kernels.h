@@ -86,6 +86,7 @@ struct GramCholArgs {
   int* fb_mask;           // optional [B] out: n + 1 if the problem needs the Householder tree, else 0
   int* fail_count;        // [1] number of such problems (caller zeroes it)
   double* dsc;            // optional [B][NPAD] out: column scales 1 / ||J_j||
+  double* colinfo;        // optional [B][2] out: min_j sqrt(h_jj), sum_j h_jj over the first n columns
 };
 bool gram_supported(int m, int n);
 int gram_chunks(int B, int m);
@@ -159,6 +160,8 @@ struct LmState {
   double* ph;             // [B][ld] p_h of the SVD-free path
   int* active_count;      // [1] problems that need another evaluation
   int* active_list;       // [2][B] their indices, compacted (list r & 1 feeds evaluation r)
+  const double* colinfo;  // optional [B][2] from the augmented Cholesky (Gram-path problems): min / sum of
+                          // the squared column norms of R_aug — a cheap sufficient test for the rank gate
   const int* path;        // optional [B]: != 0 -> the problem's Newton systems are factored by QR,
                           // 0 -> by Cholesky of the modified Gram (nullptr: QR for all)
   int round;              // evaluation number of this launch (host-set)

@@ -414,6 +414,14 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
     dl[j] = d; sq[j] = s; sc[j] = cs * d; td[j] = add * d * d;
     if (a.dsc) a.dsc[(long)b * NPAD + j] = d;
   }
+  if (a.colinfo) {                                      // (uniform) column-norm summary for the rank gate
+    psync();
+    if (tid == 0) {
+      double mn = __builtin_inf(), sm = 0.0;
+      for (int j = 0; j < n; ++j) { const double v = sq[j]; mn = v < mn ? v : mn; sm = fma(v, v, sm); }
+      a.colinfo[2 * (long)b] = mn; a.colinfo[2 * (long)b + 1] = sm;
+    }
+  }
   // strictly lower tiles are part of the triangle's image: zero
   for (int r = 16 + w; r < NPAD; r += NWP) {
     const int cend = r & ~15;
@@ -616,6 +624,14 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
     }
     dl[j] = d; sq[j] = s; sc[j] = cs * d; td[j] = add * d * d;
     if (a.dsc) a.dsc[(long)b * NPAD + j] = d;
+  }
+  if (a.colinfo) {
+    __syncthreads();
+    if (tid == 0) {
+      double mn = __builtin_inf(), sm = 0.0;
+      for (int j = 0; j < n; ++j) { const double v = sq[j]; mn = v < mn ? v : mn; sm = fma(v, v, sm); }
+      a.colinfo[2 * (long)b] = mn; a.colinfo[2 * (long)b + 1] = sm;
+    }
   }
   bad = block_or(bad, red);
   if (tid == 0) { pminsh = 1.0; flagsh = 0; }

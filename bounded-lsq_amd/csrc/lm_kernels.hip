@@ -61,6 +61,24 @@ __global__ __launch_bounds__(TRI_NT) void lm_gate_kernel(LmState lm, int enable)
   double* invd = u + ld;
   double* pfbuf = invd + ld;                 // 2 x 16 x ld doubles: DMA staging of the solves
   int ok = (enable != 0) && (lm.m >= n);
+  // Gram-path problems (gram_kernels.hip): R_aug = R'_aug diag(sqrt h_jj) with sigma_min(R'_aug) >=
+  // sigma_min(R') >= GRAM gate (0.1), so  s_min >= 0.1 min_j sqrt(h_jj)  and  s_max <= sqrt(sum_j h_jj)
+  // (the exact Frobenius norm).  When that already clears the threshold below, the iteration is
+  // not needed; otherwise (extreme column scaling near the bounds) the estimate runs as always.
+  if (ok && lm.path && lm.colinfo && lm.path[b] == 0) {
+    const double mn = lm.colinfo[2 * (long)b], sm = lm.colinfo[2 * (long)b + 1];
+    const double smin_lb = 0.1 * mn, smax_ub = sqrt(sm);
+    if (is_finite(sm) && sm > 0.0 && smin_lb > LM_GATE_MARGIN * LM_EPS * lm.m * smax_ub) {
+      if (tid == 0) {
+        lm.fast[b] = 1;
+        lm.ncols_jac[b] = 0;
+        lm.sc[(long)b * 16 + SC_SMAX] = smax_ub;
+        lm.sc[(long)b * 16 + SC_SMIN] = smin_lb;
+        lm.st[(long)b * 4 + ST_PHASE] = LM_IDLE;
+      }
+      return;
+    }
+  }
   // diagonal: finite and non-zero
   int bad = 0;
   for (int i = tid; i < n; i += TRI_NT) {
