@@ -321,6 +321,7 @@ struct blsq_dogbox_plan {
   DevBuf o_vec, o_onb, o_scal, o_info;
   DevBuf in_J, in_f, in_vec, in_scal;
   DevBuf gate_ints;                 // [2B] fast flags, Jacobi launch mask
+  DevBuf colinfo;                   // [B][2] column-norm summary of the free block (Gram-path problems)
   int svdfree_enable = 1;
   DogState st{};
   DogStepOut out{};
@@ -971,6 +972,7 @@ int dog_alloc_state(blsq_dogbox_plan* p) {
   ALLOC(p->o_info, sizeof(int) * (size_t)B * 4);
   ALLOC(p->in_scal, sizeof(double) * (size_t)B);
   ALLOC(p->gate_ints, sizeof(int) * 2 * (size_t)B);
+  ALLOC(p->colinfo, sizeof(double) * 2 * (size_t)B);
   {
     const char* env = getenv("BLSQ_NO_SVDFREE");
     p->svdfree_enable = (env && env[0] == '1') ? 0 : 1;
@@ -1028,6 +1030,7 @@ int dog_after_triangle(blsq_dogbox_plan* p, int scale_mode) {
     c.Gsrc = p->tree.gram_keep.as<double>(); c.G = p->st.X; c.NPAD = p->ld; c.n = p->n;
     c.ncols_dev = p->st.ncols; c.gather = p->st.free_idx; c.stride_vec = p->ld;
     c.skip_path = path;
+    c.colinfo = p->colinfo.as<double>();
     ctx->begin(K_AUG_CHOL);
     e = launch_gram_chol(c, p->B, ctx->stream);
     ctx->end();
@@ -1048,7 +1051,8 @@ int dog_after_triangle(blsq_dogbox_plan* p, int scale_mode) {
   int* gfast = p->gate_ints.as<int>();
   int* gmask = gfast + p->B;
   ctx->begin(K_LM_GATE);
-  e = launch_dog_gate_solve(p->st, gfast, gmask, p->svdfree_enable, ctx->stream);
+  e = launch_dog_gate_solve(p->st, gfast, gmask, p->svdfree_enable, path,
+                            (own && p->tree.any_gram) ? p->colinfo.as<double>() : nullptr, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_dog_gate_solve");
   JacobiArgs ja{};
@@ -1094,7 +1098,7 @@ extern "C" int blsq_dogbox_plan_destroy(blsq_dogbox_plan* p) {
   p->S.release(); p->X.release(); p->vecs.release(); p->ivecs.release(); p->scal2.release();
   p->sweeps.release(); p->active.release(); p->onb.release(); p->o_vec.release();
   p->o_onb.release(); p->o_scal.release(); p->o_info.release(); p->in_J.release();
-  p->in_f.release(); p->in_vec.release(); p->in_scal.release(); p->gate_ints.release();
+  p->in_f.release(); p->in_vec.release(); p->in_scal.release(); p->gate_ints.release(); p->colinfo.release();
   delete p;
   return 0;
 }

@@ -189,8 +189,9 @@ struct DogState {
 };
 hipError_t launch_dog_prep(const DogState& st, int jac_scaling, hipStream_t s);
 hipError_t launch_dog_solve(const DogState& st, const int* skip, hipStream_t s);
+// path / colinfo (optional): Gram-path flags and the column-norm summary of the free block
 hipError_t launch_dog_gate_solve(const DogState& st, int* fast, int* ncols_jac, int enable,
-                                 hipStream_t s);
+                                 const int* path, const double* colinfo, hipStream_t s);
 
 struct DogStepOut {
   double* step;           // [B][ld]  full length

@@ -311,7 +311,9 @@ hipError_t launch_lm_update(const LmState& lm, int active, hipStream_t s) {
 // upper bound on s_min to clear that threshold by the same 1e3 margin, otherwise the
 // Jacobi SVD computes the truncated min-norm solution as before.
 __global__ __launch_bounds__(TRI_NT) void dog_gate_solve_kernel(DogState st, int* fast,
-                                                                int* ncols_jac, int enable) {
+                                                                int* ncols_jac, int enable,
+                                                                const int* path,
+                                                                const double* colinfo) {
   extern __shared__ double sh[];
   __shared__ double red[32];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -337,6 +339,16 @@ __global__ __launch_bounds__(TRI_NT) void dog_gate_solve_kernel(DogState st, int
   if (ok) {
     tri_invdiag(R, nf, ld, invd);
     const double s0 = 1.0 / sqrt((double)nf);
+    const int mx = (st.m > nf) ? st.m : nf;
+    // Gram-path problems: s_min >= 0.1 min_j ||J_free[:, j]||, s_max <= ||J_free||_F (column norms
+    // from the Cholesky of the gathered Gram, as in lm_gate_kernel); the estimates below only run
+    // when that bound does not already clear the threshold
+    bool sure = false;
+    if (path && colinfo && path[b] == 0) {
+      const double mn = colinfo[2 * (long)b], sm = colinfo[2 * (long)b + 1];
+      sure = is_finite(sm) && sm > 0.0 && (0.1 * mn > LM_GATE_MARGIN * LM_EPS * mx * sqrt(sm));
+    }
+    if (!sure) {
     for (int i = tid; i < nf; i += TRI_NT) v[i] = (i & 1) ? -s0 : s0;
     __syncthreads();
     double smax = 0.0, smin = 0.0;
@@ -360,8 +372,8 @@ __global__ __launch_bounds__(TRI_NT) void dog_gate_solve_kernel(DogState st, int
       for (int i = tid; i < nf; i += TRI_NT) v[i] *= inv;
       __syncthreads();
     }
-    const int mx = (st.m > nf) ? st.m : nf;
     if (!(smin > LM_GATE_MARGIN * LM_EPS * mx * smax) || !is_finite(smax) || smax == 0.0) ok = 0;
+    }
   }
   if (ok) {
     for (int i = tid; i < nf; i += TRI_NT) v[i] = R[(long)i * ld + nf];      // c_f
@@ -373,11 +385,11 @@ __global__ __launch_bounds__(TRI_NT) void dog_gate_solve_kernel(DogState st, int
 }
 
 hipError_t launch_dog_gate_solve(const DogState& st, int* fast, int* ncols_jac, int enable,
-                                 hipStream_t s) {
+                                 const int* path, const double* colinfo, hipStream_t s) {
   const size_t lds = sizeof(double) * (3 + 32) * (size_t)st.ld;
   { static std::atomic<size_t> granted[64]; hipError_t ge = grant_lds(dog_gate_solve_kernel, lds, granted); if (ge != hipSuccess) return ge; }
   hipLaunchKernelGGL(dog_gate_solve_kernel, dim3(st.B), dim3(TRI_NT), lds, s, st, fast,
-                     ncols_jac, enable);
+                     ncols_jac, enable, path, colinfo);
   return hipGetLastError();
 }
 
