@@ -850,6 +850,91 @@ __global__ __launch_bounds__(TRI_NT) void gram_gate_kernel(GramCholArgs a) {
   }
 }
 
+// The same gate with ONE WAVE per problem for n <= 64 (eight problems per workgroup): lane i holds
+// component i of the vectors, both triangular solves walk the rows of R in order (R^T x = y is a
+// row axpy per step, R x = y a row dot product per step), rows are prefetched eight ahead straight
+// from memory — no LDS, no workgroup barrier, sixteen problems resident per CU.
+__global__ __launch_bounds__(GR_NT, 4) void gram_gate_wave_kernel(GramCholArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int pidx = (int)blockIdx.x * GR_NW + ((int)threadIdx.x >> 6);
+  if (pidx >= a.count) return;
+  const int b = pidx;
+  if (a.mask && a.mask[b] <= 1) return;
+  if (a.fb_mask[b] != 0) return;
+  const int n = a.n, ld = a.NPAD;
+  const double* R = a.G + (long)b * ld * ld;
+  const int li = lane < n ? lane : n - 1;
+  const double dsc = a.dsc[(long)b * ld + li];
+  const double rdi = R[(long)li * ld + li];
+  double invd = __builtin_amdgcn_rcp(rdi);
+  invd = invd * fma(-rdi, invd, 2.0);
+  invd = invd * fma(-rdi, invd, 2.0);
+  const double s0 = 1.0 / sqrt((double)n);
+  double v = (lane < n) ? ((lane % 3 == 0) ? s0 : -0.5 * s0) : 0.0;
+  double smin = 0.0;
+  constexpr int PF = 8;
+  for (int it = 0; it < 3; ++it) {
+    // R'^-T: t = R^-T (v / d)  — forward over the rows, axpy per step
+    double t = (lane < n) ? v / dsc : 0.0;
+    double x = 0.0;
+    double nxt[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) nxt[u] = R[(long)((u < n) ? u : n - 1) * ld + li];
+    for (int j0 = 0; j0 < n; j0 += PF) {
+      double row[PF];
+#pragma unroll
+      for (int u = 0; u < PF; ++u) row[u] = nxt[u];
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {                    // the next eight rows fly while these are used
+        const int j = (j0 + PF + u < n) ? j0 + PF + u : n - 1;
+        nxt[u] = R[(long)j * ld + li];
+      }
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int j = j0 + u;
+        if (j < n) {
+          const double xj = read_lane(t * invd, j);
+          x = (lane == j) ? xj : x;
+          t = (lane > j && lane < n) ? fma(-row[u], xj, t) : t;
+        }
+      }
+    }
+    // R'^-1: y = (R^-1 x) / d  — backward over the rows, dot product per step
+    double y = 0.0;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) nxt[u] = R[(long)((n - 1 - u >= 0) ? n - 1 - u : 0) * ld + li];
+    for (int j0 = n - 1; j0 >= 0; j0 -= PF) {
+      double row[PF];
+#pragma unroll
+      for (int u = 0; u < PF; ++u) row[u] = nxt[u];
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int j = (j0 - PF - u >= 0) ? j0 - PF - u : 0;
+        nxt[u] = R[(long)j * ld + li];
+      }
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int j = j0 - u;
+        if (j >= 0) {
+          const double sdot = wave_sum((lane > j && lane < n) ? row[u] * y : 0.0);
+          const double yj = (read_lane(x, j) - sdot) * read_lane(invd, j);
+          y = (lane == j) ? yj : y;
+        }
+      }
+    }
+    v = (lane < n) ? y / dsc : 0.0;
+    const double nv = sqrt(wave_sum(v * v));
+    smin = (nv > 0.0 && is_finite(nv)) ? 1.0 / sqrt(nv) : 0.0;
+    const double inv = (nv > 0.0 && is_finite(nv)) ? 1.0 / nv : 0.0;
+    v *= inv;
+  }
+  if (lane == 0 && !(smin >= GRAM_SMIN)) {
+    a.fb_mask[b] = n + 1;
+    if (a.path_out) a.path_out[b] = n + 1;
+    atomicAdd(a.fail_count, 1);
+  }
+}
+
 bool gram_supported(int m, int n) {
   const int NT = (n + 1 + 15) / 16;
   return NT <= 17 && m >= n && n >= 1;
@@ -955,7 +1040,14 @@ hipError_t launch_gram_chol(const GramCholArgs& a_in, int B, hipStream_t s) {
   }
   return hipGetLastError();
 }
-hipError_t launch_gram_gate(const GramCholArgs& a, int B, hipStream_t s) {
+hipError_t launch_gram_gate(const GramCholArgs& a_in, int B, hipStream_t s) {
+  if (a_in.n <= 64) {                                   // one wave per problem
+    GramCholArgs a = a_in;
+    a.count = B;
+    hipLaunchKernelGGL(gram_gate_wave_kernel, dim3((B + GR_NW - 1) / GR_NW), dim3(GR_NT), 0, s, a);
+    return hipGetLastError();
+  }
+  const GramCholArgs& a = a_in;
   const size_t lds = sizeof(double) * (2 + 32) * (size_t)a.NPAD;
   { static std::atomic<size_t> granted[64]; hipError_t ge = gram_grant_lds(gram_gate_kernel, lds, granted); if (ge != hipSuccess) return ge; }
   hipLaunchKernelGGL(gram_gate_kernel, dim3(B), dim3(TRI_NT), lds, s, a);
