@@ -14,7 +14,10 @@ Workload at N = 1: BASELINE.json configs[1] shape (m=4096, n=256, TRF exact
 step) batched, which is the configuration the metric / north_star target is
 quoted on ("batched 4096x256 dense Jacobians at 1 GPU").
 
-Prints ONE JSON line (rank 0) with `roofline` and `cpu_baseline` objects.
+Prints ONE JSON line (rank 0) with `roofline` and `cpu_baseline` objects.  `factorisation_paths`
+counts how many problems the normal-equations front end factored and how many its conditioning
+gate handed to the Householder tree; `householder_only` (N = 1) is the same workload re-timed with
+the front end switched off — a side figure, never `value`.
 """
 import argparse
 import json
@@ -182,6 +185,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=512,
                     help="problems per GPU (512: two waves of 256 CUs; the n-space kernels run one workgroup per problem)")
+    ap.add_argument("--no-householder", action="store_true",
+                    help="skip the side run with the normal-equations front end switched off")
     ap.add_argument("--m", type=int, default=4096)
     ap.add_argument("--n", type=int, default=256)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -254,6 +259,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Same workload with the normal-equations front end switched off (every problem through the
+    # Householder TSQR tree — what a batch gets whose problems fail the conditioning gate).  A
+    # reported side figure at N = 1 only, never `value`.
+    householder = None
+    if world == 1 and not args.no_householder:
+        os.environ["BLSQ_GRAM"] = "0"                  # read when a plan is created
+        sol_h = TrfStepSolver(B, m, n, ctx=ctx)
+        os.environ.pop("BLSQ_GRAM", None)
+
+        def step_h():
+            sol_h.factor_dev(d["J"], d["f"], d["x"], d["lb"], d["ub"], d["scale"])
+            sol_h.step_dev(dDelta, dAlpha)
+        step_h(); ctx.sync()
+        kh = max(2, min(args.steps, 4))
+        th = time.perf_counter()
+        for _ in range(kh):
+            step_h()
+        ctx.sync()
+        eh = time.perf_counter() - th
+        householder = {"value": B * kh / eh, "unit": "step-solves/s", "ms_per_step": 1e3 * eh / kh,
+                       "steps": kh, "note": "BLSQ_GRAM=0: Householder TSQR tree for every problem"}
+        sol_h.close()
+
     # parity spot-check of the timed configuration (rank 0, a few problems)
     parity = None
     if rank == 0 and args.check > 0:
@@ -320,6 +348,7 @@ def main():
                 "hbm_frac_of_8TBs": byts / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
             },
             "factorisation_paths": {"normal_equations": gs[0], "householder_tree": gs[1]},
+            "householder_only": householder,
             "kernels_ms_per_step": per_step_ms,
             "cpu_baseline": cpu,
             "speedup_vs_cpu": (value / cpu["value"]) if cpu else None,
