@@ -78,7 +78,14 @@ __global__ __launch_bounds__(GR_NT, (SLOTS <= 8 ? 4 : 2)) void gram_kernel(GramA
   // (Only where that saves a tile slot per wave — a.rhs_valu, decided by launch_gram.)
   const int NTJ = a.rhs_valu ? (n + 15) / 16 : NT;
   const int ntile = NTJ * (NTJ + 1) / 2;
-  const int per = (ntile + GR_NW - 1) / GR_NW;
+  // Small batches: the tiles of a problem are split over gridDim.z workgroups (tile groups), each
+  // streaming the same rows for its share of the tiles — a tile still sees the same k-steps in
+  // the same order, so the result does not depend on the split.
+  const int tpg = (ntile + (int)gridDim.z - 1) / (int)gridDim.z;   // tiles per group
+  const int q_lo = (int)blockIdx.z * tpg;
+  const int q_hi = (q_lo + tpg < ntile) ? q_lo + tpg : ntile;
+  const int per = (tpg + GR_NW - 1) / GR_NW;
+  const bool rhs_here = a.rhs_valu && blockIdx.z == 0;  // one group accumulates the rhs column
   // rows of this chunk
   const int r_lo = blockIdx.x * a.rows_per_chunk;
   int r_hi = r_lo + a.rows_per_chunk;
@@ -92,12 +99,12 @@ __global__ __launch_bounds__(GR_NT, (SLOTS <= 8 ? 4 : 2)) void gram_kernel(GramA
   int ti[SLOTS], tj[SLOTS];
   bool tv[SLOTS];
   {
-    int i = 0, rem = w * per;
+    int i = 0, rem = q_lo + w * per;
     while (i < NTJ && rem >= NTJ - i) { rem -= NTJ - i; ++i; }
     int j = i + rem;
 #pragma unroll
     for (int t = 0; t < SLOTS; ++t) {
-      const bool valid = (t < per) && (i < NTJ);
+      const bool valid = (t < per) && (i < NTJ) && (q_lo + w * per + t < q_hi);
       tv[t] = valid;
       ti[t] = valid ? 16 * i : 0;
       tj[t] = valid ? 16 * j : 0;
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(GR_NT, (SLOTS <= 8 ? 4 : 2)) void gram_kernel(GramA
     const unsigned xb = lds_addr(X) + 8u * (unsigned)(lr * LDX + lc);
     // rhs column: thread t owns column t & 255 over half of the chunk's rows; columns 256..n (and
     // f^T f when n >= 256) go to the first threads over all rows
-    if (a.rhs_valu) {
+    if (rhs_here) {
       const int c0 = tid & 255, h0 = (tid >> 8) * (GR_RC / 2);
       if (c0 <= n) {
 #pragma unroll
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(GR_NT, (SLOTS <= 8 ? 4 : 2)) void gram_kernel(GramA
         G[(long)(ti[t] + lr + 4 * g) * a.NPAD + tj[t] + lc] = acc[t][g];
     }
   }
-  if (!a.rhs_valu) return;
+  if (!rhs_here) return;
   // rhs column of the Gram: the two row halves of a column, summed in a fixed order
   lds[tid] = gf0;                                       // (the last chunk's barrier is behind us)
   __syncthreads();
@@ -967,7 +974,7 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s) {
     static std::atomic<size_t> granted[64];                                                   \
     hipError_t ge = gram_grant_lds(gram_kernel<SL, CB>, lds, granted);                        \
     if (ge != hipSuccess) return ge;                                                          \
-    hipLaunchKernelGGL((gram_kernel<SL, CB>), dim3(chunks, B), dim3(GR_NT), lds, s, a);       \
+    hipLaunchKernelGGL((gram_kernel<SL, CB>), dim3(chunks, B, tg), dim3(GR_NT), lds, s, a);   \
   } while (0)
 #define BLSQ_GRAM_DIRECT(NTT)                                                                 \
   do {                                                                                        \
@@ -991,15 +998,33 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s) {
   }
 #undef BLSQ_GRAM_DIRECT
   const int ncb = (a.n + 63) / 64;
-  const int per = (ntile + GR_NW - 1) / GR_NW;          // tile slots a wave needs
-  if (per <= 4) {                                       // n <= 111
-    if (ncb <= 1) BLSQ_GRAM_LAUNCH(4, 1); else BLSQ_GRAM_LAUNCH(4, 2);
-  } else if (per <= 8) {                                // n <= 159
-    if (ncb <= 2) BLSQ_GRAM_LAUNCH(8, 2); else BLSQ_GRAM_LAUNCH(8, 3);
-  } else if (per <= 12) {                               // n <= 207
-    if (ncb <= 3) BLSQ_GRAM_LAUNCH(12, 3); else BLSQ_GRAM_LAUNCH(12, 4);
+  // tile groups: enough workgroups to occupy the CUs when the batch is small (results identical)
+  int tg = 1;
+  {
+    const char* tge = getenv("BLSQ_GRAM_TILE_GROUPS");    // (tests compare splits bit for bit)
+    const int tenv = tge ? atoi(tge) : 0;
+    const long wgs = (long)chunks * B;
+    // (only when the row chunks alone leave most CUs idle: every group re-reads the rows)
+    tg = tenv > 0 ? tenv : (wgs <= 64 ? (int)((256 + wgs - 1) / wgs) : 1);
+    if (tg > 8) tg = 8;
+    if (tg > ntile) tg = ntile;
+    if (tg < 1) tg = 1;
+  }
+  const int per = (((ntile + tg - 1) / tg) + GR_NW - 1) / GR_NW;   // tile slots a wave needs
+  if (per <= 4) {                                       // n <= 111, or tile groups
+    if (ncb <= 1) BLSQ_GRAM_LAUNCH(4, 1);
+    else if (ncb <= 2) BLSQ_GRAM_LAUNCH(4, 2);
+    else BLSQ_GRAM_LAUNCH(4, 5);
+  } else if (per <= 8) {                                // n <= 159, or tile groups
+    if (ncb <= 2) BLSQ_GRAM_LAUNCH(8, 2);
+    else if (ncb <= 3) BLSQ_GRAM_LAUNCH(8, 3);
+    else BLSQ_GRAM_LAUNCH(8, 5);
+  } else if (per <= 12) {                               // n <= 207, or tile groups
+    if (ncb <= 3) BLSQ_GRAM_LAUNCH(12, 3);
+    else if (ncb <= 4) BLSQ_GRAM_LAUNCH(12, 4);
+    else BLSQ_GRAM_LAUNCH(12, 5);
   } else if (per <= 17) {                               // n <= 256
-    BLSQ_GRAM_LAUNCH(17, 4);
+    if (ncb <= 4) BLSQ_GRAM_LAUNCH(17, 4); else BLSQ_GRAM_LAUNCH(17, 5);
   } else {
     if (ncb <= 4) BLSQ_GRAM_LAUNCH(20, 4); else BLSQ_GRAM_LAUNCH(20, 5);
   }

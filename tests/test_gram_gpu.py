@@ -246,3 +246,23 @@ def test_badly_scaled_columns_are_equilibrated(bl, monkeypatch):
         sol.close(); ctx.close()
     for b in range(B):
         assert rel(steps["1"][b], steps["0"][b]) < 1e-11
+
+
+def test_tile_groups_do_not_change_a_single_bit(bl, monkeypatch):
+    """Small batches split the Gram's tiles over several workgroups; every tile still accumulates
+    the same k-steps in the same order, so the whole step is bitwise the same for any split."""
+    from bounded_lsq import _synth, _abi
+    for (B, m, n) in [(1, 4096, 256), (2, 3000, 200), (3, 2100, 128), (2, 1500, 100)]:
+        P = _synth.trf_batch(41 + n, B, m, n)
+        Delta = np.full(B, 0.7)
+        outs = []
+        for tg in ("1", "3", "8"):
+            monkeypatch.setenv("BLSQ_GRAM_TILE_GROUPS", tg)
+            ctx = _abi.Context(0)
+            sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
+            ctx.gram_stats(reset=True)
+            sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+            assert ctx.gram_stats() == (B, 0)
+            outs.append(sol.step(Delta, np.zeros(B)).step.copy())
+            sol.close(); ctx.close()
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
