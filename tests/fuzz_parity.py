@@ -2,7 +2,7 @@
 column scalings (both trust-region solvers).  Not part of the test suite (runtime grows with the
 count); prints the worst cases and exits non-zero on any violation of the 1e-10 / bit-exact bar.
 
-usage: python tools/fuzz_parity.py [count] [seed]"""
+usage: python tests/fuzz_parity.py [count] [seed]   (lives under tests/: it uses the CPU oracle)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
