@@ -21,7 +21,7 @@ from scipy.optimize import OptimizeResult
 
 from ._frontend import (TERMINATION_MESSAGES, _clamp_tolerances, _checked_scaling, EPS)
 from ._hip_step import (TrfStepSolver, DogboxStepSolver, SCALE_GIVEN, SCALE_JAC_INIT,
-                        SCALE_JAC_UPDATE)
+                        SCALE_JAC_UPDATE, raise_batch_status)
 from ._hostmath import shift_into_interior, active_mask, cl_vector
 
 
@@ -201,6 +201,9 @@ def least_squares_batch(fun, x0, jac, bounds=(-np.inf, np.inf), method='trf',
                 alpha = np.where(act, S.alpha, alpha)
             else:
                 S = solver.step(Delta)
+            # where the reference raises ValueError out of the step (trust_region.py:28-29,
+            # 34-35) its solve aborts: so does the batch, naming the problem
+            raise_batch_status(S.status, act)
             x_new = np.where(act[:, None], S.x_new, x)
             f_new = feval(x_new)
             accepted = np.zeros(B, dtype=bool)

@@ -38,13 +38,25 @@ def default_context(device_id=0):
     return c
 
 
+STATUS_MESSAGES = {1: "`s` is zero.",                            # trust_region.py:28-29
+                   2: "`x` is not within the trust region."}     # trust_region.py:34-35
+
+
 def _raise_status(status):
     """B == 1 drop-in behaviour: the reference raises ValueError here
     (trust_region.py:28-29,34-35)."""
-    if status == 1:
-        raise ValueError("`s` is zero.")
-    if status == 2:
-        raise ValueError("`x` is not within the trust region.")
+    if status in STATUS_MESSAGES:
+        raise ValueError(STATUS_MESSAGES[status])
+
+
+def raise_batch_status(status, active=None):
+    """Batched drivers: the reference would abort the solve of that problem with ValueError;
+    raise it naming the first offending (still active) problem."""
+    st = np.asarray(status)
+    bad = np.nonzero((st != 0) & (True if active is None else np.asarray(active)))[0]
+    if bad.size:
+        b = int(bad[0])
+        raise ValueError("problem %d: %s" % (b, STATUS_MESSAGES.get(int(st[b]), "step status %d" % st[b])))
 
 
 class TrfStepSolver:

@@ -22,6 +22,17 @@ from ._abi import vp, ptr
 METHODS = {"trf": 0, "dogbox": 1}
 
 
+def raise_step_errors(status):
+    """The reference raises ValueError out of the step (trust_region.py:28-29,34-35), which
+    aborts its solve.  The device driver freezes such a problem with status = -BLSQ_STATUS_*;
+    raise the same exception here, naming the first offending problem."""
+    from ._hip_step import STATUS_MESSAGES
+    bad = np.nonzero(np.asarray(status) < 0)[0]
+    if bad.size:
+        b = int(bad[0])
+        raise ValueError("problem %d: %s" % (b, STATUS_MESSAGES[-int(status[b])]))
+
+
 class OuterDriver:
     def __init__(self, method, B, m, n, ctx=None):
         if method not in METHODS:
@@ -84,8 +95,10 @@ class OuterDriver:
         return out
 
     # ---- helpers for host-side callbacks -----------------------------------------------
-    def _up(self, dptr, arr):
+    def _up(self, dptr, arr, shape=None, what="callback"):
         arr = np.ascontiguousarray(arr, dtype=np.float64)
+        if shape is not None and arr.shape != tuple(shape):      # never write past the buffer
+            raise RuntimeError("`%s` must return an array of shape %s." % (what, tuple(shape)))
         self.ctx.check(self.ctx.lib.blsq_memcpy_h2d(self.ctx.h, dptr, ptr(arr), arr.nbytes), "h2d")
 
     def _down(self, dptr, shape, dtype=np.float64):
@@ -101,17 +114,19 @@ class OuterDriver:
         J = np.ascontiguousarray(jac(X), dtype=np.float64)
         if J.shape != (B, m, n):
             raise RuntimeError("`jac` must return an array of shape (B, m, n).")
-        self._up(self.d_f, F)
-        self._up(self.d_J, J)
+        self._up(self.d_f, F, (B, m), "fun")
+        self._up(self.d_J, J, (B, m, n), "jac")
         self.begin()
         itemJ = m * n * 8
         while self.propose() > 0:
             Xt = self._down(self.d_x_trial, (B, n))
-            self._up(self.d_f_trial, fun(Xt))
+            self._up(self.d_f_trial, fun(Xt), (B, m), "fun")
             if self.judge() > 0:
                 acc = self._down(self.d_accepted, (B,), np.int32)
                 X = self._down(self.d_x, (B, n))
                 Jn = np.ascontiguousarray(jac(X), dtype=np.float64)
+                if Jn.shape != (B, m, n):
+                    raise RuntimeError("`jac` must return an array of shape (B, m, n).")
                 idx = np.nonzero(acc)[0]
                 # only fresh Jacobians travel: contiguous runs of accepted problems, one copy each
                 runs = np.split(idx, np.nonzero(np.diff(idx) > 1)[0] + 1)
@@ -120,7 +135,9 @@ class OuterDriver:
                     dst = vp(self.d_J.value + b0 * itemJ)
                     self.ctx.check(self.ctx.lib.blsq_memcpy_h2d(self.ctx.h, dst, ptr(Jn[b0:b0 + nb]),
                                                                 nb * itemJ), "h2d(J)")
-        return self.fetch()
+        R = self.fetch()
+        raise_step_errors(R["status"])
+        return R
 
     def run_device(self, fun_dev, jac_dev, sync=None, rel_step=None, bounds_dev=None):
         """Lock-step loop with device callbacks:
@@ -162,7 +179,9 @@ class OuterDriver:
                 if self.judge() > 0:
                     jac_dev(self.d_x, self.d_J, self.d_accepted)
                     sync()
-            return self.fetch()
+            R = self.fetch()
+            raise_step_errors(R["status"])
+            return R
         finally:
             if fd is not None:
                 fd.close()

@@ -811,10 +811,10 @@ extern "C" int blsq_trf_factor(blsq_trf_plan* p, const double* J, const double* 
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const size_t jb = sizeof(double) * (size_t)p->B * p->m * p->n;
   const size_t fb = sizeof(double) * (size_t)p->B * p->m;
-  if (!p->in_J.p) {
-    hipError_t e = p->in_J.alloc(jb);
+  if (!p->in_J.p || !p->in_f.p) {       // lazily, and again if an earlier attempt failed half way
+    hipError_t e = p->in_J.p ? hipSuccess : p->in_J.alloc(jb);
     if (e != hipSuccess) return ctx->fail(e, "hipMalloc(J staging)");
-    e = p->in_f.alloc(fb);
+    e = p->in_f.p ? hipSuccess : p->in_f.alloc(fb);
     if (e != hipSuccess) return ctx->fail(e, "hipMalloc(f staging)");
   }
   HIPCHK(ctx, hipMemcpyAsync(p->in_J.p, J, jb, hipMemcpyHostToDevice, ctx->stream));
@@ -1227,10 +1227,10 @@ extern "C" int blsq_dogbox_factor(blsq_dogbox_plan* p, const double* J, const do
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const size_t jb = sizeof(double) * (size_t)p->B * p->m * p->n;
   const size_t fb = sizeof(double) * (size_t)p->B * p->m;
-  if (!p->in_J.p) {
-    hipError_t e = p->in_J.alloc(jb);
+  if (!p->in_J.p || !p->in_f.p) {       // lazily, and again if an earlier attempt failed half way
+    hipError_t e = p->in_J.p ? hipSuccess : p->in_J.alloc(jb);
     if (e != hipSuccess) return ctx->fail(e, "hipMalloc(J staging)");
-    e = p->in_f.alloc(fb);
+    e = p->in_f.p ? hipSuccess : p->in_f.alloc(fb);
     if (e != hipSuccess) return ctx->fail(e, "hipMalloc(f staging)");
   }
   HIPCHK(ctx, hipMemcpyAsync(p->in_J.p, J, jb, hipMemcpyHostToDevice, ctx->stream));

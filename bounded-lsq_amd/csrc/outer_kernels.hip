@@ -93,11 +93,18 @@ __global__ void outer_top_kernel(OuterState o) {
 __global__ __launch_bounds__(OUT_NT) void outer_trial_kernel(OuterState o) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const int n = o.n, ld = o.ld;
-  const bool act = !o.done[b];
+  bool act = !o.done[b];
+  // The reference raises ValueError out of the step (trust_region.py:28-29,34-35) and the whole
+  // solve aborts.  Here the problem is frozen with result = -status (BLSQ_STATUS_*) before its
+  // trial point would be evaluated; the host wrappers raise the reference's exception for it.
+  const int err = act ? o.o_info[(long)b * 4 + 3] : 0;
+  __syncthreads();                                  // every thread has read done[b]
+  if (err != 0) act = false;
   for (int j = tid; j < n; j += OUT_NT)
     o.xt[(long)b * n + j] = act ? o.o_xnew[(long)b * ld + j] : o.xc[(long)b * n + j];
   if (tid == 0) {
     o.accepted[b] = 0; o.ncols_fac[b] = 0;
+    if (err != 0) { o.done[b] = 1; o.result[b] = -err; }
     if (act) atomicAdd(&o.counts[0], 1);
   }
 }

@@ -189,7 +189,10 @@ int blsq_debug_gram_stats(blsq_ctx* ctx, uint64_t out[2], int reset);
  *          caller: J[b] <- jac(x[b]) for the problems with accepted[b] != 0   (if n_accepted)
  *   fetch(...)
  * Per-problem results (x, nfev, njev, status, ...) are what the reference's driver returns for
- * that problem alone; a terminated problem is frozen.  method: 0 = 'trf', 1 = 'dogbox'. */
+ * that problem alone; a terminated problem is frozen.  A problem whose step reports a
+ * BLSQ_STATUS_* condition (where the reference raises ValueError and aborts the solve,
+ * trust_region.py:28-29,34-35) is frozen at its current x with status = -BLSQ_STATUS_*.
+ * method: 0 = 'trf', 1 = 'dogbox'. */
 typedef struct blsq_outer blsq_outer;
 int blsq_outer_create(blsq_ctx* ctx, int method, int B, int m, int n, blsq_outer** out);
 int blsq_outer_destroy(blsq_outer* o);

@@ -52,6 +52,9 @@ def dog_inputs(ins):
     from bounded_lsq import _synth
     if "seed" in ins:
         P = _synth.dogbox_problem(int(ins["seed"]), int(ins["m"]), int(ins["n"]))
+        for k in ("x", "lb", "ub", "scale", "on_bound"):   # edited vectors stored in full
+            if k in ins:
+                P[k] = np.array(ins[k])
     else:
         P = {k: np.array(ins[k]) for k in ("J", "f", "x", "lb", "ub", "scale",
                                             "on_bound")}

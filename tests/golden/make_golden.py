@@ -12,6 +12,9 @@ What is captured
   trf_small.npz  TRF step tuples with full inputs (tiny shapes, all branches)
   trf_large.npz  TRF step tuples, inputs by seed (512x64, 4096x256)
   dog_small.npz / dog_large.npz   the same for dogbox
+  dog_fallback.npz   dogbox tuples on the constrained-Cauchy fallback branch
+                 (dogbox.py:211-216: predicted_reduction <= 0, `Js` not recomputed) and
+                 near misses of it;  `python make_golden.py dogfb` rebuilds it alone
   first_iter.npz x_new of the reference's own public trf()/dogbox() first
                  inner iteration (exercises the INLINE blocks trf.py:244-308,
                  dogbox.py:170-220 rather than a re-composition of them)
@@ -398,6 +401,92 @@ def make_dog():
     np.savez_compressed(os.path.join(HERE, "dog_large.npz"), **store)
 
 
+def make_dog_fallback():
+    """Tuples that reach `if predicted_reduction <= 0` of the reference (dogbox.py:211-216).
+
+    In exact arithmetic the dogleg point never increases the model, so the branch is taken
+    when the dogleg step is exactly ZERO: a FREE variable sits exactly on a bound without
+    being flagged in `on_bound` (the state dogbox.py:257-261 can leave behind), the Cauchy
+    step points out of the box there (clipped with beta = 0) and so does the Gauss-Newton
+    step (t = 0).  The reference then calls constrained_cauchy_step, flags the variable and
+    keeps the stale Js, i.e. predicted_reduction stays -0.0.  Seeds are searched until the
+    wanted variants exist; near misses (beta = 0 but Newton pointing inwards: no fallback)
+    are kept as well."""
+    store = {}
+    names = []
+
+    def run(name, P, Delta, by_seed=None):
+        out = ref_dog_tuple(P["J"], P["f"], P["x"], P["lb"], P["ub"],
+                            P["scale"], P["on_bound"], Delta)
+        if by_seed is None:
+            Pin = dict(P, Delta=Delta)
+        else:                       # J, f by seed; the edited vectors in full
+            Pin = dict(by_seed, Delta=Delta, x=P["x"], lb=P["lb"], ub=P["ub"],
+                       scale=P["scale"], on_bound=P["on_bound"])
+        pack(name, Pin, out, store)
+        names.append(name)
+        print("dogfb", name, "fallback", int(out["fallback"]), "pred",
+              out["predicted_reduction"], "|step|", np.abs(out["step"]).max(),
+              "n_on_bound_new", int(np.abs(out["on_bound_new"]).sum()))
+        return out
+
+    def variant(seed, m, n, kind):
+        P = _synth.dogbox_problem(seed, m, n, frac_on_bound=0.15)
+        rng = np.random.default_rng(seed + 77)
+        free = np.flatnonzero(P["on_bound"] == 0)
+        k = 2 if kind == "two" else 1
+        js = rng.choice(free, size=k, replace=False)
+        if kind == "upper":
+            P["x"][js] = P["ub"][js]
+        else:
+            P["x"][js] = P["lb"][js]
+        if kind == "scaled":
+            P["scale"] = np.linspace(0.5, 2.0, n)
+        return P, js
+
+    want = {"lower": 3, "two": 2, "upper": 2, "scaled": 1, "miss": 2}
+    got = {k: 0 for k in want}
+    for seed in range(600, 1200):
+        if all(got[k] >= want[k] for k in want):
+            break
+        m, n = [(24, 6), (64, 16), (40, 8)][seed % 3]
+        kind = ["lower", "two", "upper", "scaled"][seed % 4]
+        P, js = variant(seed, m, n, kind)
+        o = ref_dog_tuple(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"],
+                          P["on_bound"], 0.02)
+        fb = bool(o["fallback"])
+        if kind == "two" and fb:
+            # both unflagged variables must end up flagged (ties at t == 0)
+            if not np.all(o["on_bound_new"][js] != 0):
+                continue
+        key = kind if fb else "miss"
+        if not fb and np.abs(o["step"]).max() == 0:
+            continue
+        if got[key] >= want[key]:
+            continue
+        got[key] += 1
+        run("fb_%s_%dx%d_s%d" % (key if fb else "miss_" + kind, m, n, seed), P, 0.02)
+    assert all(got[k] >= want[k] for k in want), got
+    # the BASELINE shape of config 3 (512x64): J, f by seed, edited vectors stored
+    nbig = 0
+    for seed in range(1300, 1400):
+        if nbig >= 2:
+            break
+        P = _synth.dogbox_problem(seed, 512, 64)
+        rng = np.random.default_rng(seed + 77)
+        free = np.flatnonzero(P["on_bound"] == 0)
+        j = rng.choice(free)
+        P["x"][j] = P["lb"][j]
+        o = ref_dog_tuple(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"],
+                          P["on_bound"], 0.02)
+        if o["fallback"]:
+            nbig += 1
+            run("fb_seed%d_512x64" % seed, P, 0.02, by_seed=dict(seed=seed, m=512, n=64))
+    assert nbig == 2
+    store["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "dog_fallback.npz"), **store)
+
+
 # ---------------------------------------------------------------- drivers
 class _StrNeverEqual(np.ndarray):
     """Harness-side shim: numpy >= 1.25 makes
@@ -569,6 +658,9 @@ def make_suite():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "dogfb":
+        make_dog_fallback()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "suite":
         make_suite()
         print("suite fixture written to", HERE)
@@ -577,6 +669,7 @@ if __name__ == "__main__":
         json.dump(helpers(), fh, indent=0)
     make_trf()
     make_dog()
+    make_dog_fallback()
     make_first_iter()
     make_e2e()
     make_suite()

@@ -108,7 +108,8 @@ def test_trf_golden(bl, tr_path, name, ins, out):
     sol.close()
 
 
-DOG_CASES = load_npz("dog_small.npz") + load_npz("dog_large.npz")
+DOG_CASES = (load_npz("dog_small.npz") + load_npz("dog_large.npz") +
+             load_npz("dog_fallback.npz"))   # dogbox.py:211-216 taken (fallback = 1) + near misses
 
 
 @pytest.mark.parametrize("name,ins,out", DOG_CASES, ids=[c[0] for c in DOG_CASES])

@@ -88,7 +88,8 @@ def test_trf_tuple_matches_reference(name, ins, out):
         out["active_new"])
 
 
-DOG_CASES = load_npz("dog_small.npz") + load_npz("dog_large.npz")
+DOG_CASES = (load_npz("dog_small.npz") + load_npz("dog_large.npz") +
+             load_npz("dog_fallback.npz"))   # dogbox.py:211-216 taken (fallback = 1) + near misses
 
 
 @pytest.mark.parametrize("name,ins,out", DOG_CASES, ids=[c[0] for c in DOG_CASES])
@@ -134,3 +135,46 @@ def test_rankdef_fixture_is_noise_determined():
         worst = max(worst, np.linalg.norm(S2.p_h_tr - S.p_h_tr) / np.linalg.norm(S.p_h_tr))
         assert abs(S2.predicted_reduction - S.predicted_reduction) < 1e-3 * S.predicted_reduction
     assert worst > 1e-2
+
+
+def test_outside_trust_region_is_a_knife_edge_in_the_reference():
+    """trust_region.py:34-35 as reached from trf.py:128: solve_lsq_trust_region returns
+    ||p_h|| <= Delta up to ONE rounding, and the argument of intersect_trust_region is that
+    vector times p_stride < 1 — so "`x` is not within the trust region." needs p_stride within an
+    ulp of 1 and lucky roundings.  Evidence on the oracle (= the reference's arithmetic):
+    (i) over random steps ||p_h|| / Delta - 1 never exceeds 2 ulp; (ii) on a batch engineered to
+    to_bound = 1 - 2^-53 (the hitting variable at x = 0, where (bound - x) / p has that
+    resolution) the exception is raised for a few problems and not for the others."""
+    from bounded_lsq import _synth
+    from _cases import knife_edge_batch
+    eps = np.finfo(float).eps
+    worst = 0.0
+    for seed in range(2000, 2060):
+        m, n = [(24, 6), (40, 8), (64, 16)][seed % 3]
+        P = _synth.trf_problem(seed, m, n)
+        F = orc.trf_factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+        pg = np.linalg.norm(F.V.dot(F.uf / F.s))
+        for frac in (0.9, 0.5, 0.2, 0.05):
+            Delta = frac * pg
+            p, _, _ = orc.tr_subproblem(F.n, F.m, F.uf, F.s, F.V, Delta, initial_alpha=0.0)
+            worst = max(worst, np.linalg.norm(p) / Delta - 1.0)
+    assert worst <= 2 * eps
+    Q = knife_edge_batch(B=128, m=100, n=64)      # (a few per cent of them raise; none at n = 6)
+    raised = 0
+    for b in range(128):
+        try:
+            orc.trf_step_solve(Q["J"][b], Q["f"][b], Q["x"][b], Q["lb"][b], Q["ub"][b],
+                               Q["scale"][b], Q["Delta"][b], 0.0)
+        except ValueError as exc:
+            assert "not within the trust region" in str(exc)
+            raised += 1
+    assert 0 < raised < 16
+
+
+def test_zero_direction_needs_underflow():
+    """trust_region.py:28-29 from trf.py:128: dot(r_h, r_h) == 0 with r_h a sign-flipped p_h is
+    an underflow of the squares (|p_h| ~ 1e-170)."""
+    from _cases import zero_direction_problem
+    P = zero_direction_problem()
+    with pytest.raises(ValueError, match="`s` is zero"):
+        orc.trf_step_solve(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"], 1.0, 0.0)
