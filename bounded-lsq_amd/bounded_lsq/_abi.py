@@ -60,6 +60,7 @@ SIGNATURES = {
     "blsq_tsqr_combine_dev": (C.c_int, [vp] + [vp] * 5 + [C.c_int]),
     "blsq_debug_cqr_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
     "blsq_debug_gram_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
+    "blsq_debug_probe": (C.c_int, [vp, C.c_int, C.c_int, c_double_p]),
     "blsq_outer_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "blsq_outer_destroy": (C.c_int, [vp]),
     "blsq_outer_buffers": (C.c_int, [vp] + [C.POINTER(vp)] * 6),
@@ -176,6 +177,14 @@ class Context:
         out = (C.c_uint64 * 2)()
         self.check(self.lib.blsq_debug_gram_stats(self.h, out, 1 if reset else 0), "gram_stats")
         return int(out[0]), int(out[1])
+
+    def probe(self, kind, arg):
+        """Measured peaks (blsq_debug_probe): kind 'mfma_f64' (arg = waves per SIMD) -> (TFLOP/s,
+        MFMA wave-instructions, ms); kind 'copy' (arg = MiB) -> (GB/s read + written, bytes, ms)."""
+        out = (C.c_double * 3)()
+        self.check(self.lib.blsq_debug_probe(self.h, {"mfma_f64": 0, "copy": 1}[kind], int(arg), out),
+                   "blsq_debug_probe")
+        return float(out[0]), float(out[1]), float(out[2])
 
     # ---- timing ------------------------------------------------------------
     def timing(self, on=True):

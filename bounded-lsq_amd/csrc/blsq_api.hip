@@ -1525,6 +1525,52 @@ extern "C" int blsq_fd_assemble_dev(blsq_ctx* ctx, int B, int m, int n, int meth
   return 0;
 }
 
+extern "C" int blsq_debug_probe(blsq_ctx* ctx, int kind, int arg, double out[3]) {
+  if (!ctx) return -1;
+  if (!out) return ctx->bad(4, "out is NULL");
+  if (kind != 0 && kind != 1) return ctx->bad(2, "kind must be 0 (MFMA f64) or 1 (copy)");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipEvent_t e0 = ctx->get_event(), e1 = ctx->get_event();
+  float ms = 0.f;
+  if (kind == 0) {
+    double* sink = nullptr;
+    HIPCHK(ctx, hipMalloc((void**)&sink, 64));
+    long nm = 0;
+    const int iters = 20000;                       // x 8 MFMAs: ~10 ms per launch at the nominal rate
+    hipError_t e = launch_mfma_probe(arg, 200, sink, &nm, ctx->stream);   // warm-up
+    if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+    if (e == hipSuccess) e = launch_mfma_probe(arg, iters, sink, &nm, ctx->stream);
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    hipFree(sink);
+    ctx->pool.push_back(e0); ctx->pool.push_back(e1);
+    if (e != hipSuccess) return ctx->fail(e, "mfma probe");
+    out[0] = (double)nm * 2048.0 / ((double)ms * 1e-3) * 1e-12;
+    out[1] = (double)nm; out[2] = ms;
+    return 0;
+  }
+  if (arg <= 0) return ctx->bad(3, "copy probe needs a size in MiB");
+  const size_t bytes = (size_t)arg << 20;
+  void *src = nullptr, *dst = nullptr;
+  hipError_t e = hipMalloc(&src, bytes);
+  if (e == hipSuccess) e = hipMalloc(&dst, bytes);
+  if (e == hipSuccess) e = hipMemsetAsync(src, 1, bytes, ctx->stream);
+  if (e == hipSuccess) e = launch_copy_probe(src, dst, bytes, ctx->stream);   // warm-up
+  if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+  for (int r = 0; r < 4 && e == hipSuccess; ++r) e = launch_copy_probe(src, dst, bytes, ctx->stream);
+  if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  if (src) hipFree(src);
+  if (dst) hipFree(dst);
+  ctx->pool.push_back(e0); ctx->pool.push_back(e1);
+  if (e != hipSuccess) return ctx->fail(e, "copy probe");
+  out[0] = 4.0 * 2.0 * (double)bytes / ((double)ms * 1e-3) * 1e-9;
+  out[1] = 4.0 * 2.0 * (double)bytes; out[2] = ms;
+  return 0;
+}
+
 extern "C" int blsq_debug_gram_stats(blsq_ctx* ctx, uint64_t* out2, int reset) {
   if (!ctx) return -1;
   if (!out2) return ctx->bad(2, "out is NULL");

@@ -242,4 +242,10 @@ hipError_t launch_fd_assemble(int B, int m, int n, int method, const double* x, 
                               const unsigned char* one_sided, const double* f0, const double* F,
                               double* J, const int* mask, hipStream_t s);
 
+// ---------------------------------------------------------------- probes ----
+// probe_kernels.hip: measured peaks / counter calibration (blsq_debug_probe)
+hipError_t launch_mfma_probe(int waves_per_simd, int iters, double* sink, long* n_mfma,
+                             hipStream_t s);
+hipError_t launch_copy_probe(const void* src, void* dst, size_t bytes, hipStream_t s);
+
 }  // namespace blsq

@@ -172,6 +172,16 @@ int blsq_debug_cqr_stats(blsq_ctx* ctx, uint64_t out[2], int reset);
  * problems the gate handed to the Householder TSQR tree, since the last reset. */
 int blsq_debug_gram_stats(blsq_ctx* ctx, uint64_t out[2], int reset);
 
+/* Diagnostics: measured peaks of the device the ctx is bound to ("confirm on the
+ * box with a copy kernel and an MFMA-f64 probe").
+ *   kind 0: FP64 MFMA probe — every SIMD issues independent v_mfma_f64_16x16x4_f64 back to back on
+ *           register operands (`arg` waves per SIMD, 1 or 2); out[0] = TFLOP/s, out[1] = number of
+ *           MFMA wave-instructions executed, out[2] = milliseconds (HIP events).  The same launch
+ *           calibrates the SQ MFMA counters (tools/pmc_mfma.py).
+ *   kind 1: streaming copy of `arg` MiB (device to device, 16 B per lane); out[0] = GB/s counting
+ *           bytes read + bytes written, out[1] = bytes moved, out[2] = milliseconds. */
+int blsq_debug_probe(blsq_ctx* ctx, int kind, int arg, double out[3]);
+
 /* ---- batched outer trust-region drivers, device-resident ------------------
  * Replaces, for B problems of one shape advancing in lock-step, the Python loops around the
  * step path: trf.py:173-237 (initialisation), :238-261 (top of the outer loop: nfev / gtol
