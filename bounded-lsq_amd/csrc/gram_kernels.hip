@@ -16,6 +16,7 @@
 // Non-finite input, zero columns, rank deficiency and m < n all fail the gate by construction.
 #include <atomic>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "blsq_device.h"
 #include "blsq_kernels.h"
@@ -132,17 +133,27 @@ __global__ __launch_bounds__(GR_NT, (SLOTS <= 8 ? 4 : 2)) void gram_kernel(GramA
       }
     }
   };
+  // rhs column in registers (a.rhs_valu): a wave has the rows it stages in registers, one column
+  // per lane and 64-column block, so it adds its rows' share of J^T f / f^T f before committing
+  // them (rows w, w + 8, ... in order); the eight per-wave partials are added in wave order at
+  // the end.  gram16_wave below does exactly the same, so the two kernels agree bit for bit.
+  double gf[NCB], gff = 0.0;
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) gf[cb] = 0.0;
   auto commit = [&](int row0, int h, double* X) {
 #pragma unroll
     for (int rr = 0; rr < HR; ++rr) {
       const int lrow = w + GR_NW * (HR * h + rr);
       const bool in = row0 + lrow < m;
+      const double fv = in ? fpre[rr] : 0.0;
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
         const int col = lane + 64 * cb;
         if (col < n) X[lrow * LDX + col] = in ? pre[rr][cb] : 0.0;
+        if (rhs_here) gf[cb] = fma(pre[rr][cb], fv, gf[cb]);   // (columns >= n: clamped loads, never stored)
       }
-      if (lane == 0) X[lrow * LDX + n] = in ? fpre[rr] : 0.0;
+      if (rhs_here) gff = fma(fv, fv, gff);
+      if (lane == 0) X[lrow * LDX + n] = fv;
     }
   };
 
@@ -150,7 +161,6 @@ __global__ __launch_bounds__(GR_NT, (SLOTS <= 8 ? 4 : 2)) void gram_kernel(GramA
 #pragma unroll
   for (int t = 0; t < SLOTS; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
 
-  double gf0 = 0.0, gf1 = 0.0;                          // partial (J^T f)_c / f^T f of this thread
   double* X0 = lds;
   double* X1 = lds + GR_RC * LDX;
   // padding columns (n, LDX) of both buffers are zero for the whole pass
@@ -169,26 +179,9 @@ __global__ __launch_bounds__(GR_NT, (SLOTS <= 8 ? 4 : 2)) void gram_kernel(GramA
     const double* X = (cidx & 1) ? X1 : X0;
     double* Xn = (cidx & 1) ? X0 : X1;
     const unsigned xb = lds_addr(X) + 8u * (unsigned)(lr * LDX + lc);
-    // rhs column: thread t owns column t & 255 over half of the chunk's rows; columns 256..n (and
-    // f^T f when n >= 256) go to the first threads over all rows
-    if (rhs_here) {
-      const int c0 = tid & 255, h0 = (tid >> 8) * (GR_RC / 2);
-      if (c0 <= n) {
-#pragma unroll
-        for (int r = 0; r < GR_RC / 2; ++r)
-          gf0 = fma(X[(h0 + r) * LDX + c0], X[(h0 + r) * LDX + n], gf0);
-      }
-      const int c1 = 256 + tid;
-      if (c1 <= n) {
-#pragma unroll
-        for (int r = 0; r < GR_RC; ++r) gf1 = fma(X[r * LDX + c1], X[r * LDX + n], gf1);
-      }
-    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-#if !defined(GRAM_EXP) || (GRAM_EXP != 2 && GRAM_EXP != 3)
       if (more) issue(row0 + GR_RC, h);
-#endif
       // Operand fragments are fetched TWO MFMAs ahead of their use: the LDS round trip under
       // load is longer than one MFMA of each of the SIMD's two waves.  The reads and the counted
       // waits are explicit (the compiler would otherwise fold the stages back into one register
@@ -198,12 +191,8 @@ __global__ __launch_bounds__(GR_NT, (SLOTS <= 8 ? 4 : 2)) void gram_kernel(GramA
       double fa[3], fb[3];
       auto fetch = [&](int q) {
         const unsigned so = 8u * (unsigned)((KS * h + q / SLOTS) * 4 * LDX);
-#if defined(GRAM_EXP) && (GRAM_EXP == 1 || GRAM_EXP == 3)
-        fa[q % 3] = (double)so; fb[q % 3] = (double)xb;
-#else
         lds_read64(fa[q % 3], xb + so + 8u * (unsigned)ti[q % SLOTS]);
         lds_read64(fb[q % 3], xb + so + 8u * (unsigned)tj[q % SLOTS]);
-#endif
       };
       fetch(0);
       fetch(1);
@@ -219,9 +208,7 @@ __global__ __launch_bounds__(GR_NT, (SLOTS <= 8 ? 4 : 2)) void gram_kernel(GramA
         }
         acc[q % SLOTS] = gmfma(fa[q % 3], fb[q % 3], acc[q % SLOTS]);
       }
-#if !defined(GRAM_EXP) || (GRAM_EXP != 2 && GRAM_EXP != 3)
       if (more) commit(row0 + GR_RC, h, Xn);
-#endif
     }
     __syncthreads();
   }
@@ -236,15 +223,249 @@ __global__ __launch_bounds__(GR_NT, (SLOTS <= 8 ? 4 : 2)) void gram_kernel(GramA
     }
   }
   if (!rhs_here) return;
-  // rhs column of the Gram: the two row halves of a column, summed in a fixed order
-  lds[tid] = gf0;                                       // (the last chunk's barrier is behind us)
+  // rhs column: the eight per-wave partials, added in wave order (the last barrier is behind us)
+  constexpr int GW = 64 * NCB;
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) lds[w * GW + 64 * cb + lane] = gf[cb];
+  if (lane == 0) lds[GR_NW * GW + w] = gff;
   __syncthreads();
-  if (tid < 256 && tid <= n) G[(long)tid * a.NPAD + n] = lds[tid] + lds[tid + 256];
-  if (256 + tid <= n) G[(long)(256 + tid) * a.NPAD + n] = gf1;
+  for (int c = tid; c < n; c += GR_NT) {
+    double sum = 0.0;
+#pragma unroll
+    for (int ww = 0; ww < GR_NW; ++ww) sum += lds[ww * GW + c];
+    G[(long)c * a.NPAD + n] = sum;
+  }
+  if (tid == 0) {
+    double sum = 0.0;
+#pragma unroll
+    for (int ww = 0; ww < GR_NW; ++ww) sum += lds[GR_NW * GW + ww];
+    G[(long)n * a.NPAD + n] = sum;
+  }
   // the rest of the rhs tile column of the slot: padding columns (n, 16 NT) stay zero
   for (int e = tid; e < a.NPAD * (16 * NT - N); e += GR_NT) {
     const int r = e / (16 * NT - N), c = N + e % (16 * NT - N);
     if ((r >> 4) <= (c >> 4)) G[(long)r * a.NPAD + c] = 0.0;
+  }
+}
+
+// ---- 16 column tiles (n = 241 .. 256): static tile rows per wave -------------------------------
+// The generic kernel above keeps its tile table in registers, so every MFMA fetches both operand
+// fragments from LDS (2 ds_read_b64 per MFMA) — nothing tells the compiler that two tiles share one.
+// Here the assignment is a compile-time function of the wave: wave W owns tile rows W and 15 - W of
+// the upper triangle, (16 - W) + (W + 1) = 17 tiles for every wave.  Both operands of tile (i, j) are
+// the fragment pattern X[4 s + lr][16 c + lc] with c = i resp. c = j, and all of a wave's tiles have
+// i, j >= W: a k-step needs the 16 - W fragments of column tiles W .. 15 ONCE (9 .. 16 reads for 17
+// MFMAs instead of 34), held in two register sets so that the reads of k-step s + 1 fly behind the
+// MFMAs of k-step s.  Each wave runs its own specialisation of the row loop (wave-uniform switch);
+// the workgroup barriers are the same instruction in every specialisation.
+// The rhs column (J^T f, f^T f) at n = 256 costs no LDS pass either: a wave has the rows it stages in
+// registers (one column per lane and 64-column block), so it accumulates its rows' contribution
+// there before committing them; the eight per-wave partials are added in a fixed order at the end.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read64_off(double& dst, unsigned byte_addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(byte_addr), "n"(OFF));
+}
+
+template <int W, bool RHS>
+__device__ __forceinline__ void gram16_wave(const GramArgs& a, double* lds) {
+  constexpr int LDX = 272, NCB = 4;
+  constexpr int NF = 16 - W;                            // fragments per k-step: column tiles W .. 15
+  constexpr int N0 = 16 - W, N1 = W + 1;                // tiles of tile row W / of tile row 15 - W
+  constexpr int A1 = 15 - 2 * W;                        // fragment index of tile row 15 - W
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int lr = lane >> 4, lc = lane & 15;
+  const int n = a.n, N = n + 1;
+  const int r_lo = blockIdx.x * a.rows_per_chunk;
+  int r_hi = r_lo + a.rows_per_chunk;
+  if (r_hi > a.m) r_hi = a.m;
+  const int m = r_hi;
+  const double* Jb = a.J + (long)b * a.strideJ;
+  const double* Fb = a.F + (long)b * a.strideF;
+
+  constexpr int HR = GR_RC / GR_NW / 2;                 // rows per wave per half chunk
+  double pre[HR][NCB], fpre[HR];
+  double gf[NCB] = {0.0, 0.0, 0.0, 0.0}, gff = 0.0;     // this wave's rows of J^T f / f^T f
+  auto issue = [&](int row0, int h) {
+#pragma unroll
+    for (int rr = 0; rr < HR; ++rr) {
+      const int row = row0 + W + GR_NW * (HR * h + rr);
+      const int rc = row < m ? row : m - 1;
+      fpre[rr] = Fb[rc];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int col = lane + 64 * cb;
+        const int cc = col < n ? col : n - 1;
+        pre[rr][cb] = __builtin_nontemporal_load(Jb + (long)rc * a.ldJ + cc);
+      }
+    }
+  };
+  auto commit = [&](int row0, int h, double* X) {
+#pragma unroll
+    for (int rr = 0; rr < HR; ++rr) {
+      const int lrow = W + GR_NW * (HR * h + rr);
+      const bool in = row0 + lrow < m;
+      const double fv = in ? fpre[rr] : 0.0;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int col = lane + 64 * cb;
+        if (col < n) X[lrow * LDX + col] = in ? pre[rr][cb] : 0.0;
+        if (RHS) gf[cb] = fma(pre[rr][cb], fv, gf[cb]);   // (columns >= n: clamped loads, never stored)
+      }
+      if (RHS) gff = fma(fv, fv, gff);
+      else if (lane == 0) X[lrow * LDX + n] = fv;
+    }
+  };
+
+  v4d acc0[N0], acc1[N1];
+#pragma unroll
+  for (int t = 0; t < N0; ++t) acc0[t] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int t = 0; t < N1; ++t) acc1[t] = v4d{0.0, 0.0, 0.0, 0.0};
+
+  double* X0 = lds;
+  double* X1 = lds + GR_RC * LDX;
+  for (int idx = tid; idx < 2 * GR_RC * (LDX - N); idx += GR_NT) {   // padding columns stay zero
+    const int r = idx / (LDX - N), c = idx - r * (LDX - N);
+    lds[r * LDX + N + c] = 0.0;
+  }
+  if (RHS) {                                            // the f column is not staged: keep it defined
+    for (int r = tid; r < 2 * GR_RC; r += GR_NT) lds[r * LDX + n] = 0.0;
+  }
+  if (r_lo < m) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { issue(r_lo, h); commit(r_lo, h, X0); }
+  }
+  __syncthreads();
+
+  double fr[2][NF];
+  // one asm per k-step ties every fragment register of a set to the counted wait
+  auto wait_set = [&](double (&f)[NF]) {
+    if constexpr (NF == 16)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]),
+                   "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]), "+v"(f[10]), "+v"(f[11]),
+                   "+v"(f[12]), "+v"(f[13]), "+v"(f[14]), "+v"(f[15]));
+    else if constexpr (NF == 15)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]),
+                   "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]), "+v"(f[10]), "+v"(f[11]),
+                   "+v"(f[12]), "+v"(f[13]), "+v"(f[14]));
+    else if constexpr (NF == 14)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]),
+                   "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]), "+v"(f[10]), "+v"(f[11]),
+                   "+v"(f[12]), "+v"(f[13]));
+    else if constexpr (NF == 13)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]),
+                   "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]), "+v"(f[10]), "+v"(f[11]),
+                   "+v"(f[12]));
+    else if constexpr (NF == 12)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]),
+                   "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]), "+v"(f[10]), "+v"(f[11]));
+    else if constexpr (NF == 11)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]),
+                   "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]), "+v"(f[10]));
+    else if constexpr (NF == 10)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]),
+                   "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]), "+v"(f[9]));
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]),
+                   "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]));
+  };
+
+  int cidx = 0;
+  for (int row0 = r_lo; row0 < m; row0 += GR_RC, ++cidx) {
+    const bool more = row0 + GR_RC < m;
+    const double* X = (cidx & 1) ? X1 : X0;
+    double* Xn = (cidx & 1) ? X0 : X1;
+    const unsigned xb = lds_addr(X) + 8u * (unsigned)(lr * LDX + lc);
+    // fragments of the chunk's first k-step (its latency is exposed once per chunk)
+    static_for<0, NF>([&](auto ic) {
+      constexpr int c = decltype(ic)::value;
+      lds_read64_off<8 * 16 * (W + c)>(fr[0][c], xb);
+    });
+    static_for<0, 8>([&](auto is) {
+      constexpr int s = decltype(is)::value;            // k-step of the chunk
+      constexpr int cur = s & 1, nxt = cur ^ 1;
+      if constexpr (s == 0 || s == 4) {
+        if (more) issue(row0 + GR_RC, s / 4);
+      }
+      wait_set(fr[cur]);
+      // 17 MFMAs; the next k-step's fragments are requested two per MFMA behind the first ones
+      static_for<0, N0 + N1>([&](auto it) {
+        constexpr int t = decltype(it)::value;
+        if constexpr (t < N0) acc0[t] = gmfma(fr[cur][0], fr[cur][t], acc0[t]);
+        else acc1[t - N0] = gmfma(fr[cur][A1], fr[cur][A1 + (t - N0)], acc1[t - N0]);
+        if constexpr (s < 7) {
+          if constexpr (2 * t < NF)
+            lds_read64_off<8 * (4 * (s + 1) * LDX + 16 * (W + 2 * t))>(fr[nxt][2 * t], xb);
+          if constexpr (2 * t + 1 < NF)
+            lds_read64_off<8 * (4 * (s + 1) * LDX + 16 * (W + 2 * t + 1))>(fr[nxt][2 * t + 1], xb);
+        }
+      });
+      if constexpr (s == 3 || s == 7) {
+        if (more) commit(row0 + GR_RC, s / 4, Xn);
+      }
+    });
+    __syncthreads();
+  }
+
+  double* G = a.G + ((long)b * gridDim.x + blockIdx.x) * (long)a.NPAD * a.NPAD;
+#pragma unroll
+  for (int t = 0; t < N0; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      G[(long)(16 * W + lr + 4 * g) * a.NPAD + 16 * (W + t) + lc] = acc0[t][g];
+#pragma unroll
+  for (int t = 0; t < N1; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      G[(long)(16 * (15 - W) + lr + 4 * g) * a.NPAD + 16 * (15 - W + t) + lc] = acc1[t][g];
+  if (!RHS) return;
+  // rhs column: the eight per-wave partials, added in wave order (the last barrier is behind us)
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) lds[W * 256 + 64 * cb + lane] = gf[cb];
+  if (lane == 0) lds[GR_NW * 256 + W] = gff;
+  __syncthreads();
+  if (tid < n) {
+    double sum = 0.0;
+#pragma unroll
+    for (int ww = 0; ww < GR_NW; ++ww) sum += lds[ww * 256 + tid];
+    G[(long)tid * a.NPAD + n] = sum;
+  }
+  if (tid == 0) {
+    double sum = 0.0;
+#pragma unroll
+    for (int ww = 0; ww < GR_NW; ++ww) sum += lds[GR_NW * 256 + ww];
+    G[(long)n * a.NPAD + n] = sum;
+  }
+  const int NT = (N + 15) / 16;
+  for (int e = tid; e < a.NPAD * (16 * NT - N); e += GR_NT) {   // padding columns of the rhs tile column
+    const int r = e / (16 * NT - N), c = N + e % (16 * NT - N);
+    if ((r >> 4) <= (c >> 4)) G[(long)r * a.NPAD + c] = 0.0;
+  }
+}
+
+template <bool RHS>
+__global__ __launch_bounds__(GR_NT, 2) void gram16_kernel(GramArgs a) {
+  extern __shared__ double lds[];
+  if (a.mask && a.mask[blockIdx.y] <= 1) return;
+  const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  switch (w) {
+    case 0: gram16_wave<0, RHS>(a, lds); break;
+    case 1: gram16_wave<1, RHS>(a, lds); break;
+    case 2: gram16_wave<2, RHS>(a, lds); break;
+    case 3: gram16_wave<3, RHS>(a, lds); break;
+    case 4: gram16_wave<4, RHS>(a, lds); break;
+    case 5: gram16_wave<5, RHS>(a, lds); break;
+    case 6: gram16_wave<6, RHS>(a, lds); break;
+    default: gram16_wave<7, RHS>(a, lds); break;
   }
 }
 
@@ -965,8 +1186,10 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s) {
     const int per_ = (nt * (nt + 1) / 2 + GR_NW - 1) / GR_NW;
     return per_ <= 4 ? 4 : per_ <= 8 ? 8 : per_ <= 12 ? 12 : per_ <= 17 ? 17 : 20;
   };
-  // the rhs column goes to the vector ALUs where that saves tile slots (n = 256: 20 -> 17)
-  a.rhs_valu = slots_for((a.n + 15) / 16) < slots_for(NT) ? 1 : 0;
+  // n % 16 == 0: the rhs column would be a tile column of its own (NT tiles for one useful column
+  // each) — it is accumulated in registers beside the MFMA stream instead (n = 256: 153 -> 136 tiles)
+  a.rhs_valu = ((a.n + 15) / 16 < NT) ? 1 : 0;
+  (void)slots_for;
   const int NTJ = a.rhs_valu ? (a.n + 15) / 16 : NT;
   const int ntile = NTJ * (NTJ + 1) / 2;
 #define BLSQ_GRAM_LAUNCH(SL, CB)                                                              \
@@ -1009,6 +1232,26 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s) {
     if (tg > 8) tg = 8;
     if (tg > ntile) tg = ntile;
     if (tg < 1) tg = 1;
+  }
+  {
+    // 16 column tiles of J^T J (n = 241 .. 256) and one workgroup per row chunk: the kernel with
+    // static tile rows per wave (BLSQ_GRAM16 = 0 keeps the generic one: tests compare the two)
+    const char* g16e = getenv("BLSQ_GRAM16");
+    const int g16_env = g16e ? atoi(g16e) : 1;
+    if (NTJ == 16 && tg == 1 && g16_env != 0 && a.m >= 1) {
+      if (a.rhs_valu) {
+        static std::atomic<size_t> granted[64];
+        hipError_t ge = gram_grant_lds(gram16_kernel<true>, lds, granted);
+        if (ge != hipSuccess) return ge;
+        hipLaunchKernelGGL((gram16_kernel<true>), dim3(chunks, B, 1), dim3(GR_NT), lds, s, a);
+      } else {
+        static std::atomic<size_t> granted[64];
+        hipError_t ge = gram_grant_lds(gram16_kernel<false>, lds, granted);
+        if (ge != hipSuccess) return ge;
+        hipLaunchKernelGGL((gram16_kernel<false>), dim3(chunks, B, 1), dim3(GR_NT), lds, s, a);
+      }
+      return hipGetLastError();
+    }
   }
   const int per = (((ntile + tg - 1) / tg) + GR_NW - 1) / GR_NW;   // tile slots a wave needs
   if (per <= 4) {                                       // n <= 111, or tile groups

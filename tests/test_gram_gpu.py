@@ -266,3 +266,30 @@ def test_tile_groups_do_not_change_a_single_bit(bl, monkeypatch):
             outs.append(sol.step(Delta, np.zeros(B)).step.copy())
             sol.close(); ctx.close()
         assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_static_tile_row_kernel_matches_the_generic_one_bit_for_bit(bl, monkeypatch):
+    """n = 241 .. 256 (16 column tiles) with one workgroup per row chunk runs gram16_kernel (static
+    tile rows per wave, shared operand fragments); every tile still accumulates the same k-steps in
+    the same order and the rhs column is summed in the same order as in the generic kernel, so the
+    whole step is bitwise the same (BLSQ_GRAM16 = 0 forces the generic kernel) — and so a problem's
+    bits do not depend on whether its batch was small enough for tile groups."""
+    from bounded_lsq import _synth, _abi
+    for (B, m, n) in [(3, 4096, 256), (2, 2100, 250), (2, 5000, 241), (2, 1000, 256), (2, 900, 255)]:
+        P = _synth.trf_batch(51 + n, B, m, n)
+        Delta = np.full(B, 0.7)
+        outs = []
+        for g16, tg in (("1", "1"), ("0", "1"), ("1", "4")):
+            monkeypatch.setenv("BLSQ_GRAM16", g16)
+            monkeypatch.setenv("BLSQ_GRAM_TILE_GROUPS", tg)
+            ctx = _abi.Context(0)
+            sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
+            ctx.gram_stats(reset=True)
+            sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+            assert ctx.gram_stats() == (B, 0)
+            S = sol.step(Delta, np.zeros(B))
+            outs.append((S.step.copy(), sol.fetch_factor().g.copy()))
+            sol.close(); ctx.close()
+        for o in outs[1:]:
+            assert np.array_equal(outs[0][1], o[1])        # g = J^T f: the rhs column
+            assert np.array_equal(outs[0][0], o[0])
