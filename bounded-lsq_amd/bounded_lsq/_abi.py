@@ -55,7 +55,15 @@ SIGNATURES = {
     "blsq_dogbox_fetch_factor": (C.c_int, [vp] + [vp] * 7),
     "blsq_dogbox_fetch_step": (C.c_int, [vp] + [vp] * 8),
     "blsq_tsqr_tri_ld": (C.c_int, [C.c_int]),
-    "blsq_tsqr_plan_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    "blsq_comm_id_bytes": (C.c_int, []),
+    "blsq_comm_get_id": (C.c_int, [vp, vp, C.c_size_t]),
+    "blsq_comm_init": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_size_t]),
+    "blsq_comm_destroy": (C.c_int, [vp]),
+    "blsq_comm_size": (C.c_int, [vp]),
+    "blsq_comm_rank": (C.c_int, [vp]),
+    "blsq_comm_allreduce_max": (C.c_int, [vp, c_double_p, C.c_int]),
+    "blsq_tsqr_plan_create": (C.c_int, [vp, C.c_int, C.c_longlong, C.c_int, C.c_int, C.POINTER(vp)]),
+    "blsq_tsqr_factor_dev": (C.c_int, [vp] + [vp] * 6 + [C.c_int]),
     "blsq_tsqr_local_dev": (C.c_int, [vp, vp, vp, vp]),
     "blsq_tsqr_combine_dev": (C.c_int, [vp] + [vp] * 5 + [C.c_int]),
     "blsq_debug_cqr_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
@@ -177,6 +185,29 @@ class Context:
         out = (C.c_uint64 * 2)()
         self.check(self.lib.blsq_debug_gram_stats(self.h, out, 1 if reset else 0), "gram_stats")
         return int(out[0]), int(out[1])
+
+    # ---- collective over the ranks of one tall problem (RCCL, blsq_comm_*) ---------------------
+    def comm_new_id(self):
+        """Rendezvous id (bytes) — call on ONE rank and hand it to the others."""
+        n = self.lib.blsq_comm_id_bytes()
+        buf = (C.c_char * n)()
+        self.check(self.lib.blsq_comm_get_id(self.h, buf, n), "blsq_comm_get_id")
+        return bytes(buf)
+
+    def comm_init(self, nranks, rank, comm_id):
+        buf = C.create_string_buffer(bytes(comm_id), len(comm_id))
+        self.check(self.lib.blsq_comm_init(self.h, int(nranks), int(rank), buf, len(comm_id)),
+                   "blsq_comm_init")
+
+    def comm_destroy(self):
+        self.check(self.lib.blsq_comm_destroy(self.h), "blsq_comm_destroy")
+
+    def comm_max(self, values):
+        """Max over the ranks (also a barrier); `values`: up to 64 floats."""
+        arr = np.ascontiguousarray(values, dtype=np.float64).copy()
+        self.check(self.lib.blsq_comm_allreduce_max(self.h, arr.ctypes.data_as(c_double_p),
+                                                    arr.size), "blsq_comm_allreduce_max")
+        return arr
 
     def probe(self, kind, arg):
         """Measured peaks (blsq_debug_probe): kind 'mfma_f64' (arg = waves per SIMD) -> (TFLOP/s,

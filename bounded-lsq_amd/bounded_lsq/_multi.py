@@ -1,21 +1,24 @@
-"""Multi-GPU host logic: one process per GPU (torch.distributed over RCCL).
+"""Multi-GPU host logic: one process per GPU, no PyTorch.
 
 Two cases:
 
-* batches of independent problems -> contiguous shards, NO data-path
-  collective (``shard_range``);
-* ONE very tall problem -> row blocks; each rank factors its block of [J f] to
-  an (n+1)x(n+1) triangle on its GPU, the triangles are exchanged with ONE
-  all-gather (RCCL over xGMI: n=128 -> 162 KB per rank, latency-bound), every
-  rank merges the stack and runs the ordinary n-space path redundantly, so
-  g, the SVD factor and the step come out replicated (``TsqrTrfSolver``).
+* batches of independent problems -> contiguous shards, NO data-path collective
+  (``shard_range``);
+* ONE very tall problem -> row blocks (``row_block``); ``TsqrTrfSolver.factor_dev`` takes this
+  rank's block and the library does the rest on its own stream: local Gram, ONE
+  ``ncclAllReduce`` of the (n+1)^2 Gram over RCCL / xGMI, replicated Cholesky + gate — or, for a
+  problem the gate rejects, local Householder TSQR, ONE ``ncclAllGather`` of the triangles and a
+  replicated merge (``blsq_tsqr_factor_dev``).  Every rank ends with the same factor state and
+  computes the same step.
 
-torch is plumbing here (exchange buffers + the collective); all arithmetic is
-in libblsq_hip.so.
+The only thing the host has to move between the ranks is the communicator's rendezvous id (128
+bytes, once): ``exchange_id_tcp`` does that over a plain TCP socket; any other channel works
+(``comm_id=`` takes the bytes).
 """
 import ctypes as C
-
-import numpy as np
+import socket
+import struct
+import time
 
 from . import _abi
 from ._hip_step import TrfStepSolver, SCALE_GIVEN
@@ -37,39 +40,82 @@ def tri_ld(n):
     return (n + 1 + 15) // 16 * 16
 
 
-def allgather_triangles(local_tri, world):
-    """All-gather of the per-rank triangles (torch tensor, any device) ->
-    tensor [world, ld, ld] in rank order.  backend nccl == RCCL on ROCm."""
-    import torch
-    import torch.distributed as dist
-    out = torch.empty((world,) + tuple(local_tri.shape), dtype=local_tri.dtype,
-                      device=local_tri.device)
-    if world == 1:
-        out[0].copy_(local_tri)
-        return out
-    dist.all_gather_into_tensor(out.view(-1), local_tri.contiguous().view(-1))
-    return out
+def exchange_id_tcp(rank, world, addr, port, make_id, timeout=120.0):
+    """Rank 0 calls ``make_id()`` (-> bytes) and serves it to the other world - 1 ranks on
+    (addr, port); they connect (retrying until `timeout`) and receive it.  Returns the id on
+    every rank.  Plain sockets: no dependency beyond the standard library."""
+    rank, world = int(rank), int(world)
+    if rank == 0:
+        payload = bytes(make_id())
+        if world == 1:
+            return payload
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, int(port)))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            for _ in range(world - 1):
+                conn, _peer = srv.accept()
+                with conn:
+                    conn.sendall(struct.pack("<I", len(payload)) + payload)
+        return payload
+    deadline = time.time() + timeout
+    while True:
+        try:
+            with socket.create_connection((addr, int(port)), timeout=5.0) as sk:
+                head = _recv_exact(sk, 4)
+                return _recv_exact(sk, struct.unpack("<I", head)[0])
+        except (ConnectionRefusedError, socket.timeout, OSError):
+            if time.time() > deadline:
+                raise
+            time.sleep(0.05)
+
+
+def _recv_exact(sk, n):
+    buf = b""
+    while len(buf) < n:
+        chunk = sk.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("peer closed while sending the communicator id")
+        buf += chunk
+    return buf
 
 
 class TsqrTrfSolver(TrfStepSolver):
     """TRF step solver for one tall problem whose rows are split over ranks.
 
-    ``factor_dev`` takes THIS rank's row block (device pointers); the state
-    after it (and every ``step``) is identical on all ranks.
+    ``factor_dev`` takes THIS rank's row block (device pointers); the state after it (and every
+    ``step``) is identical on all ranks.  `m_total` = rows of the whole problem (it enters the
+    reference's rank test, trust_region.py:109, and must be the same number everywhere).
+    `comm_id`: the rendezvous id every rank got from rank 0 (``Context.comm_new_id`` +
+    ``exchange_id_tcp``); None when the ctx already carries a communicator, when world == 1, or
+    when the caller exchanges the triangles itself (``local_triangle_dev`` / ``combine_dev``).
     """
 
-    def __init__(self, m_local, n, world, rank, ctx=None):  # noqa: D401 (no super().__init__)
+    def __init__(self, m_local, n, world, rank, ctx=None, m_total=None, comm_id=None):  # noqa: D401
         from ._hip_step import default_context
         self.ctx = ctx or default_context()
         self.lib = self.ctx.lib
         self.B, self.m, self.n = 1, int(m_local), int(n)
         self.world, self.rank = int(world), int(rank)
+        self.m_total = int(m_total) if m_total is not None else self.m * self.world
         self.ld = tri_ld(n)
+        if comm_id is not None:
+            self.ctx.comm_init(self.world, self.rank, comm_id)
         h = _abi.vp()
-        self.ctx.check(self.lib.blsq_tsqr_plan_create(self.ctx.h, self.m, self.n, self.world,
-                                                      C.byref(h)), "blsq_tsqr_plan_create")
+        self.ctx.check(self.lib.blsq_tsqr_plan_create(self.ctx.h, self.m, self.m_total, self.n,
+                                                      self.world, C.byref(h)),
+                       "blsq_tsqr_plan_create")
         self.h = h
 
+    def factor_dev(self, dJ_block, df_block, dx, dlb, dub, dscale, scale_mode=SCALE_GIVEN):
+        """local Gram -> all-reduce -> Cholesky + gate (or: local TSQR -> all-gather -> merge),
+        then the n-space path; asynchronous on the ctx stream apart from the gate read-back."""
+        self.ctx.check(self.lib.blsq_tsqr_factor_dev(self.h, dJ_block, df_block, dx, dlb, dub,
+                                                     dscale, int(scale_mode)),
+                       "blsq_tsqr_factor_dev")
+
+    # the two halves of the Householder route, for hosts that exchange the triangles themselves
     def local_triangle_dev(self, dJ_block, df_block, dtri_out):
         self.ctx.check(self.lib.blsq_tsqr_local_dev(self.h, dJ_block, df_block, dtri_out),
                        "blsq_tsqr_local_dev")
@@ -78,16 +124,3 @@ class TsqrTrfSolver(TrfStepSolver):
         self.ctx.check(self.lib.blsq_tsqr_combine_dev(self.h, dtri_stack, dx, dlb, dub, dscale,
                                                       int(scale_mode)),
                        "blsq_tsqr_combine_dev")
-
-    def factor_dev(self, dJ_block, df_block, dx, dlb, dub, dscale, scale_mode=SCALE_GIVEN):
-        """local QR -> all-gather (torch.distributed, RCCL) -> merge + n-space."""
-        import torch
-        dev = torch.device("cuda", self.ctx.device_id)
-        tri = torch.empty((self.ld, self.ld), dtype=torch.float64, device=dev)
-        self.local_triangle_dev(dJ_block, df_block, _abi.vp(tri.data_ptr()))
-        self.ctx.sync()                                   # library stream -> torch stream
-        stack = allgather_triangles(tri, self.world)
-        torch.cuda.synchronize(dev)
-        self.combine_dev(_abi.vp(stack.data_ptr()), dx, dlb, dub, dscale, scale_mode)
-        self.ctx.sync()
-        return stack

@@ -2,6 +2,8 @@
 // the kernel sequence of each call.  Host-side only; kernels live in the
 // sibling .hip files.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is dlopen'ed on first use
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -49,6 +51,9 @@ struct blsq_ctx {
   std::vector<hipEvent_t> pool;
   int* pinned = nullptr;            // 4 pinned host ints: device -> host counters without staging
   long long gram_fast = 0, gram_fallback = 0;   // problems factored by the normal equations / handed to the QR tree
+  // collective over the ranks of one tall problem (RCCL over xGMI; blsq_comm_*)
+  ncclComm_t comm = nullptr;
+  int comm_ranks = 1, comm_rank = 0;
 
   int fail(hipError_t e, const char* where) {
     err = std::string(where) + ": " + hipGetErrorString(e);
@@ -95,6 +100,62 @@ struct blsq_ctx {
   } while (0)
 
 namespace {
+
+// ---- RCCL, bound at run time ------------------------------------------------------------------
+// Only the tall-problem path needs a collective, so librccl (0.5 GB) is not a link-time dependency:
+// it is dlopen'ed by the first blsq_comm_* call, from the directory of the HIP runtime this process
+// already uses (a host that imported PyTorch first runs on PyTorch's bundled runtime and must get
+// the RCCL built against it; everybody else gets /opt/rocm's).
+struct Rccl {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string err;
+  bool load() {
+    if (lib) return true;
+    std::vector<std::string> cand;
+    Dl_info info;
+    if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+      std::string dir(info.dli_fname);
+      const size_t k = dir.rfind('/');
+      if (k != std::string::npos) {
+        dir.resize(k);
+        cand.push_back(dir + "/librccl.so.1");
+        cand.push_back(dir + "/librccl.so");
+      }
+    }
+    cand.push_back("librccl.so.1");
+    cand.push_back("/opt/rocm/lib/librccl.so.1");
+    for (const auto& c : cand) {
+      lib = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) { err = std::string("dlopen(librccl): ") + dlerror(); return false; }
+#define BLSQ_RCCL_SYM(name)                                                 \
+    name = reinterpret_cast<decltype(name)>(dlsym(lib, "nccl" #name));        \
+    if (!name) { err = "librccl lacks nccl" #name; dlclose(lib); lib = nullptr; return false; }
+    BLSQ_RCCL_SYM(GetUniqueId) BLSQ_RCCL_SYM(CommInitRank) BLSQ_RCCL_SYM(CommDestroy)
+    BLSQ_RCCL_SYM(AllGather) BLSQ_RCCL_SYM(AllReduce) BLSQ_RCCL_SYM(GetErrorString)
+#undef BLSQ_RCCL_SYM
+    return true;
+  }
+};
+Rccl g_rccl;
+constexpr int RCCL_ERR_BASE = 10000;           // return code of a failed RCCL call: 10000 + ncclResult_t
+
+int rccl_fail(blsq_ctx* ctx, ncclResult_t r, const char* where) {
+  ctx->err = std::string(where) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error");
+  return RCCL_ERR_BASE + (int)r;
+}
+#define RCCLCHK(ctx, call)                                           \
+  do {                                                               \
+    ncclResult_t r__ = (call);                                       \
+    if (r__ != ncclSuccess) return rccl_fail((ctx), r__, #call);     \
+  } while (0)
 
 struct DevBuf {
   void* p = nullptr;
@@ -187,6 +248,8 @@ struct QrTree {
       if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Grams)");
       e = gram_ints.alloc(sizeof(int) * (2 * (size_t)B + 4));     // launch mask, count, path
       if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Gram mask)");
+      e = hipMemsetAsync(gram_keep.p, 0, gram_keep.bytes, ctx->stream);      // (lower tiles are never written)
+      if (e != hipSuccess) return ctx->fail(e, "hipMemsetAsync(Grams)");
       e = hipMemsetAsync(gram_ints.p, 0xFF, gram_ints.bytes, ctx->stream);   // path: all QR until factored
       if (e != hipSuccess) return ctx->fail(e, "hipMemsetAsync(Gram mask)");
     }
@@ -200,8 +263,11 @@ struct QrTree {
   // [J f] -> triangle by the normal equations where the conditioning gate allows it.
   // Returns the number of problems left for the Householder tree in *nfallback; their indices
   // are flagged in the fallback mask (n + 1 / 0 per problem).
+  // `collective`: the rows of the problem are split over the ranks of ctx->comm — the local Grams
+  // are summed over the ranks (ONE ncclAllReduce on the ctx stream) before the factorisation, which
+  // is then replicated: every rank holds the same bits, so every rank takes the same gate decision.
   int run_gram(blsq_ctx* ctx, const double* dJ, const double* df, int ldJ, const int* mask,
-               int* nfallback) {
+               int* nfallback, bool collective) {
     int* fb = gram_ints.as<int>();
     int* cnt = fb + B;
     HIPCHK(ctx, hipMemsetAsync(cnt, 0, sizeof(int), ctx->stream));
@@ -217,6 +283,9 @@ struct QrTree {
       e = launch_gram_reduce(gram_part.as<double>(), gram_nchunk, NPAD, Gk, mask, B, ctx->stream);
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_gram");
+    if (collective && ctx->comm && ctx->comm_ranks > 1)
+      RCCLCHK(ctx, g_rccl.AllReduce(Gk, Gk, (size_t)B * NPAD * NPAD, ncclDouble, ncclSum, ctx->comm,
+                                    ctx->stream));
     GramCholArgs c{};
     c.Gsrc = Gk; c.G = Rf; c.NPAD = NPAD; c.n = n; c.mask = mask; c.fb_mask = fb; c.fail_count = cnt;
     c.path_out = fb + B + 4;
@@ -246,10 +315,10 @@ struct QrTree {
   // ncols_mask (optional, device [B]): problems with an entry <= 1 are skipped — their
   // triangles of the previous run stay in place (outer driver: only fresh Jacobians are factored)
   int run(blsq_ctx* ctx, const double* dJ, const double* df, int ldJ,
-          const int* ncols_mask = nullptr) {
+          const int* ncols_mask = nullptr, bool collective = false) {
     if (gram && df != nullptr) {
       int nfb = 0;
-      int rc = run_gram(ctx, dJ, df, ldJ, ncols_mask, &nfb);
+      int rc = run_gram(ctx, dJ, df, ldJ, ncols_mask, &nfb, collective);
       if (rc) return rc;
       ctx->gram_fallback += nfb;
       ctx->gram_fast += B - nfb;            // (masked problems count as fast: diagnostics only)
@@ -299,6 +368,7 @@ struct blsq_trf_plan {
   // TSQR (multi-rank) extras
   int nranks = 1, m_total = 0;
   DevBuf Rcomb;                     // [1][NPAD*NPAD] merged triangle
+  DevBuf Rstack;                    // [nranks][NPAD*NPAD] gathered triangles (blsq_tsqr_factor_dev)
   // n-space state
   DevBuf X, vecs, scal2, sweeps;
   DevBuf o_vec, o_hits, o_act, o_scal, o_info;
@@ -360,6 +430,8 @@ extern "C" int blsq_ctx_destroy(blsq_ctx* ctx) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   ctx->collect();
+  if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+  ctx->comm = nullptr;
   for (auto e : ctx->pool) hipEventDestroy(e);
   hipStreamDestroy(ctx->stream);
   if (ctx->pinned) hipHostFree(ctx->pinned);
@@ -375,6 +447,73 @@ extern "C" int blsq_sync(blsq_ctx* ctx) {
   if (!ctx) return -1;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->collect();
+  return 0;
+}
+
+// ================================================================= comm ====
+extern "C" int blsq_comm_id_bytes(void) { return NCCL_UNIQUE_ID_BYTES; }
+
+extern "C" int blsq_comm_get_id(blsq_ctx* ctx, void* id_out, size_t bytes) {
+  if (!ctx) return -1;
+  if (!id_out) return ctx->bad(2, "id_out is NULL");
+  if (bytes < (size_t)NCCL_UNIQUE_ID_BYTES) return ctx->bad(3, "id buffer too small (blsq_comm_id_bytes)");
+  if (!g_rccl.load()) { ctx->err = g_rccl.err; return RCCL_ERR_BASE; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ncclUniqueId id;
+  RCCLCHK(ctx, g_rccl.GetUniqueId(&id));
+  memcpy(id_out, &id, NCCL_UNIQUE_ID_BYTES);
+  return 0;
+}
+
+extern "C" int blsq_comm_init(blsq_ctx* ctx, int nranks, int rank, const void* id, size_t bytes) {
+  if (!ctx) return -1;
+  if (nranks < 1) return ctx->bad(2, "nranks must be positive");
+  if (rank < 0 || rank >= nranks) return ctx->bad(3, "rank out of range");
+  if (!id) return ctx->bad(4, "id is NULL");
+  if (bytes < (size_t)NCCL_UNIQUE_ID_BYTES) return ctx->bad(5, "id too small (blsq_comm_id_bytes)");
+  if (ctx->comm) return ctx->bad(1, "this ctx already has a communicator");
+  if (!g_rccl.load()) { ctx->err = g_rccl.err; return RCCL_ERR_BASE; }
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ncclUniqueId uid;
+  memcpy(&uid, id, NCCL_UNIQUE_ID_BYTES);
+  RCCLCHK(ctx, g_rccl.CommInitRank(&ctx->comm, nranks, uid, rank));
+  ctx->comm_ranks = nranks; ctx->comm_rank = rank;
+  return 0;
+}
+
+extern "C" int blsq_comm_destroy(blsq_ctx* ctx) {
+  if (!ctx) return -1;
+  if (!ctx->comm) return 0;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  RCCLCHK(ctx, g_rccl.CommDestroy(ctx->comm));
+  ctx->comm = nullptr; ctx->comm_ranks = 1; ctx->comm_rank = 0;
+  return 0;
+}
+
+extern "C" int blsq_comm_size(const blsq_ctx* ctx) { return ctx ? ctx->comm_ranks : 0; }
+extern "C" int blsq_comm_rank(const blsq_ctx* ctx) { return ctx ? ctx->comm_rank : -1; }
+
+// max over the ranks of `n` host doubles (n <= 64), which is also a barrier: used by bench.py for
+// the max-over-ranks timing; blocks until the collective has finished on the ctx stream
+extern "C" int blsq_comm_allreduce_max(blsq_ctx* ctx, double* host_io, int n) {
+  if (!ctx) return -1;
+  if (!host_io) return ctx->bad(2, "host_io is NULL");
+  if (n < 1 || n > 64) return ctx->bad(3, "n must be in 1..64");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (!ctx->comm || ctx->comm_ranks == 1) return 0;
+  double* d = nullptr;
+  HIPCHK(ctx, hipMalloc((void**)&d, sizeof(double) * 64));
+  hipError_t e = hipMemcpyAsync(d, host_io, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream);
+  ncclResult_t r = ncclSuccess;
+  if (e == hipSuccess) r = g_rccl.AllReduce(d, d, (size_t)n, ncclDouble, ncclMax, ctx->comm, ctx->stream);
+  if (e == hipSuccess && r == ncclSuccess)
+    e = hipMemcpyAsync(host_io, d, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(d);
+  if (r != ncclSuccess) return rccl_fail(ctx, r, "ncclAllReduce(max)");
+  if (e != hipSuccess) return ctx->fail(e, "blsq_comm_allreduce_max");
   return 0;
 }
 
@@ -660,7 +799,7 @@ extern "C" int blsq_trf_plan_create(blsq_ctx* ctx, int B, int m, int n, blsq_trf
 extern "C" int blsq_trf_plan_destroy(blsq_trf_plan* p) {
   if (!p) return -1;
   hipStreamSynchronize(p->ctx->stream);
-  p->tree.release(); p->Rcomb.release();
+  p->tree.release(); p->Rcomb.release(); p->Rstack.release();
   p->X.release(); p->vecs.release(); p->scal2.release(); p->sweeps.release();
   p->o_vec.release(); p->o_hits.release(); p->o_act.release(); p->o_scal.release();
   p->o_info.release(); p->in_J.release(); p->in_f.release(); p->in_vec.release();
@@ -851,23 +990,25 @@ extern "C" int blsq_trf_step(blsq_trf_plan* p, const double* Delta, double* alph
 // ================================================================= TSQR ====
 extern "C" int blsq_tsqr_tri_ld(int n) { return round_up(n + 1, 16); }
 
-extern "C" int blsq_tsqr_plan_create(blsq_ctx* ctx, int m_local, int n, int nranks,
-                                     blsq_trf_plan** out) {
+extern "C" int blsq_tsqr_plan_create(blsq_ctx* ctx, int m_local, long long m_total, int n,
+                                     int nranks, blsq_trf_plan** out) {
   if (!ctx) return -1;
-  if (!out) return ctx->bad(5, "out is NULL");
+  if (!out) return ctx->bad(6, "out is NULL");
   *out = nullptr;
   if (m_local <= 0) return ctx->bad(2, "m_local must be positive");
-  if (n <= 0) return ctx->bad(3, "n must be positive");
-  if (nranks <= 0) return ctx->bad(4, "nranks must be positive");
+  if (m_total < m_local) return ctx->bad(3, "m_total must be >= m_local");
+  if (n <= 0) return ctx->bad(4, "n must be positive");
+  if (nranks <= 0) return ctx->bad(5, "nranks must be positive");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   blsq_trf_plan* p = new blsq_trf_plan();
   p->ctx = ctx; p->B = 1; p->m = m_local; p->n = n; p->nranks = nranks;
-  long long mt = (long long)m_local * nranks;
-  p->m_total = mt > 2147483647LL ? 2147483647 : (int)mt;
+  // the GLOBAL row count enters the reference's rank test eps * m * s[0] (trust_region.py:109):
+  // it must be the same number on every rank, whatever the sizes of the row blocks
+  p->m_total = m_total > 2147483647LL ? 2147483647 : (int)m_total;
   const int NPAD = round_up(n + 1, 16);
   if (nranks > 1 && !merge_fits(n)) {
     delete p;
-    return ctx->bad(3, "TSQR needs n <= 512");
+    return ctx->bad(4, "TSQR needs n <= 512");
   }
   const int aug_rp = std::max(aug_rows(n), NPAD);
   // scratch must also cover the combine merges: nranks triangles, G per workgroup
@@ -880,6 +1021,10 @@ extern "C" int blsq_tsqr_plan_create(blsq_ctx* ctx, int m_local, int n, int nran
     hipError_t e = p->Rcomb.alloc(sizeof(double) * 2 * (size_t)((nranks + G - 1) / G + 1) *
                                   NPAD * NPAD);
     if (e != hipSuccess) rc = ctx->fail(e, "hipMalloc(Rcomb)");
+  }
+  if (rc == 0) {
+    hipError_t e = p->Rstack.alloc(sizeof(double) * (size_t)nranks * NPAD * NPAD);
+    if (e != hipSuccess) rc = ctx->fail(e, "hipMalloc(Rstack)");
   }
   if (rc != 0) { blsq_trf_plan_destroy(p); return rc; }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -902,18 +1047,11 @@ extern "C" int blsq_tsqr_local_dev(blsq_trf_plan* p, const double* dJ_block,
   return 0;
 }
 
-extern "C" int blsq_tsqr_combine_dev(blsq_trf_plan* p, const double* dtri_stack,
-                                     const double* dx, const double* dlb, const double* dub,
-                                     double* dscale_io, int scale_mode) {
-  if (!p) return -1;
+namespace {
+// merge the stack of nranks triangles (rank order) and run the n-space path on the result
+int tsqr_merge_and_finish(blsq_trf_plan* p, const double* dtri_stack, int scale_mode,
+                          double* dscale_io) {
   blsq_ctx* ctx = p->ctx;
-  if (!dtri_stack) return ctx->bad(2, "tri stack is NULL");
-  if (!dx || !dlb || !dub) return ctx->bad(3, "x/lb/ub is NULL");
-  if (!dscale_io) return ctx->bad(6, "scale is NULL");
-  if (scale_mode < 0 || scale_mode > 2) return ctx->bad(7, "scale_mode");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  int rc = trf_put_bounds(p, dx, dlb, dub, dscale_io, hipMemcpyDeviceToDevice);
-  if (rc) return rc;
   const int NPAD = p->ld;
   const double* src = dtri_stack;
   int ntri = p->nranks;
@@ -937,12 +1075,66 @@ extern "C" int blsq_tsqr_combine_dev(blsq_trf_plan* p, const double* dtri_stack,
     flip ^= 1;
     ntri = nleaf;
   }
-  if ((rc = trf_after_triangle(p, src, scale_mode))) return rc;
+  int rc = trf_after_triangle(p, src, scale_mode);
+  if (rc) return rc;
   if (scale_mode != BLSQ_SCALE_GIVEN) {
     HIPCHK(ctx, hipMemcpyAsync(dscale_io, p->st.scale, sizeof(double) * p->n,
                                hipMemcpyDeviceToDevice, ctx->stream));
   }
   return 0;
+}
+}  // namespace
+
+extern "C" int blsq_tsqr_combine_dev(blsq_trf_plan* p, const double* dtri_stack,
+                                     const double* dx, const double* dlb, const double* dub,
+                                     double* dscale_io, int scale_mode) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!dtri_stack) return ctx->bad(2, "tri stack is NULL");
+  if (!dx || !dlb || !dub) return ctx->bad(3, "x/lb/ub is NULL");
+  if (!dscale_io) return ctx->bad(6, "scale is NULL");
+  if (scale_mode < 0 || scale_mode > 2) return ctx->bad(7, "scale_mode");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = trf_put_bounds(p, dx, dlb, dub, dscale_io, hipMemcpyDeviceToDevice);
+  if (rc) return rc;
+  return tsqr_merge_and_finish(p, dtri_stack, scale_mode, dscale_io);
+}
+
+// The whole factor call of one tall problem whose rows are split over the ranks of the ctx's
+// communicator (blsq_comm_init), this rank's row block in, replicated factor state out:
+//   normal-equations front end:  local Gram -> ncclAllReduce(sum) of the (n+1)^2 Gram -> Cholesky + gate
+//                                (replicated, bit-identical on every rank)
+//   if the gate rejects:         local Householder TSQR -> ncclAllGather of the triangles -> merge
+// then the ordinary n-space path.  Everything is enqueued on the ctx stream; the only host wait is
+// the read-back of the gate's verdict (one integer).
+extern "C" int blsq_tsqr_factor_dev(blsq_trf_plan* p, const double* dJ_block, const double* df_block,
+                                    const double* dx, const double* dlb, const double* dub,
+                                    double* dscale_io, int scale_mode) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!dJ_block) return ctx->bad(2, "J block is NULL");
+  if (!df_block) return ctx->bad(3, "f block is NULL");
+  if (!dx || !dlb || !dub) return ctx->bad(4, "x/lb/ub is NULL");
+  if (!dscale_io) return ctx->bad(7, "scale is NULL");
+  if (scale_mode < 0 || scale_mode > 2) return ctx->bad(8, "scale_mode");
+  if (p->nranks > 1 && (!ctx->comm || ctx->comm_ranks != p->nranks))
+    return ctx->bad(1, "the plan's ranks need a communicator of that size on this ctx (blsq_comm_init)");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = trf_put_bounds(p, dx, dlb, dub, dscale_io, hipMemcpyDeviceToDevice);
+  if (rc) return rc;
+  if ((rc = p->tree.run(ctx, dJ_block, df_block, p->n, nullptr, /*collective=*/true))) return rc;
+  const bool global_gram = p->tree.gram && p->tree.path_valid && !p->tree.any_qr;
+  if (global_gram || p->nranks == 1) {               // the triangle is already the global one
+    if ((rc = trf_after_triangle(p, p->tree.Rfinal(), scale_mode))) return rc;
+    if (scale_mode != BLSQ_SCALE_GIVEN)
+      HIPCHK(ctx, hipMemcpyAsync(dscale_io, p->st.scale, sizeof(double) * p->n,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+  }
+  const size_t tri = (size_t)p->ld * p->ld;
+  RCCLCHK(ctx, g_rccl.AllGather(p->tree.Rfinal(), p->Rstack.as<double>(), tri, ncclDouble, ctx->comm,
+                                ctx->stream));
+  return tsqr_merge_and_finish(p, p->Rstack.as<double>(), scale_mode, dscale_io);
 }
 
 // =============================================================== dogbox ====

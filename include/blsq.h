@@ -148,15 +148,45 @@ int blsq_dogbox_fetch_step(blsq_dogbox_plan* plan, double* step, double* x_new,
                            double* predicted_reduction, double* step_scaled_norm,
                            uint8_t* fallback, int32_t* status);
 
-/* ----------------------------------------------------------------- TSQR --
- * Row-block partition of ONE very tall problem across ranks.
- * Each rank factors its own row block of [J f] to an (n+1) x (n+1) triangle;
- * the host exchanges the triangles (RCCL all-gather); every rank then merges
- * the stack and continues with the ordinary n-space path.  `tri` buffers are
- * dense row-major blsq_tsqr_tri_ld(n)^2 doubles.
+/* ------------------------------------------------------ tall problem / comm --
+ * Row-block partition of ONE very tall problem across the GPUs of a node, one process (rank) per
+ * GPU (the reference has no counterpart — it would call svd on the whole matrix,
+ * trf.py:272).  The collective is the library's own: RCCL over xGMI, bound at run time (dlopen),
+ * enqueued on the ctx stream between the local and the replicated kernels.
+ *
+ *   blsq_comm_get_id   rank 0 makes the rendezvous id (ncclUniqueId, blsq_comm_id_bytes() bytes);
+ *                      the HOST distributes it to the other ranks (any channel: a TCP socket,
+ *                      MPI, a file, torch.distributed — bounded_lsq._multi has a socket helper)
+ *   blsq_comm_init     every rank, collectively: communicator of `nranks` ranks on the ctx device
+ *   blsq_tsqr_plan_create / blsq_tsqr_factor_dev / blsq_trf_step_dev / blsq_trf_fetch_step
+ *
+ * blsq_tsqr_factor_dev takes THIS rank's row block [J_r f_r] and leaves the same factor state on
+ * every rank (so every rank computes the same step, redundantly):
+ *   - normal-equations front end: local Gram, ONE ncclAllReduce(sum) of the (n+1)^2 Gram (n = 128:
+ *     166 KB: "all-reduce of R" in north_star's words), replicated Cholesky + conditioning gate;
+ *   - a problem the gate rejects: local Householder TSQR, ONE ncclAllGather of the (n+1)^2
+ *     triangles, every rank merges the stack.
+ * m_total (all ranks' rows) enters the reference's rank test eps * m * s[0] (trust_region.py:109).
+ * blsq_tsqr_local_dev / blsq_tsqr_combine_dev expose the two halves of the Householder route for
+ * hosts that exchange the triangles themselves (`tri` buffers: dense row-major
+ * blsq_tsqr_tri_ld(n)^2 doubles, stack in rank order).
+ * Return codes of failed RCCL calls: 10000 + ncclResult_t.
  */
+int blsq_comm_id_bytes(void);
+int blsq_comm_get_id(blsq_ctx* ctx, void* id_out, size_t bytes);
+int blsq_comm_init(blsq_ctx* ctx, int nranks, int rank, const void* id, size_t bytes);
+int blsq_comm_destroy(blsq_ctx* ctx);
+int blsq_comm_size(const blsq_ctx* ctx);
+int blsq_comm_rank(const blsq_ctx* ctx);
+/* max over the ranks of n <= 64 host doubles, in place; doubles as a barrier (bench timing) */
+int blsq_comm_allreduce_max(blsq_ctx* ctx, double* host_io, int n);
+
 int blsq_tsqr_tri_ld(int n);
-int blsq_tsqr_plan_create(blsq_ctx* ctx, int m_local, int n, int nranks, blsq_trf_plan** out);
+int blsq_tsqr_plan_create(blsq_ctx* ctx, int m_local, long long m_total, int n, int nranks,
+                          blsq_trf_plan** out);
+int blsq_tsqr_factor_dev(blsq_trf_plan* plan, const double* dJ_block, const double* df_block,
+                         const double* dx, const double* dlb, const double* dub,
+                         double* dscale_io, int scale_mode);
 int blsq_tsqr_local_dev(blsq_trf_plan* plan, const double* dJ_block, const double* df_block,
                         double* dtri_out);
 int blsq_tsqr_combine_dev(blsq_trf_plan* plan, const double* dtri_stack /*nranks tris*/,

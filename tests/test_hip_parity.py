@@ -227,12 +227,13 @@ def test_invalid_arguments_are_reported(bl):
         bl.TrfStepSolver(1, 5000, 600)         # tall needs n + 1 <= 544
 
 
-@pytest.mark.parametrize("m,n,nranks", [(6000, 40, 4), (3000, 128, 3), (20000, 16, 8)])
+@pytest.mark.parametrize("m,n,nranks", [(6000, 40, 4), (3000, 128, 3), (20000, 16, 8),
+                                        (6001, 40, 4), (1003, 24, 3)])      # unequal row blocks
 def test_tsqr_row_blocks_single_gpu(bl, m, n, nranks):
-    """Row-block TSQR rehearsed on ONE GPU: every 'rank' factors
-    its row block, the triangles are stacked in rank order (what the RCCL
-    all-gather produces) and merged; the step must match the oracle on the
-    full problem."""
+    """Row-block TSQR, Householder route, rehearsed on ONE GPU: every 'rank'
+    factors its row block, the triangles are stacked in rank order (what the all-gather inside
+    blsq_tsqr_factor_dev produces) and merged; the step must match the oracle on the full
+    problem.  Every plan gets the GLOBAL row count (it enters the reference's rank test)."""
     from oracle import blsq_oracle as orc
     from bounded_lsq import _synth, _abi
     from bounded_lsq._multi import TsqrTrfSolver, row_block, tri_ld
@@ -244,7 +245,7 @@ def test_tsqr_row_blocks_single_gpu(bl, m, n, nranks):
     sols = []
     for r in range(nranks):
         lo, hi = row_block(m, nranks, r)
-        sol = TsqrTrfSolver(hi - lo, n, nranks, r, ctx=ctx)
+        sol = TsqrTrfSolver(hi - lo, n, nranks, r, ctx=ctx, m_total=m)
         dJ = ctx.to_device(P["J"][lo:hi]); df = ctx.to_device(P["f"][lo:hi])
         sol.local_triangle_dev(dJ, df, _abi.vp(dstack.value + 8 * r * ld * ld))
         ctx.sync()
@@ -260,6 +261,40 @@ def test_tsqr_row_blocks_single_gpu(bl, m, n, nranks):
         assert int(S.n_iter[0]) == So.n_iter
     for sol in sols:
         sol.close()
+    for d in list(dvec.values()) + [dstack]:
+        ctx.free(d)
+
+
+@pytest.mark.parametrize("m,n", [(6000, 40), (3000, 128), (20000, 16), (5000, 256)])
+def test_tall_problem_factor_through_the_librarys_own_collective(bl, m, n, fact_path):
+    """blsq_tsqr_factor_dev on a real RCCL communicator (one rank: all a one-GPU box allows — RCCL
+    refuses two ranks on one device): rendezvous id, ncclCommInitRank, the Gram all-reduce (or, with
+    the front end off / the gate failing, the triangle all-gather) enqueued on the library's stream,
+    replicated factorisation; the step must match the oracle."""
+    from oracle import blsq_oracle as orc
+    from bounded_lsq import _synth, _abi
+    from bounded_lsq._multi import TsqrTrfSolver, exchange_id_tcp
+    P = _synth.trf_problem(777 + n, m, n)
+    ctx = _abi.Context(0)
+    comm_id = exchange_id_tcp(0, 1, "127.0.0.1", 0, ctx.comm_new_id)
+    assert len(comm_id) == ctx.lib.blsq_comm_id_bytes() == 128
+    sol = TsqrTrfSolver(m, n, 1, 0, ctx=ctx, m_total=m, comm_id=comm_id)
+    assert ctx.lib.blsq_comm_size(ctx.h) == 1 and ctx.lib.blsq_comm_rank(ctx.h) == 0
+    d = {k: ctx.to_device(P[k]) for k in ("J", "f", "x", "lb", "ub", "scale")}
+    ctx.gram_stats(reset=True)
+    sol.factor_dev(d["J"], d["f"], d["x"], d["lb"], d["ub"], d["scale"])
+    stats = ctx.gram_stats()
+    assert stats == ((1, 0) if fact_path == "gram_front_end" else (0, 0))
+    for Delta in (0.7, 10.0):
+        _, So = orc.trf_step_solve(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"], Delta, 0.0)
+        S = sol.step(np.array([Delta]), np.array([0.0]))
+        assert rel(S.step[0], So.step) < RTOL
+        np.testing.assert_array_equal(S.hits[0], So.hits)
+        assert int(S.n_iter[0]) == So.n_iter
+    assert np.allclose(ctx.comm_max([1.5, -2.0]), [1.5, -2.0])       # (single rank: identity)
+    sol.close()
+    ctx.comm_destroy()
+    ctx.close()
 
 
 def test_mixed_rank_batch_takes_both_paths(bl):
@@ -509,3 +544,58 @@ def test_randomised_shapes_against_oracle(bl):
             np.testing.assert_array_equal(D.on_bound_new[b], So.on_bound_new)
         dog.close()
     assert worst < RTOL
+
+
+# ---- BASELINE configs 3 / 4 at their batch sizes: B = 1024, 512 x 64 -------------------------
+@pytest.mark.parametrize("kind", ["dogbox", "trf"])
+def test_batch_of_1024_problems_512x64(bl, kind):
+    """Config 3 (dogbox) / the per-GPU share of config 4 (TRF): 1024 problems of 512 x 64 in one
+    call.  16 sampled problems against the oracle (1e-10 / bit-exact masks); all 1024 through
+    size-independent properties: feasibility, model decrease, the trust-region bound, and — the
+    batch being 64 copies of the same 16 problems — bit-identical results for every copy (a
+    problem's arithmetic does not depend on its position in the launch)."""
+    from oracle import blsq_oracle as orc
+    from bounded_lsq import _synth
+    B, m, n, K = 1024, 512, 64, 16
+    gen = _synth.dogbox_batch if kind == "dogbox" else _synth.trf_batch
+    P0 = gen(31000, K, m, n)
+    P = {k: np.tile(v, (B // K,) + (1,) * (v.ndim - 1)) for k, v in P0.items()}
+    if kind == "trf":
+        Delta = np.tile(np.where(np.arange(K) % 2 == 0, 10.0, 0.5), B // K)
+        sol = bl.TrfStepSolver(B, m, n)
+        sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+        S = sol.step(Delta, np.zeros(B))
+        mask = S.hits
+    else:
+        Delta = np.tile(np.where(np.arange(K) % 2 == 0, 0.02, 0.005), B // K)
+        sol = bl.DogboxStepSolver(B, m, n)
+        sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"], P["on_bound"])
+        S = sol.step(Delta)
+        mask = S.on_bound_new
+    sol.close()
+    for b in range(K):                                   # the oracle on the 16 distinct problems
+        if kind == "trf":
+            _, So = orc.trf_step_solve(P0["J"][b], P0["f"][b], P0["x"][b], P0["lb"][b], P0["ub"][b],
+                                       P0["scale"][b], Delta[b], 0.0)
+            np.testing.assert_array_equal(S.hits[b], So.hits)
+            assert int(S.n_iter[b]) == So.n_iter and int(S.branch[b]) == So.branch
+        else:
+            _, So = orc.dogbox_step_solve(P0["J"][b], P0["f"][b], P0["x"][b], P0["lb"][b],
+                                          P0["ub"][b], P0["scale"][b], P0["on_bound"][b], Delta[b])
+            np.testing.assert_array_equal(S.on_bound_new[b], So.on_bound_new)
+            assert int(S.tr_hit[b]) == int(So.tr_hit)
+        assert rel(S.step[b], So.step) < RTOL, (b, rel(S.step[b], So.step))
+        assert abs(S.predicted_reduction[b] - So.predicted_reduction) <= 1e-10 * abs(So.predicted_reduction)
+    # every copy of a problem: the same bits
+    for arr in (S.step, S.x_new, mask, S.predicted_reduction):
+        a = np.asarray(arr).reshape((B // K, K) + np.asarray(arr).shape[1:])
+        assert np.array_equal(a, np.broadcast_to(a[0], a.shape))
+    # properties over the whole batch
+    assert np.all(S.status == 0)
+    assert np.all(S.predicted_reduction > 0)
+    if kind == "trf":
+        assert np.all(S.x_new > P["lb"]) and np.all(S.x_new < P["ub"])      # strictly feasible
+        assert np.all(S.step_h_norm <= Delta * (1 + 1e-12))
+    else:
+        assert np.all(S.x_new >= P["lb"]) and np.all(S.x_new <= P["ub"])
+        assert np.all(np.abs(S.step) <= Delta[:, None] * P["scale"] * (1 + 1e-15))

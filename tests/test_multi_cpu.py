@@ -1,7 +1,12 @@
-"""N > 1 host logic on CPU: sharding arithmetic and the triangle exchange over
-torch.distributed (gloo, world_size 2).  The triangles here come from the
-oracle-side QR (numpy) — the point is the plumbing: rank order of the
-all-gather and that merging the gathered stack reproduces the full problem."""
+"""N > 1 host logic on CPU (no GPU, no RCCL):
+  * sharding arithmetic;
+  * the communicator-id hand-off over TCP between two real processes (the only thing the product's
+    host side moves between ranks);
+  * the two exchange patterns of the tall-problem path rehearsed with torch.distributed / gloo,
+    world_size 2 — the collectives are RCCL's on the GPU path (blsq_tsqr_factor_dev); what is checked
+    here is what they must deliver: rank order of the all-gather, and that merging the gathered
+    triangles / factoring the all-reduced Gram reproduces the whole problem.  (torch is used by
+    THIS TEST only; bounded_lsq._multi does not import it.)"""
 import os
 import subprocess
 import sys
@@ -21,7 +26,51 @@ def test_shard_and_row_block_arithmetic():
         assert max(hi - lo for lo, hi in spans) == -(-total // world)
     blocks = [row_block(2_000_000, 8, r) for r in range(8)]
     assert blocks[0] == (0, 250_000) and blocks[-1] == (1_750_000, 2_000_000)
+    blocks = [row_block(1003, 4, r) for r in range(4)]            # unequal blocks cover every row once
+    assert blocks[0][0] == 0 and blocks[-1][1] == 1003
+    assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
     assert tri_ld(128) == 144 and tri_ld(256) == 272 and tri_ld(15) == 16
+
+
+def test_product_multi_module_does_not_import_torch():
+    src = open(os.path.join(ROOT, "bounded-lsq_amd", "bounded_lsq", "_multi.py")).read()
+    assert "import torch" not in src
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+ID_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%(root)r, "bounded-lsq_amd"))
+from bounded_lsq._multi import exchange_id_tcp
+rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+calls = []
+def make_id():
+    calls.append(1)
+    return bytes(range(128))
+got = exchange_id_tcp(rank, world, "127.0.0.1", port, make_id)
+assert got == bytes(range(128)), got
+assert len(calls) == (1 if rank == 0 else 0)          # only rank 0 makes the id
+open(os.path.join(%(out)r, "id%%d.ok" %% rank), "w").write("ok")
+'''
+
+
+def test_communicator_id_handoff_tcp_world3(tmp_path):
+    script = tmp_path / "idw.py"
+    script.write_text(ID_WORKER % {"root": ROOT, "out": str(tmp_path)})
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "3", str(port)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in (1, 2, 0)]                                  # clients first: they must retry
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0, out[-2000:]
+    assert all((tmp_path / ("id%d.ok" % r)).exists() for r in range(3))
 
 
 WORKER = r'''
@@ -30,27 +79,35 @@ import numpy as np
 sys.path.insert(0, os.path.join(%(root)r, "bounded-lsq_amd"))
 sys.path.insert(0, %(root)r)
 import torch, torch.distributed as dist
-from bounded_lsq._multi import allgather_triangles, row_block, tri_ld
+from bounded_lsq._multi import row_block, tri_ld
 from bounded_lsq import _synth
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-m, n = 600, 12
+m, n = 601, 12                                         # m %% world != 0: unequal row blocks
 P = _synth.trf_problem(99, m, n)
 lo, hi = row_block(m, world, rank)
 A = np.column_stack([P["J"][lo:hi], P["f"][lo:hi]])
-R = np.linalg.qr(A, mode="r")                      # (n+1) x (n+1) triangle of the row block
 ld = tri_ld(n)
+Rf = np.linalg.qr(np.column_stack([P["J"], P["f"]]), mode="r")
+# --- route 1 (gate passed): all-reduce (sum) of the local Grams, replicated Cholesky ---
+G = torch.zeros((ld, ld), dtype=torch.float64)
+G[:n + 1, :n + 1] = torch.from_numpy(A.T @ A)
+dist.all_reduce(G, op=dist.ReduceOp.SUM)
+Gn = G.numpy()[:n + 1, :n + 1]
+Af = np.column_stack([P["J"], P["f"]])
+assert np.allclose(Gn, Af.T @ Af, rtol=1e-13, atol=1e-12)
+Rc = np.linalg.cholesky(Gn).T
+assert np.allclose(np.abs(Rc), np.abs(Rf), rtol=1e-10, atol=1e-11)
+assert np.allclose(Gn[:n, n], P["J"].T @ P["f"], rtol=1e-12, atol=1e-12)      # g = J^T f
+# --- route 2 (gate rejected): all-gather of the local triangles, replicated merge ---
+R = np.linalg.qr(A, mode="r")                      # (n+1) x (n+1) triangle of the row block
 tri = torch.zeros((ld, ld), dtype=torch.float64)
 tri[:n + 1, :n + 1] = torch.from_numpy(R)
-stack = allgather_triangles(tri, world)
-assert stack.shape == (world, ld, ld)
-# rank order: slot r must hold rank r's triangle
-mine = stack[rank].numpy()
-assert np.array_equal(mine, tri.numpy())
-# merging the gathered stack == QR of the whole problem (up to row signs)
+stack = torch.empty((world, ld, ld), dtype=torch.float64)
+dist.all_gather_into_tensor(stack.view(-1), tri.view(-1))
+assert np.array_equal(stack[rank].numpy(), tri.numpy())      # rank order: slot r = rank r
 S = np.vstack([stack[r].numpy()[:n + 1, :n + 1] for r in range(world)])
 Rm = np.linalg.qr(S, mode="r")
-Rf = np.linalg.qr(np.column_stack([P["J"], P["f"]]), mode="r")
 assert np.allclose(np.abs(Rm), np.abs(Rf), rtol=1e-11, atol=1e-12)
 g = Rm[:n, :n].T @ Rm[:n, n]
 assert np.allclose(g, P["J"].T @ P["f"], rtol=1e-11, atol=1e-11)
@@ -60,13 +117,10 @@ open(os.path.join(%(out)r, "rank%%d.ok" %% rank), "w").write("ok")
 '''
 
 
-def test_triangle_allgather_gloo_world2(tmp_path):
+def test_tall_problem_exchange_patterns_gloo_world2(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT, "out": str(tmp_path)})
-    import socket
-    with socket.socket() as sk:                    # a free rendezvous port
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    port = _free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]

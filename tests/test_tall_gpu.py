@@ -1,0 +1,88 @@
+"""BASELINE config 5 at its per-rank size: one tall problem, 250 000 x 128 rows per rank
+(2 000 000 x 128 over 8 GPUs).  A one-GPU box cannot host two RCCL ranks, so the two
+row blocks are factored one after the other on the same device and exchanged by the test (the
+Householder route: blsq_tsqr_local_dev / blsq_tsqr_combine_dev), and the Gram route runs as ONE
+rank on the stacked 500 000 rows through blsq_tsqr_factor_dev; both must match the reference's
+own path (oracle: scipy gesdd on the whole 500 128 x 128 augmented matrix)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b)
+
+
+@pytest.fixture(scope="module")
+def tall():
+    from oracle import blsq_oracle as orc
+    rng = np.random.default_rng(2_000_000)
+    m, n = 500_000, 128
+    J = rng.standard_normal((m, n))
+    f = rng.standard_normal(m)
+    x = rng.uniform(-1.0, 1.0, n)
+    lb = x - rng.uniform(1e-3, 0.05, n)
+    ub = x + rng.uniform(1e-3, 0.05, n)
+    P = dict(J=J, f=f, x=x, lb=lb, ub=ub, scale=np.ones(n))
+    F = orc.trf_factor(J, f, x, lb, ub, P["scale"])           # ~10-20 s of LAPACK on the host
+    ref = {D: orc.trf_step(F, D, 0.0) for D in (0.5, 10.0)}
+    return P, ref
+
+
+def test_config5_row_blocks_of_250000_rows(tall):
+    import bounded_lsq as bl
+    from bounded_lsq import _abi
+    from bounded_lsq._multi import TsqrTrfSolver, row_block, tri_ld
+    P, ref = tall
+    m, n = P["J"].shape
+    nranks = 2
+    ctx = _abi.Context(0)
+    ld = tri_ld(n)
+    dstack = ctx.malloc(8 * nranks * ld * ld)
+    dvec = {k: ctx.to_device(P[k]) for k in ("x", "lb", "ub", "scale")}
+    sols = []
+    for r in range(nranks):
+        lo, hi = row_block(m, nranks, r)
+        assert hi - lo == 250_000
+        sol = TsqrTrfSolver(hi - lo, n, nranks, r, ctx=ctx, m_total=m)
+        dJ = ctx.to_device(P["J"][lo:hi]); df = ctx.to_device(P["f"][lo:hi])
+        sol.local_triangle_dev(dJ, df, _abi.vp(dstack.value + 8 * r * ld * ld))
+        ctx.sync()
+        ctx.free(dJ); ctx.free(df)
+        sols.append(sol)
+    for sol in sols:                              # every rank reaches the same step
+        sol.combine_dev(dstack, dvec["x"], dvec["lb"], dvec["ub"], dvec["scale"])
+        for Delta, So in ref.items():
+            S = sol.step(np.array([Delta]), np.array([0.0]))
+            assert rel(S.step[0], So.step) < RTOL, (Delta, rel(S.step[0], So.step))
+            np.testing.assert_array_equal(S.hits[0], So.hits)
+            assert int(S.n_iter[0]) == So.n_iter and int(S.branch[0]) == So.branch
+        sol.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("gram", ["1", "0"])
+def test_config5_single_rank_collective_route(tall, gram, monkeypatch):
+    """The same 500 000 rows as ONE rank through blsq_tsqr_factor_dev (real communicator): Gram
+    all-reduce route with the front end on, triangle all-gather route with it off."""
+    monkeypatch.setenv("BLSQ_GRAM", gram)
+    from bounded_lsq import _abi
+    from bounded_lsq._multi import TsqrTrfSolver
+    P, ref = tall
+    m, n = P["J"].shape
+    ctx = _abi.Context(0)
+    sol = TsqrTrfSolver(m, n, 1, 0, ctx=ctx, m_total=m, comm_id=ctx.comm_new_id())
+    d = {k: ctx.to_device(P[k]) for k in ("J", "f", "x", "lb", "ub", "scale")}
+    ctx.gram_stats(reset=True)
+    sol.factor_dev(d["J"], d["f"], d["x"], d["lb"], d["ub"], d["scale"])
+    assert ctx.gram_stats() == ((1, 0) if gram == "1" else (0, 0))
+    for Delta, So in ref.items():
+        S = sol.step(np.array([Delta]), np.array([0.0]))
+        assert rel(S.step[0], So.step) < RTOL, (Delta, rel(S.step[0], So.step))
+        np.testing.assert_array_equal(S.hits[0], So.hits)
+        assert int(S.n_iter[0]) == So.n_iter
+    sol.close()
+    ctx.comm_destroy()
+    ctx.close()
