@@ -1,28 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py — TRF step-solves/second on batched dense Jacobians (MI355X).
+"""bench.py — trust-region step-solves/second on batched dense Jacobians (MI355X).
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N > 1 is launched by torch.distributed.run, one rank per GPU; the batch is
-  sharded by problem (independent problems, NO data-path collective, weak
-  scaling: per-GPU batch fixed).  torch is used only for the barrier and the
-  max-over-ranks of the elapsed time; the compute path is libblsq_hip.so
-  through ctypes.
+  N > 1 is launched by torch.distributed.run, one rank per GPU.  Batches are sharded by problem
+  (independent problems, NO data-path collective, weak scaling: per-GPU batch fixed); the tall
+  problem of config 5 is split by rows and uses the library's own RCCL collective.  torch is
+  used only for the barrier and the max-over-ranks of the elapsed time; the compute path is
+  libblsq_hip.so through ctypes.
 
-One "step" = one TRF step-solve (trf.py:244-308 = factor + one
+One "step" = one step-solve (trf.py:244-308 resp. dogbox.py:170-220 = factor + one
 inner step) for every problem of the per-GPU batch, inputs resident in HBM.
-Workload at N = 1: BASELINE.json configs[1] shape (m=4096, n=256, TRF exact
-step) batched, which is the configuration the metric / north_star target is
-quoted on ("batched 4096x256 dense Jacobians at 1 GPU").
 
-Prints ONE JSON line (rank 0) with `roofline` and `cpu_baseline` objects.  `factorisation_paths`
-counts how many problems the normal-equations front end factored and how many its conditioning
-gate handed to the Householder tree; `householder_only` (N = 1) is the same workload re-timed with
-the front end switched off — a side figure, never `value`.
+--config selects the BASELINE.json workload (default c2, the one the metric is quoted on):
+    c2         TRF, 4096 x 256, 512 problems per GPU ("batched 4096x256 dense Jacobians at 1 GPU")
+    c2-single  TRF, 4096 x 256, one problem          (configs[1] as written)
+    c3         dogbox, 512 x 64, 1024 problems per GPU (configs[2])
+    c4         TRF, 512 x 64, 1024 problems per GPU  (configs[3]: 8192 over 8 GPUs)
+    c5         TRF, one tall problem, 250 000 x 128 rows PER RANK (configs[4]: 2 000 000 x 128 over
+               8 GPUs), blsq_tsqr_factor_dev: local Gram + ncclAllReduce over RCCL
+Every config prints the same JSON shape with its own SURVEY 8(d) bytes / flops.  The default (c2)
+line also carries, at N = 1: `side_configs` (the other configs' rates, same process, short runs),
+`householder_only` (the same workload with the normal-equations front end off), `h2d_inclusive`
+(the host-pointer API: numpy in, numpy out) and `cpu_baseline`; at N > 1 a `c5_tsqr` side figure
+(the tall problem over all ranks).  Side figures are never `value`.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -31,64 +37,79 @@ sys.path.insert(0, os.path.join(ROOT, "bounded-lsq_amd"))
 
 import numpy as np  # noqa: E402
 
-PEAK_FP64_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (nominal)
-PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+PEAK_FP64_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (nominal; AMD spec)
+PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
+
+CONFIGS = {
+    "c2": dict(kind="trf", m=4096, n=256, batch=512,
+               label="C2 batched: TRF exact step-solve, m=4096 n=256"),
+    "c2-single": dict(kind="trf", m=4096, n=256, batch=1,
+                      label="C2 single problem: TRF exact step-solve, m=4096 n=256"),
+    "c3": dict(kind="dogbox", m=512, n=64, batch=1024,
+               label="C3: dogbox dogleg step-solve, m=512 n=64"),
+    "c4": dict(kind="trf", m=512, n=64, batch=1024,
+               label="C4 (per-GPU share of 8192): TRF exact step-solve, m=512 n=64"),
+    "c5": dict(kind="tsqr", m=250_000, n=128, batch=1,
+               label="C5: one tall TRF problem split by rows, 250000 x 128 per rank"),
+}
 
 
-def alg_bytes_trf(m, n):    # single pass over inputs, outputs once
-    return 8 * (m * n + m + 4 * n) + 8 * 2 * n + 8 * n
+# ---- algorithmic work per step-solve ------------------------------------------
+def alg_bytes(kind, m, n):
+    b = 8 * (m * n + m + 4 * n) + 8 * 2 * n + 8 * n
+    return b + (8 * n if kind == "dogbox" else 0)
 
 
-def alg_flops_trf(m, n):    # R-SVD count + GEMV terms
+def alg_flops(kind, m, n):
+    if kind == "dogbox":
+        return 2 * m * n * n - 2.0 * n ** 3 / 3.0 + 10 * m * n + n * n
     return 2 * (m + n) * n * n + 11 * n ** 3 + 6 * (m + n) * n
 
 
-def leaf_flops_trf(m, n, rows_per_leaf=1024):
-    """Flops of the dominant kernel's OWN work: Householder QR of the [J f] row blocks
-    (2 r N^2 - 2/3 N^3 per r x N leaf, N = n + 1), nothing else of the step-solve."""
+def leaf_flops(m, n, rows_per_leaf=1024):
+    """Householder QR of the [J f] row blocks (2 r N^2 - 2/3 N^3 per r x N leaf, N = n + 1)."""
     N = n + 1
     nleaf = max(1, -(-m // rows_per_leaf))
     r = -(-m // nleaf)
     return nleaf * (2.0 * r * N * N - 2.0 * N ** 3 / 3.0)
 
 
-def gram_flops_trf(m, n):
-    """Flops of the normal-equations front end's Gram kernel: the symmetric product
-    [J f]^T [J f], one multiply-add per row and per entry of the upper triangle."""
+def gram_flops(m, n):
+    """The symmetric product [J f]^T [J f]: one multiply-add per row and entry of the upper triangle."""
     N = n + 1
     return float(m) * N * (N + 1)
 
 
-def gram_bytes_trf(m, n):
+def gram_bytes(m, n):
     return 8.0 * (m * (n + 1) + (n + 1) * (n + 2) / 2)
 
 
-def measured_traffic(kernel, m, n, B):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary
-    (profiles/hbm_traffic_latest.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes,
-    gfx950 correction per MI355X_MICROARCH.md) when it was collected for this exact
-    workload; None otherwise (bench.py itself cannot collect PMC counters)."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
+def measured_traffic(cfg_name, kernel, m, n, B):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary, when it was
+    collected for this exact workload (bench.py itself cannot collect PMC counters).
+    -> (bytes or None, source string or None)"""
+    fname = "hbm_traffic_latest.json" if cfg_name == "c2" else "hbm_traffic_%s.json" % cfg_name
+    path = os.path.join(ROOT, "profiles", fname)
     try:
         with open(path) as fh:
             t = json.load(fh)
         cfg = t.get("config", {})
         if (cfg.get("m"), cfg.get("n"), cfg.get("batch")) != (m, n, B):
-            return None
+            return None, None
         dom = t.get("dominant")
         if dom and dom.get("slot") == kernel:
-            return dom["hbm_bytes_per_launch"]
-        for name, v in t["kernels"].items():          # older summaries: first QR entry = leaf
-            if kernel.split("_")[0] in name:
-                return v["hbm_bytes"]
+            return dom["hbm_bytes_per_launch"], "profiles/%s (%s; separate rocprofv3 --pmc FETCH_SIZE / " \
+                "WRITE_SIZE passes of the same workload, gfx950 FETCH x2 correction)" % (fname, t.get("tag", "committed"))
     except Exception:
         pass
-    return None
+    return None, None
 
 
-def make_deltas(B):
-    """Half 'reflective' (Delta=10: Gauss-Newton step, reflection branch) and
-    half 'feasible' (Delta=0.5: More' iterations) as SURVEY.md 8(d) asks."""
+def make_deltas(kind, B):
+    """TRF: half 'reflective' (Delta=10: Gauss-Newton step, reflection branch) and half 'feasible'
+    (Delta=0.5: More' iterations) as SURVEY.md 8(d) asks; dogbox: Delta = 0.02."""
+    if kind == "dogbox":
+        return np.full(B, 0.02)
     return np.where(np.arange(B) % 2 == 0, 10.0, 0.5)
 
 
@@ -112,19 +133,45 @@ def _cpu_worker_init():
         pass
 
 
+def _host_info():
+    info = {"cpu": "", "logical_cores": os.cpu_count() or 1}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        info["affinity"] = info["logical_cores"]
+    try:
+        phys = set()
+        pid = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and not info["cpu"]:
+                info["cpu"] = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+                phys.add((pid, core))
+        info["physical_cores"] = len(phys) or info["logical_cores"]
+    except Exception:
+        info["physical_cores"] = info["logical_cores"]
+    try:                                        # cgroup v2 CPU quota of this container, if any
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        info["cgroup_cpu_quota"] = None if q == "max" else float(q) / float(per)
+    except Exception:
+        info["cgroup_cpu_quota"] = None
+    return info
+
+
 def cpu_baseline(P, Delta, budget_s=24.0):
-    """The reference's CPU path (numpy/scipy restatement, oracle/) on the host
-    cores, three threading configurations; best is reported.
-    Must run BEFORE the GPU is initialised (uses fork)."""
+    """The reference's CPU path (numpy/scipy restatement, oracle/) on the host cores, four
+    threading configurations; the best is `value`.  Runs BEFORE the GPU is
+    initialised (fork).  Process pools: the box's one-GPU share of the host (16 workers) AND the
+    host's physical cores (capped by what this process may run on)."""
     import multiprocessing as mp
     from threadpoolctl import threadpool_limits, threadpool_info
-    ncpu = os.cpu_count() or 1
-    try:
-        ncpu = min(ncpu, len(os.sched_getaffinity(0)))
-    except Exception:
-        pass
-    host_logical = ncpu
-    ncpu = min(ncpu, int(os.environ.get("BLSQ_CPU_WORKERS", "16")))  # a 1-GPU box's CPU share
+    host = _host_info()
+    share = min(host["affinity"], int(os.environ.get("BLSQ_CPU_WORKERS", "16")))
+    allc = min(host["affinity"], host["physical_cores"],
+               int(os.environ.get("BLSQ_CPU_WORKERS_ALL", "128")))
     _CPU["P"] = P
     _CPU["Delta"] = Delta
     B = P["J"].shape[0]
@@ -133,79 +180,290 @@ def cpu_baseline(P, Delta, budget_s=24.0):
     with threadpool_limits(limits=1):
         _cpu_one(0)
     t1 = time.perf_counter() - t0                 # single-thread cost of one solve
-    per_mode = budget_s / 3.0
+    per_mode = budget_s / 4.0
     res = {}
-    # (ii) one BLAS thread, sequential loop
     k = int(max(2, min(B, per_mode / max(t1, 1e-6))))
-    with threadpool_limits(limits=1):
+    with threadpool_limits(limits=1):             # (ii) one BLAS thread, sequential loop
         t0 = time.perf_counter()
         for b in range(k):
             _cpu_one(b % B)
         res["blas1_loop"] = (k / (time.perf_counter() - t0), 1, k)
-    # (i) default BLAS threads, sequential loop
-    k = int(max(2, min(B, per_mode / max(t1, 1e-6))))
-    t0 = time.perf_counter()
+    t0 = time.perf_counter()                      # (i) default BLAS threads, sequential loop
     for b in range(k):
         _cpu_one(b % B)
     nthr = max([d.get("num_threads", 1) for d in threadpool_info()] + [1])
     res["blas_default_loop"] = (k / (time.perf_counter() - t0), nthr, k)
-    # (iii) ncpu processes x 1 BLAS thread
-    if ncpu > 1:
-        k = int(max(ncpu, min(4 * B, ncpu * per_mode / max(t1, 1e-6))))
-        ctx = mp.get_context("fork")
-        with ctx.Pool(ncpu, initializer=_cpu_worker_init) as pool:
-            pool.map(_cpu_one, [b % B for b in range(ncpu)])   # warm the workers
+    ctx = mp.get_context("fork")
+    for label, nw in (("procs_x_blas1_gpu_share", share), ("procs_x_blas1_physical_cores", allc)):
+        if nw <= 1 or (label.endswith("physical_cores") and nw <= share):
+            continue
+        k = int(max(nw, min(8 * B, nw * per_mode / max(t1, 1e-6))))
+        with ctx.Pool(nw, initializer=_cpu_worker_init) as pool:
+            pool.map(_cpu_one, [b % B for b in range(nw)])       # warm the workers
             t0 = time.perf_counter()
             pool.map(_cpu_one, [b % B for b in range(k)], chunksize=1)
-            res["procs_x_blas1"] = (k / (time.perf_counter() - t0), ncpu, k)
+            res[label] = (k / (time.perf_counter() - t0), nw, k)
     best = max(res, key=lambda kk: res[kk][0])
-    cpu_model = ""
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                cpu_model = line.split(":", 1)[1].strip()
-                break
-    except Exception:
-        pass
     return {
         "value": res[best][0], "unit": "step-solves/s", "cores": res[best][1],
         "kind": "port",
         "sample": "%d TRF step-solves of the same seeded batch (mode %s; oracle/blsq_oracle.py "
                   "= scipy.linalg.svd(gesdd) path of trf.py:244-308)" % (res[best][2], best),
         "modes": {kk: {"value": v[0], "threads": v[1], "solves": v[2]} for kk, v in res.items()},
-        "host": {"cpu": cpu_model, "logical_cores": host_logical, "workers_cap": ncpu},
+        "host": host,
     }
+
+
+# ------------------------------------------------------------- one config --
+class Bench:
+    """Device-resident inputs + the step closure of one config on one ctx."""
+
+    def __init__(self, name, ctx, rank, world, batch=None, m=None, n=None, comm_ready=False):
+        from bounded_lsq import TrfStepSolver, DogboxStepSolver, _synth
+        cfg = dict(CONFIGS[name])
+        if batch:
+            cfg["batch"] = batch
+        if m:
+            cfg["m"] = m
+        if n:
+            cfg["n"] = n
+        self.name, self.cfg, self.ctx = name, cfg, ctx
+        self.rank, self.world = rank, world
+        kind, B, m, n = cfg["kind"], cfg["batch"], cfg["m"], cfg["n"]
+        self.kind, self.B, self.m, self.n = kind, B, m, n
+        self.Delta = make_deltas(kind, B)
+        if kind == "tsqr":
+            from bounded_lsq._multi import TsqrTrfSolver
+            rng = np.random.default_rng(555 + rank)            # this rank's row block
+            J = rng.standard_normal((m, n))
+            f = rng.standard_normal(m)
+            r0 = np.random.default_rng(554)                     # x / bounds: the same on every rank
+            x = r0.uniform(-1.0, 1.0, n)
+            self.P = dict(J=J[None], f=f[None], x=x[None], lb=(x - r0.uniform(1e-3, 0.05, n))[None],
+                          ub=(x + r0.uniform(1e-3, 0.05, n))[None], scale=np.ones((1, n)))
+            assert world == 1 or comm_ready, "c5 at N > 1 needs ctx.comm_init first"
+            self.sol = TsqrTrfSolver(m, n, world, rank, ctx=ctx, m_total=m * world)
+            self.Delta = np.array([0.5])
+        elif kind == "dogbox":
+            self.P = _synth.dogbox_batch(20_000 + rank * B, B, m, n)
+            self.sol = DogboxStepSolver(B, m, n, ctx=ctx)
+        else:
+            self.P = _synth.trf_batch(10_000 + rank * B, B, m, n)   # each rank its own problems
+            self.sol = TrfStepSolver(B, m, n, ctx=ctx)
+        keys = ("J", "f", "x", "lb", "ub", "scale") + (("on_bound",) if kind == "dogbox" else ())
+        self.d = {k: ctx.to_device(self.P[k]) for k in keys}
+        self.dDelta = ctx.to_device(self.Delta)
+        self.dAlpha = ctx.to_device(np.zeros(B))
+
+    def step(self):
+        d, s = self.d, self.sol
+        if self.kind == "dogbox":
+            s.factor_dev(d["J"], d["f"], d["x"], d["lb"], d["ub"], d["scale"], d["on_bound"])
+            s.step_dev(self.dDelta)
+        else:
+            s.factor_dev(d["J"], d["f"], d["x"], d["lb"], d["ub"], d["scale"])
+            s.step_dev(self.dDelta, self.dAlpha)
+
+    def step_host(self):
+        """The host-pointer API: numpy in, numpy out (H2D of J inside the call)."""
+        P, s = self.P, self.sol
+        if self.kind == "dogbox":
+            s.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"], P["on_bound"])
+            return s.step(self.Delta)
+        s.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+        return s.step(self.Delta, np.zeros(self.B))
+
+    def close(self):
+        self.sol.close()
+        for p in list(self.d.values()) + [self.dDelta, self.dAlpha]:
+            self.ctx.free(p)
+
+    # ---- parity spot check against the oracle (rank 0) ----
+    def parity(self, nprob):
+        from oracle import blsq_oracle as orc
+        P, B = self.P, self.B
+        S = self.sol.fetch_step()
+        worst, masks_ok = 0.0, True
+        if self.kind == "tsqr" and self.world > 1:
+            return {"problems": 0, "note": "row blocks of other ranks are not on this host: "
+                                           "parity of the split problem is covered by tests/"}
+        for b in range(min(nprob, B)):
+            if self.kind == "dogbox":
+                _, So = orc.dogbox_step_solve(P["J"][b], P["f"][b], P["x"][b], P["lb"][b], P["ub"][b],
+                                              P["scale"][b], P["on_bound"][b], float(self.Delta[b]))
+                masks_ok = masks_ok and bool(np.array_equal(S.on_bound_new[b], So.on_bound_new))
+            else:
+                _, So = orc.trf_step_solve(P["J"][b], P["f"][b], P["x"][b], P["lb"][b], P["ub"][b],
+                                           P["scale"][b], float(self.Delta[b]), 0.0)
+                masks_ok = masks_ok and bool(np.array_equal(S.hits[b], So.hits))
+            worst = max(worst, float(np.linalg.norm(S.step[b] - So.step) / np.linalg.norm(So.step)))
+        out = {"problems": min(nprob, B), "max_rel_step_err": worst, "masks_bit_exact": masks_ok}
+        if self.kind != "dogbox":
+            out["svd_free_fraction"] = float(self.sol.debug_fast().mean())
+        return out
+
+
+def time_steps(bench, steps, warmup, fence):
+    ctx = bench.ctx
+    for _ in range(warmup):
+        bench.step()
+    fence()
+    ctx.timing(True)
+    ctx.timing_reset()
+    ctx.gram_stats(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        bench.step()
+    ctx.sync()
+    elapsed = time.perf_counter() - t0
+    fence()
+    ctx.timing(False)
+    return elapsed
+
+
+def record(bench, cfg_name, elapsed, steps, warmup, world, probe):
+    """The JSON record of one timed config (rank 0)."""
+    ctx = bench.ctx
+    kind, B, m, n = bench.kind, bench.B, bench.m, bench.n
+    akind = "dogbox" if kind == "dogbox" else "trf"
+    timing = ctx.timing_read()
+    units = (1 if kind == "tsqr" else B * world) * steps         # step-solves in the timed region
+    value = units / elapsed
+    ms_per_step = 1e3 * elapsed / steps
+    kern = {k: {"ms_total": v[0], "launches": v[1], "avg_ms": (v[0] / v[1] if v[1] else 0.0)}
+            for k, v in timing.items()}
+    per_step_ms = {k: v["ms_total"] / steps for k, v in kern.items()}
+    dom = max(per_step_ms, key=lambda k: per_step_ms[k])
+    dom_launches_per_step = max(1, kern[dom]["launches"] // max(1, steps))
+    dom_ms = kern[dom]["avg_ms"] * dom_launches_per_step          # dominant kernel, per step
+    # The dominant launch is priced with the work of ITS OWN algorithm (DESIGN.md 5): the Gram
+    # kernel m N (N + 1) flops over 8 m N bytes, the Householder leaf 2 r N^2 - 2/3 N^3.  SURVEY
+    # 8(d)'s per-solve figure (an SVD-based count of the whole step-solve) is larger than what
+    # either kernel executes and is reported beside it, never as `achieved`.
+    if dom == "gram":
+        own_f, own_b = gram_flops(m, n), gram_bytes(m, n)
+    elif dom == "qr_leaf":
+        own_f, own_b = leaf_flops(m, n), 8.0 * m * (n + 1)
+    else:
+        own_f, own_b = float(alg_flops(akind, m, n)), float(alg_bytes(akind, m, n))
+    balance = PEAK_FP64_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+    bound = "mfma" if own_f / own_b > balance else "hbm"
+    ach_tf = own_f * B / (dom_ms * 1e-3) / 1e12
+    ach_gbs = own_b * B / (dom_ms * 1e-3) / 1e9
+    traffic, tsrc = measured_traffic(cfg_name, dom, m, n, B)
+    roof = {
+        "bound": bound,
+        "achieved": ach_tf if bound == "mfma" else ach_gbs,
+        "peak": PEAK_FP64_TFLOPS if bound == "mfma" else PEAK_HBM_GBS,
+        "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+        "frac": (ach_tf / PEAK_FP64_TFLOPS) if bound == "mfma" else (ach_gbs / PEAK_HBM_GBS),
+        "traffic": traffic, "traffic_source": tsrc,
+        "peak_source": "nominal (AMD spec: FP64 matrix = vector 78.6 TFLOP/s; HBM3E 8 TB/s)",
+        "kernel": dom, "kernel_ms_per_step": per_step_ms[dom],
+        "kernel_flops_per_solve": own_f, "kernel_bytes_per_solve": own_b,
+        "kernel_tflops": ach_tf, "kernel_hbm_gbs": ach_gbs,
+        "survey_flops_per_solve": alg_flops(akind, m, n),
+        "survey_bytes_per_solve": alg_bytes(akind, m, n),
+        "whole_step_hbm_gbs": alg_bytes(akind, m, n) * B / (ms_per_step * 1e-3) / 1e9,
+        "whole_step_hbm_frac_of_8TBs": alg_bytes(akind, m, n) * B / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
+    }
+    if probe:
+        roof["peak_measured"] = probe
+        if bound == "mfma" and probe.get("mfma_f64_tflops"):
+            roof["frac_of_measured_peak"] = ach_tf / probe["mfma_f64_tflops"]
+        if bound == "hbm" and probe.get("hbm_copy_gbs"):
+            roof["frac_of_measured_peak"] = ach_gbs / probe["hbm_copy_gbs"]
+    gs = ctx.gram_stats()
+    metric = ("dogbox" if kind == "dogbox" else "TRF") + " step-solves/sec (batched m x n dense Jacobian)"
+    return {
+        "metric": metric, "value": value, "unit": "step-solves/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s, %d problem%s per GPU, %s, inputs resident in HBM" % (
+                       CONFIGS[cfg_name]["label"] if (m, n) == (CONFIGS[cfg_name]["m"], CONFIGS[cfg_name]["n"])
+                       else "%s step-solve, m=%d n=%d" % (akind, m, n), B, "" if B == 1 else "s",
+                       "Delta = 0.02" if kind == "dogbox" else "Delta mix 10/0.5 (reflective/feasible)"),
+                   "name": cfg_name, "m": m, "n": n, "batch_per_gpu": B,
+                   "sharding": ("by rows: %d rows per rank, one ncclAllReduce of the Gram per factor call"
+                                % m) if kind == "tsqr" else "by problem, no collective"},
+        "roofline": roof,
+        "factorisation_paths": {"normal_equations": gs[0], "householder_tree": gs[1]},
+        "kernels_ms_per_step": per_step_ms,
+    }
+
+
+def side_run(name, ctx, steps, warmup, probe, **kw):
+    """A short run of another config on the same ctx -> compact record (never `value`)."""
+    b = Bench(name, ctx, 0, 1, **kw)
+    try:
+        el = time_steps(b, steps, warmup, ctx.sync)
+        r = record(b, name, el, steps, warmup, 1, probe)
+        par = b.parity(2)
+    finally:
+        b.close()
+    rf = r["roofline"]
+    return {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"],
+            "ms_per_step": r["ms_per_step"], "steps": steps,
+            "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel",
+                                            "kernel_ms_per_step", "whole_step_hbm_frac_of_8TBs")},
+            "mfma_ceiling_frac_survey": r["value"] * rf["survey_flops_per_solve"] / (PEAK_FP64_TFLOPS * 1e12),
+            "kernels_ms_per_step": {k: round(v, 4) for k, v in r["kernels_ms_per_step"].items() if v > 0},
+            "parity": par}
+
+
+def with_timeout(fn, seconds, what):
+    """Run fn() in a thread; a side figure that hangs must not take the bench line with it."""
+    box = {}
+
+    def run():
+        try:
+            box["out"] = fn()
+        except Exception as exc:                              # noqa: BLE001
+            box["out"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        return {"error": "%s did not finish within %d s" % (what, seconds)}, True
+    return box["out"], False
 
 
 # --------------------------------------------------------------------- main --
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=512,
-                    help="problems per GPU (512: two waves of 256 CUs; the n-space kernels run one workgroup per problem)")
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: enough for a timed region of about a second)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=None, help="problems per GPU (default: the config's)")
+    ap.add_argument("--m", type=int, default=None)
+    ap.add_argument("--n", type=int, default=None)
     ap.add_argument("--no-householder", action="store_true",
                     help="skip the side run with the normal-equations front end switched off")
-    ap.add_argument("--m", type=int, default=4096)
-    ap.add_argument("--n", type=int, default=256)
+    ap.add_argument("--no-side", action="store_true", help="skip the other configs' side figures")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the host-pointer (PCIe-inclusive) leg")
+    ap.add_argument("--no-probe", action="store_true", help="skip the measured-peak probes")
     ap.add_argument("--check", type=int, default=2, help="problems checked against the oracle")
     args = ap.parse_args()
+    name = args.config
+    default_steps = {"c2": 250, "c2-single": 500, "c3": 400, "c4": 300, "c5": 400}[name]
+    steps = args.steps if args.steps is not None else default_steps
+    warmup = args.warmup if args.warmup is not None else 10
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    B, m, n = args.batch, args.m, args.n
-
-    from bounded_lsq import _synth
-    P = _synth.trf_batch(10_000 + rank * B, B, m, n)   # each rank its own problems
-    Delta = make_deltas(B)
-    alpha0 = np.zeros(B)
+    main_line = name == "c2" and not (args.m or args.n)
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(P, Delta)              # before any GPU initialisation (fork)
+    if rank == 0 and world == 1 and not args.no_cpu and main_line:
+        from bounded_lsq import _synth
+        Bc = args.batch or CONFIGS["c2"]["batch"]
+        Pc = _synth.trf_batch(10_000, min(Bc, 64), 4096, 256)      # a sample of the same seeded batch
+        cpu = cpu_baseline(Pc, make_deltas("trf", min(Bc, 64)))    # before any GPU initialisation (fork)
+        del Pc
 
     dist = None
     backend = os.environ.get("BLSQ_DIST_BACKEND", "nccl")     # "gloo": rehearsal on one GPU
@@ -218,17 +476,20 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from bounded_lsq import TrfStepSolver, _abi
+    from bounded_lsq import _abi
     ndev = max(1, _abi.load().blsq_device_count())
     ctx = _abi.Context(local_rank % ndev)
-    sol = TrfStepSolver(B, m, n, ctx=ctx)
-    d = {k: ctx.to_device(P[k]) for k in ("J", "f", "x", "lb", "ub", "scale")}
-    dDelta = ctx.to_device(Delta)
-    dAlpha = ctx.to_device(alpha0)
 
-    def one_step():
-        sol.factor_dev(d["J"], d["f"], d["x"], d["lb"], d["ub"], d["scale"])
-        sol.step_dev(dDelta, dAlpha)
+    def bcast_comm_id():
+        """rank 0's RCCL rendezvous id to every rank, through the launcher's process group"""
+        import torch
+        dev = "cuda" if backend == "nccl" else "cpu"
+        nb = ctx.lib.blsq_comm_id_bytes()
+        buf = torch.zeros(nb, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            buf.copy_(torch.frombuffer(bytearray(ctx.comm_new_id()), dtype=torch.uint8))
+        dist.broadcast(buf, src=0)
+        return bytes(buf.cpu().numpy().tobytes())
 
     def fence():
         ctx.sync()
@@ -240,122 +501,107 @@ def main():
             if backend == "nccl":
                 torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
-    fence()
-    ctx.timing(True)
-    ctx.timing_reset()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    ctx.sync()
-    elapsed = time.perf_counter() - t0
-    fence()
-    ctx.timing(False)
-    if dist is not None:
+    def max_over_ranks(v):
+        if dist is None:
+            return v
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device="cuda" if backend == "nccl" else "cpu")
+        t = torch.tensor([v], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
 
-    # Same workload with the normal-equations front end switched off (every problem through the
-    # Householder TSQR tree — what a batch gets whose problems fail the conditioning gate).  A
-    # reported side figure at N = 1 only, never `value`.
-    householder = None
-    if world == 1 and not args.no_householder:
-        os.environ["BLSQ_GRAM"] = "0"                  # read when a plan is created
-        sol_h = TrfStepSolver(B, m, n, ctx=ctx)
-        os.environ.pop("BLSQ_GRAM", None)
+    probe = None
+    if not args.no_probe:
+        try:
+            probe = {"mfma_f64_tflops": ctx.probe("mfma_f64", 2)[0],
+                     "hbm_copy_gbs": ctx.probe("copy", 1024)[0],
+                     "source": "blsq_debug_probe in this run: back-to-back v_mfma_f64_16x16x4_f64 from "
+                               "every SIMD (2 waves); 1 GiB device-to-device copy, read + written bytes"}
+        except Exception as exc:                               # noqa: BLE001
+            probe = {"error": str(exc)[:200]}
 
-        def step_h():
-            sol_h.factor_dev(d["J"], d["f"], d["x"], d["lb"], d["ub"], d["scale"])
-            sol_h.step_dev(dDelta, dAlpha)
-        step_h(); ctx.sync()
-        kh = max(2, min(args.steps, 4))
-        th = time.perf_counter()
-        for _ in range(kh):
-            step_h()
-        ctx.sync()
-        eh = time.perf_counter() - th
-        householder = {"value": B * kh / eh, "unit": "step-solves/s", "ms_per_step": 1e3 * eh / kh,
-                       "steps": kh, "note": "BLSQ_GRAM=0: Householder TSQR tree for every problem"}
-        sol_h.close()
+    comm_ready = False
+    if name == "c5" and world > 1:
+        ctx.comm_init(world, rank, bcast_comm_id())
+        comm_ready = True
+    bench = Bench(name, ctx, rank, world, batch=args.batch, m=args.m, n=args.n, comm_ready=comm_ready)
+    elapsed = max_over_ranks(time_steps(bench, steps, warmup, fence))
+    out = record(bench, name, elapsed, steps, warmup, world, probe) if rank == 0 else None
+    parity = bench.parity(args.check) if (rank == 0 and args.check > 0) else None
 
-    # parity spot-check of the timed configuration (rank 0, a few problems)
-    parity = None
-    if rank == 0 and args.check > 0:
-        from oracle import blsq_oracle as orc
-        S = sol.fetch_step()
-        worst = 0.0
-        masks_ok = True
-        for b in range(min(args.check, B)):
-            _, So = orc.trf_step_solve(P["J"][b], P["f"][b], P["x"][b], P["lb"][b], P["ub"][b],
-                                       P["scale"][b], float(Delta[b]), 0.0)
-            worst = max(worst, float(np.linalg.norm(S.step[b] - So.step) /
-                                     np.linalg.norm(So.step)))
-            masks_ok = masks_ok and bool(np.array_equal(S.hits[b], So.hits))
-        sw = sol.debug_sweeps()
-        parity = {"problems": min(args.check, B), "max_rel_step_err": worst,
-                  "masks_bit_exact": masks_ok,
-                  "jacobi_sweeps": [int(sw.min()), float(sw.mean()), int(sw.max())],
-                  "svd_free_fraction": float(sol.debug_fast().mean())}
+    extras = {}
+    if world == 1 and main_line:
+        B, m, n = bench.B, bench.m, bench.n
+        if not args.no_householder:
+            # the same workload with the normal-equations front end off: every problem through the
+            # Householder TSQR tree — what a batch gets whose problems fail the conditioning gate
+            os.environ["BLSQ_GRAM"] = "0"                      # read when a plan is created
+            bh = Bench(name, ctx, 0, 1, batch=args.batch)
+            os.environ.pop("BLSQ_GRAM", None)
+            kh = max(2, min(steps, 20))
+            eh = time_steps(bh, kh, 1, ctx.sync)
+            extras["householder_only"] = {
+                "value": B * kh / eh, "unit": "step-solves/s", "ms_per_step": 1e3 * eh / kh, "steps": kh,
+                "kernels_ms_per_step": {k: round(v[0] / kh, 4) for k, v in ctx.timing_read().items() if v[0] > 0},
+                "note": "BLSQ_GRAM=0: Householder TSQR tree for every problem"}
+            bh.close()
+        if not args.no_h2d:
+            # numpy in, numpy out through blsq_trf_factor / blsq_trf_step: the 8 MiB Jacobian of every
+            # problem crosses PCIe inside the call ("including and excluding H2D of J")
+            bench.step_host()
+            kh = 3
+            t0 = time.perf_counter()
+            for _ in range(kh):
+                bench.step_host()
+            eh = time.perf_counter() - t0
+            extras["h2d_inclusive"] = {
+                "value": B * kh / eh, "unit": "step-solves/s", "ms_per_step": 1e3 * eh / kh, "steps": kh,
+                "host_to_device_GBps": 8.0 * B * m * (n + 1) * kh / eh / 1e9,
+                "note": "host-pointer API (pageable numpy buffers); the link bounds this mode, never `value`"}
+        if not args.no_side:
+            side = {}
+            for sn, ks in (("c2-single", 100), ("c3", 40), ("c4", 40), ("c5", 100)):
+                side[sn], hung = with_timeout(lambda sn=sn, ks=ks: side_run(sn, ctx, ks, 3, probe), 180,
+                                              "side config " + sn)
+                if hung:
+                    break
+            extras["side_configs"] = side
+    if world > 1 and main_line and not args.no_side:
+        # the tall problem of config 5 over ALL ranks (250 000 rows each): the library's own RCCL
+        # communicator, Gram all-reduce inside blsq_tsqr_factor_dev.  A side figure: guarded, timed out.
+        def c5_leg():
+            ctx.comm_init(world, rank, bcast_comm_id())
+            b5 = Bench("c5", ctx, rank, world, comm_ready=True)
+            try:
+                k5 = 100
+                e5 = max_over_ranks(time_steps(b5, k5, 5, fence))
+                r5 = record(b5, "c5", e5, k5, 5, world, probe) if rank == 0 else None
+            finally:
+                b5.close()
+            if r5 is None:
+                return None
+            return {"workload": "one TRF problem of %d x 128 split by rows over %d ranks" % (250_000 * world, world),
+                    "value": r5["value"], "unit": "step-solves/s", "ms_per_step": r5["ms_per_step"],
+                    "steps": k5, "kernels_ms_per_step": r5["kernels_ms_per_step"],
+                    "mfma_ceiling_frac_survey": r5["value"] * alg_flops("trf", 250_000 * world, 128)
+                    / (PEAK_FP64_TFLOPS * 1e12 * world),
+                    "collective": "ncclAllReduce(sum) of the 144 x 144 Gram on the library's stream"}
+        c5, hung = with_timeout(c5_leg, 240, "c5 over RCCL")
+        if rank == 0:
+            extras["c5_tsqr"] = c5
+        if hung:                                   # a hung collective: report and leave without teardown
+            if rank == 0:
+                out.update(extras)
+                out["parity"] = parity
+                print(json.dumps(out), flush=True)
+            os._exit(0)
 
     if rank == 0:
-        timing = ctx.timing_read()
-        total_solves = B * world * args.steps
-        value = total_solves / elapsed
-        ms_per_step = 1e3 * elapsed / args.steps
-        kern = {k: {"ms_total": v[0], "launches": v[1],
-                    "avg_ms": (v[0] / v[1] if v[1] else 0.0)} for k, v in timing.items()}
-        per_step_ms = {k: v["ms_total"] / args.steps for k, v in kern.items()}
-        dom = max(per_step_ms, key=lambda k: per_step_ms[k])
-        dom_launches_per_step = max(1, kern[dom]["launches"] // max(1, args.steps))
-        dom_avg_ms = kern[dom]["avg_ms"]
-        dom_ms = dom_avg_ms * dom_launches_per_step        # dominant kernel, per step
-        survey_flops = alg_flops_trf(m, n) * B             # R-SVD based step-solve count
-        byts = alg_bytes_trf(m, n) * B
-        # The roofline prices the dominant launch with the flops of ITS OWN algorithm (DESIGN.md
-        # 6): the Gram kernel m N (N + 1), the Householder leaf 2 r N^2 - 2/3 N^3 per row block.
-        # SURVEY 8(d)'s per-solve figure (an SVD-based count of the whole step-solve) is larger
-        # than what either kernel executes and is reported beside it, never as `achieved`.
-        own = {"gram": gram_flops_trf, "qr_leaf": leaf_flops_trf}.get(dom, alg_flops_trf)(m, n)
-        achieved_tf = own * B / (dom_ms * 1e-3) / 1e12
-        gs = ctx.gram_stats()
-        out = {
-            "metric": "TRF step-solves/sec (batched m x n dense Jacobian)",
-            "value": value, "unit": "step-solves/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C2 batched: TRF exact step-solve, m=%d n=%d, %d problems "
-                                   "per GPU, Delta mix 10/0.5 (reflective/feasible), inputs "
-                                   "resident in HBM" % (m, n, B),
-                       "m": m, "n": n, "batch_per_gpu": B, "sharding": "by problem, no collective"},
-            "roofline": {
-                "bound": "mfma", "achieved": achieved_tf, "peak": PEAK_FP64_TFLOPS,
-                "unit": "TFLOP/s", "frac": achieved_tf / PEAK_FP64_TFLOPS,
-                "traffic": measured_traffic(dom, m, n, B),
-                "kernel": dom, "kernel_ms_per_step": per_step_ms[dom],
-                "kernel_flops_per_solve": own,
-                "kernel_bytes_per_solve": gram_bytes_trf(m, n) if dom == "gram" else alg_bytes_trf(m, n),
-                "kernel_hbm_gbs": (gram_bytes_trf(m, n) if dom == "gram" else alg_bytes_trf(m, n))
-                * B / (dom_ms * 1e-3) / 1e9,
-                "survey_flops_per_solve": alg_flops_trf(m, n),
-                "survey_flops_over_kernel_time_tflops": survey_flops / (dom_ms * 1e-3) / 1e12,
-                "alg_bytes_per_solve": alg_bytes_trf(m, n),
-                "whole_step_survey_tflops": survey_flops / (ms_per_step * 1e-3) / 1e12,
-                "whole_step_hbm_gbs": byts / (ms_per_step * 1e-3) / 1e9,
-                "hbm_frac_of_8TBs": byts / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
-            },
-            "factorisation_paths": {"normal_equations": gs[0], "householder_tree": gs[1]},
-            "householder_only": householder,
-            "kernels_ms_per_step": per_step_ms,
-            "cpu_baseline": cpu,
-            "speedup_vs_cpu": (value / cpu["value"]) if cpu else None,
-            "parity": parity,
-        }
-        print(json.dumps(out))
-    sol.close()
+        out.update(extras)
+        out["cpu_baseline"] = cpu
+        out["speedup_vs_cpu"] = (out["value"] / cpu["value"]) if cpu else None
+        out["parity"] = parity
+        print(json.dumps(out), flush=True)
+    bench.close()
     if dist is not None:
         dist.destroy_process_group()
 
