@@ -7,6 +7,7 @@ behind the product API.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -134,6 +135,12 @@ class Context:
                             "(no MI355X visible?)" % (device_id, rc))
         self.h = h
         self.device_id = int(device_id)
+        self._plans = weakref.WeakSet()      # plans / drivers created on this ctx: closed before it
+
+    def adopt(self, plan):
+        """Register an object whose close() must run before the context is destroyed (the
+        library's plans keep a pointer to their ctx)."""
+        self._plans.add(plan)
 
     def check(self, rc, what=""):
         if rc != 0:
@@ -142,6 +149,11 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            for pl in list(getattr(self, "_plans", ())):
+                try:
+                    pl.close()
+                except Exception:
+                    pass
             self.lib.blsq_ctx_destroy(self.h)
             self.h = None
 

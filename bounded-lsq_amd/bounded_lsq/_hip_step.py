@@ -68,10 +68,12 @@ class TrfStepSolver:
         self.ctx.check(self.lib.blsq_trf_plan_create(self.ctx.h, self.B, self.m, self.n,
                                                      C.byref(h)), "blsq_trf_plan_create")
         self.h = h
+        self.ctx.adopt(self)
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.blsq_trf_plan_destroy(self.h)
+            if getattr(self.ctx, "h", None):         # (a closed ctx has closed its plans already)
+                self.lib.blsq_trf_plan_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -166,10 +168,12 @@ class DogboxStepSolver:
         self.ctx.check(self.lib.blsq_dogbox_plan_create(self.ctx.h, self.B, self.m, self.n,
                                                         C.byref(h)), "blsq_dogbox_plan_create")
         self.h = h
+        self.ctx.adopt(self)
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.blsq_dogbox_plan_destroy(self.h)
+            if getattr(self.ctx, "h", None):
+                self.lib.blsq_dogbox_plan_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -107,6 +107,7 @@ class TsqrTrfSolver(TrfStepSolver):
                                                       self.world, C.byref(h)),
                        "blsq_tsqr_plan_create")
         self.h = h
+        self.ctx.adopt(self)
 
     def factor_dev(self, dJ_block, df_block, dx, dlb, dub, dscale, scale_mode=SCALE_GIVEN):
         """local Gram -> all-reduce -> Cholesky + gate (or: local TSQR -> all-gather -> merge),

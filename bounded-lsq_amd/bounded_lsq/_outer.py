@@ -48,10 +48,12 @@ class OuterDriver:
         self.ctx.check(self.ctx.lib.blsq_outer_buffers(self.h, *[C.byref(b) for b in bufs]),
                        "blsq_outer_buffers")
         (self.d_x, self.d_x_trial, self.d_f, self.d_f_trial, self.d_J, self.d_accepted) = bufs
+        self.ctx.adopt(self)
 
     def close(self):
         if getattr(self, "h", None):
-            self.ctx.lib.blsq_outer_destroy(self.h)
+            if self.ctx is not None and getattr(self.ctx, "h", None):
+                self.ctx.lib.blsq_outer_destroy(self.h)
             self.h = None
         if self._own_ctx and self.ctx is not None:
             self.ctx.close()

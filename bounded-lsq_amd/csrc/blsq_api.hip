@@ -303,6 +303,61 @@ struct QrTree {
     *nfallback = ctx->pinned[1];
     return 0;
   }
+  // Gram front end ONLY: G = [J f]^T [J f] into gram_keep (+ the cross-rank sum); nothing is factored.
+  int run_gram_only(blsq_ctx* ctx, const double* dJ, const double* df, int ldJ, const int* mask,
+                    bool collective) {
+    GramArgs g{};
+    g.J = dJ; g.strideJ = (long)m * ldJ; g.ldJ = ldJ; g.F = df; g.strideF = m;
+    g.m = m; g.n = n; g.NPAD = NPAD; g.mask = mask;
+    double* Gk = gram_keep.as<double>();
+    g.G = gram_nchunk > 1 ? gram_part.as<double>() : Gk;
+    ctx->begin(K_GRAM);
+    hipError_t e = launch_gram(g, gram_nchunk, B, ctx->stream);
+    if (e == hipSuccess && gram_nchunk > 1)
+      e = launch_gram_reduce(gram_part.as<double>(), gram_nchunk, NPAD, Gk, mask, B, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_gram");
+    if (collective && ctx->comm && ctx->comm_ranks > 1)
+      RCCLCHK(ctx, g_rccl.AllReduce(Gk, Gk, (size_t)B * NPAD * NPAD, ncclDouble, ncclSum, ctx->comm,
+                                    ctx->stream));
+    return 0;
+  }
+  // Householder TSQR tree only (problems selected by ncols_mask; nullptr: all)
+  int run_levels(blsq_ctx* ctx, const double* dJ, const double* df, int ldJ, const int* ncols_mask) {
+    for (size_t l = 0; l < levels.size(); ++l) {
+      const Level& L = levels[l];
+      QrArgs q = base_args();
+      q.ncols_dev = ncols_mask;
+      if (l == 0) {
+        q.A = dJ; q.strideA = (long)m * ldJ; q.ldA = ldJ; q.rowsA = m;
+        q.F = df; q.strideF = m;
+      } else {
+        const Level& Pv = levels[l - 1];
+        q.A = Pv.R.as<double>(); q.strideA = (long)Pv.nleaf * NPAD * NPAD;
+        q.ldA = NPAD; q.rowsA = Pv.nleaf * NPAD; q.F = nullptr; q.strideF = 0;
+        q.stack_rows = NPAD;
+      }
+      q.rows_per_leaf = L.rows_per_leaf; q.RP = L.RP; q.LDP = L.LDP;
+      q.Rout = L.R.as<double>();
+      ctx->begin(l == 0 ? K_QR_LEAF : K_QR_MERGE);
+      hipError_t e = launch_qr(q, L.nleaf, B, ctx->stream);
+      ctx->end();
+      if (e != hipSuccess) return ctx->fail(e, "launch_qr");
+    }
+    return 0;
+  }
+  int* fb_mask() const { return gram_ints.as<int>(); }
+  int* fb_count() const { return gram_ints.as<int>() + B; }
+  int* path_rw() const { return gram_ints.as<int>() + B + 4; }
+  // host bookkeeping after a gate verdict: nfb of the problems refreshed by this call failed
+  void note_paths(blsq_ctx* ctx, int nfb, bool masked) {
+    ctx->gram_fallback += nfb;
+    ctx->gram_fast += B - nfb;              // (masked problems count as fast: diagnostics only)
+    // a masked call refreshes some problems only: the others keep their earlier path
+    if (!masked || !path_valid) { any_qr = nfb > 0 || masked; any_gram = nfb < B; }
+    else { any_qr = any_qr || nfb > 0; any_gram = true; }
+    path_valid = true;
+  }
   const double* Rfinal() const { return levels.back().R.as<double>(); }
 
   QrArgs base_args() const {
@@ -592,7 +647,7 @@ int trf_alloc_state(blsq_trf_plan* p) {
     if (e__ != hipSuccess) return ctx->fail(e__, "hipMalloc(" #buf ")"); \
   } while (0)
   ALLOC(p->X, sizeof(double) * B * mat);
-  ALLOC(p->vecs, sizeof(double) * (size_t)B * ld * 12);
+  ALLOC(p->vecs, sizeof(double) * (size_t)B * ld * 13);
   ALLOC(p->scal2, sizeof(double) * (size_t)B * 8);
   ALLOC(p->sweeps, sizeof(int) * (size_t)B);
   ALLOC(p->o_vec, sizeof(double) * (size_t)B * ld * 4);
@@ -610,6 +665,7 @@ int trf_alloc_state(blsq_trf_plan* p) {
   st.x = v; st.lb = v + vs; st.ub = v + 2 * vs; st.scale = v + 3 * vs;
   st.g = v + 4 * vs; st.v = v + 5 * vs; st.d = v + 6 * vs; st.g_h = v + 7 * vs;
   st.diag_h = v + 8 * vs; st.s = v + 9 * vs; st.uf = v + 10 * vs; st.ediag = v + 11 * vs;
+  st.scale_in = v + 12 * vs;
   double* sc = p->scal2.as<double>();
   st.srange = sc; st.g_norm = sc + 2 * (size_t)B; st.theta = sc + 3 * (size_t)B;
   double* ov = p->o_vec.as<double>();
@@ -656,51 +712,35 @@ int trf_alloc_state(blsq_trf_plan* p) {
 #undef ALLOC
 }
 
-// everything after the triangle R~ is known: prep, augmented QR, Jacobi SVD
-int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode) {
+// ---- after the front end --------------------------------------------------------------------------
+// Two ways into the n-space path:
+//   trf_after_triangle   a triangle [R c] of [J f] is given for every problem (front end off, TSQR
+//                        merge): prep from R, stacked QR of [R D; E]
+//   trf_gram_stage ...   the normal-equations path: prep from the Gram, H = D G D + E^2 factored by
+//                        Cholesky, and the conditioning gate applied to THAT factor — the system the
+//                        step is solved from.  No triangle of J is ever formed for such a problem;
+//                        a problem the gate rejects is factored by the Householder tree and prepared
+//                        again from its triangle (trf_fallback_stage).
+int trf_finish(blsq_trf_plan* p) {
   blsq_ctx* ctx = p->ctx;
-  p->st.Rt = Rt;
-  ctx->begin(K_PREP);
-  hipError_t e = launch_trf_prep(p->st, scale_mode, ctx->stream);
-  ctx->end();
-  if (e != hipSuccess) return ctx->fail(e, "launch_trf_prep");
-  // Per problem: a triangle that came from its Gram G gets the triangle of [R D | c; E | 0] as the
-  // Cholesky factor of D G D + E^2 (gram_kernels.hip; no new gate needed, see there); a triangle
-  // from the Householder tree gets the stacked QR.  The choice depends on the problem alone.
-  const bool own = (Rt == p->tree.Rfinal()) && p->tree.gram && p->tree.path_valid;
-  p->path = own ? p->tree.gram_path() : nullptr;
-  p->use_chol = own && p->tree.any_gram;
-  p->use_qr = !own || p->tree.any_qr;
-  p->lm.path = p->path;
-  p->lm.colinfo = p->use_chol ? p->aug_colinfo.as<double>() : nullptr;
-  if (p->use_chol) {
-    GramCholArgs c{};
-    c.Gsrc = p->tree.gram_keep.as<double>(); c.G = p->st.X; c.NPAD = p->ld; c.n = p->n;
-    c.colscale = p->st.d; c.diag_vec = p->st.ediag; c.stride_vec = p->ld;
-    c.skip_path = p->path;
-    c.colinfo = p->aug_colinfo.as<double>();
-    ctx->begin(K_AUG_CHOL);
-    e = launch_gram_chol(c, p->B, ctx->stream);
-    ctx->end();
-    if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(aug)");
-  }
+  hipError_t e;
   if (p->use_qr) {
-  QrArgs q = p->tree.base_args();
-  q.ncols_dev = p->path;                // (nullptr: all problems)
-  // source = R read in place, columns scaled by d on the fly, on top of the VIRTUAL block
-  // E = diag(ediag): [R D | c ; E | 0] is never written to memory
-  q.A = Rt; q.strideA = (long)p->ld * p->ld; q.ldA = p->ld;
-  q.rowsA = aug_block_rows(p->n) + p->n;
-  q.vdiag_row0 = aug_block_rows(p->n); q.vdiag_vec = p->st.ediag;
-  q.colscale = p->st.d; q.stride_vec = p->ld;
-  q.F = nullptr; q.strideF = 0;
-  q.rows_per_leaf = p->aug_RP; q.RP = p->aug_RP; q.LDP = p->aug_LDP;
-  q.Rout = p->st.X;
-  q.stack_rows = aug_block_rows(p->n); // [R D; E]: two upper-triangular blocks
-  ctx->begin(K_QR_AUG);
-  e = launch_qr(q, 1, p->B, ctx->stream);
-  ctx->end();
-  if (e != hipSuccess) return ctx->fail(e, "launch_qr(aug)");
+    QrArgs q = p->tree.base_args();
+    q.ncols_dev = p->path;                // (nullptr: all problems)
+    // source = R read in place, columns scaled by d on the fly, on top of the VIRTUAL block
+    // E = diag(ediag): [R D | c ; E | 0] is never written to memory
+    q.A = p->st.Rt; q.strideA = (long)p->ld * p->ld; q.ldA = p->ld;
+    q.rowsA = aug_block_rows(p->n) + p->n;
+    q.vdiag_row0 = aug_block_rows(p->n); q.vdiag_vec = p->st.ediag;
+    q.colscale = p->st.d; q.stride_vec = p->ld;
+    q.F = nullptr; q.strideF = 0;
+    q.rows_per_leaf = p->aug_RP; q.RP = p->aug_RP; q.LDP = p->aug_LDP;
+    q.Rout = p->st.X;
+    q.stack_rows = aug_block_rows(p->n); // [R D; E]: two upper-triangular blocks
+    ctx->begin(K_QR_AUG);
+    e = launch_qr(q, 1, p->B, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_qr(aug)");
   }
   // rank gate: clearly full-rank problems skip the SVD (lm_kernels.hip)
   ctx->begin(K_LM_GATE);
@@ -716,6 +756,85 @@ int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode) {
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_jacobi");
   return 0;
+}
+
+int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode) {
+  blsq_ctx* ctx = p->ctx;
+  p->st.Rt = Rt; p->st.Gk = nullptr; p->st.path = nullptr;
+  p->path = nullptr; p->use_chol = false; p->use_qr = true;
+  p->lm.path = nullptr; p->lm.colinfo = nullptr;
+  p->tree.path_valid = false; p->tree.any_gram = false; p->tree.any_qr = true;
+  ctx->begin(K_PREP);
+  hipError_t e = launch_trf_prep(p->st, scale_mode, 0, nullptr, 0, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_trf_prep");
+  return trf_finish(p);
+}
+
+// prep from the Gram, Cholesky of H with the pivot gate, conditioning gate; *nfb = problems of this
+// call that must go to the Householder tree (their indices are flagged in tree.fb_mask()).
+int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb) {
+  blsq_ctx* ctx = p->ctx;
+  QrTree& t = p->tree;
+  HIPCHK(ctx, hipMemsetAsync(t.fb_count(), 0, sizeof(int), ctx->stream));
+  p->st.Rt = t.Rfinal(); p->st.Gk = t.gram_keep.as<double>(); p->st.path = t.path_rw();
+  ctx->begin(K_PREP);
+  hipError_t e = launch_trf_prep(p->st, scale_mode, 1, mask, 0, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_trf_prep(gram)");
+  GramCholArgs c{};
+  c.Gsrc = t.gram_keep.as<double>(); c.G = p->st.X; c.NPAD = p->ld; c.n = p->n;
+  c.colscale = p->st.d; c.diag_vec = p->st.ediag; c.stride_vec = p->ld;
+  c.mask = mask; c.fb_mask = t.fb_mask(); c.fail_count = t.fb_count(); c.path_out = t.path_rw();
+  c.dsc = t.gram_dsc.as<double>();
+  c.colinfo = p->aug_colinfo.as<double>();
+  ctx->begin(K_AUG_CHOL);
+  e = launch_gram_chol(c, p->B, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(aug)");
+  ctx->begin(K_GRAM_GATE);
+  e = launch_gram_gate(c, p->B, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_gram_gate");
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 1, t.fb_count(), sizeof(int), hipMemcpyDeviceToHost,
+                             ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  *nfb = ctx->pinned[1];
+  t.note_paths(ctx, *nfb, mask != nullptr);
+  p->path = t.path_rw();
+  p->use_chol = t.any_gram;
+  p->use_qr = t.any_qr;
+  p->lm.path = p->path;
+  p->lm.colinfo = p->use_chol ? p->aug_colinfo.as<double>() : nullptr;
+  return 0;
+}
+
+// the problems the gate rejected: Householder tree on [J f], prep again from the triangle
+int trf_fallback_stage(blsq_trf_plan* p, const double* dJ, const double* df, int ldJ, int scale_mode) {
+  blsq_ctx* ctx = p->ctx;
+  int rc = p->tree.run_levels(ctx, dJ, df, ldJ, p->tree.fb_mask());
+  if (rc) return rc;
+  ctx->begin(K_PREP);
+  hipError_t e = launch_trf_prep(p->st, scale_mode, 0, p->tree.fb_mask(), 1, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_trf_prep(redo)");
+  return 0;
+}
+
+// the whole factor call from device-resident [J f] (mask: outer driver, fresh Jacobians only)
+int trf_factor_core(blsq_trf_plan* p, const double* dJ, const double* df, int ldJ, int scale_mode,
+                    const int* mask) {
+  blsq_ctx* ctx = p->ctx;
+  int rc;
+  if (!p->tree.gram) {
+    if ((rc = p->tree.run_levels(ctx, dJ, df, ldJ, mask))) return rc;
+    return trf_after_triangle(p, p->tree.Rfinal(), scale_mode);
+  }
+  if ((rc = p->tree.run_gram_only(ctx, dJ, df, ldJ, mask, false))) return rc;
+  int nfb = 0;
+  if ((rc = trf_gram_stage(p, scale_mode, mask, &nfb))) return rc;
+  if (nfb > 0 && (rc = trf_fallback_stage(p, dJ, df, ldJ, scale_mode))) return rc;
+  return trf_finish(p);
 }
 
 // Safeguarded Newton iteration of the SVD-free problems: lock-step rounds of
@@ -834,8 +953,7 @@ extern "C" int blsq_trf_factor_dev(blsq_trf_plan* p, const double* dJ, const dou
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc = trf_put_bounds(p, dx, dlb, dub, dscale_io, hipMemcpyDeviceToDevice);
   if (rc) return rc;
-  if ((rc = p->tree.run(ctx, dJ, df, p->n))) return rc;
-  if ((rc = trf_after_triangle(p, p->tree.Rfinal(), scale_mode))) return rc;
+  if ((rc = trf_factor_core(p, dJ, df, p->n, scale_mode, nullptr))) return rc;
   if (scale_mode != BLSQ_SCALE_GIVEN) {
     HIPCHK(ctx, hipMemcpy2DAsync(dscale_io, sizeof(double) * p->n, p->st.scale,
                                  sizeof(double) * p->ld, sizeof(double) * p->n, p->B,
@@ -960,8 +1078,8 @@ extern "C" int blsq_trf_factor(blsq_trf_plan* p, const double* J, const double* 
   HIPCHK(ctx, hipMemcpyAsync(p->in_f.p, f, fb, hipMemcpyHostToDevice, ctx->stream));
   int rc = trf_put_bounds(p, x, lb, ub, scale_io, hipMemcpyHostToDevice);
   if (rc) return rc;
-  if ((rc = p->tree.run(ctx, p->in_J.as<double>(), p->in_f.as<double>(), p->n))) return rc;
-  if ((rc = trf_after_triangle(p, p->tree.Rfinal(), scale_mode))) return rc;
+  if ((rc = trf_factor_core(p, p->in_J.as<double>(), p->in_f.as<double>(), p->n, scale_mode, nullptr)))
+    return rc;
   return blsq_trf_fetch_factor(p, g, g_norm, theta,
                                scale_mode != BLSQ_SCALE_GIVEN ? scale_io : nullptr, nullptr);
 }
@@ -1122,14 +1240,26 @@ extern "C" int blsq_tsqr_factor_dev(blsq_trf_plan* p, const double* dJ_block, co
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc = trf_put_bounds(p, dx, dlb, dub, dscale_io, hipMemcpyDeviceToDevice);
   if (rc) return rc;
-  if ((rc = p->tree.run(ctx, dJ_block, df_block, p->n, nullptr, /*collective=*/true))) return rc;
-  const bool global_gram = p->tree.gram && p->tree.path_valid && !p->tree.any_qr;
-  if (global_gram || p->nranks == 1) {               // the triangle is already the global one
-    if ((rc = trf_after_triangle(p, p->tree.Rfinal(), scale_mode))) return rc;
+  auto put_scale = [&]() -> int {
     if (scale_mode != BLSQ_SCALE_GIVEN)
       HIPCHK(ctx, hipMemcpyAsync(dscale_io, p->st.scale, sizeof(double) * p->n,
                                  hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
+  };
+  if (p->tree.gram) {
+    if ((rc = p->tree.run_gram_only(ctx, dJ_block, df_block, p->n, nullptr, /*collective=*/true))) return rc;
+    int nfb = 0;
+    if ((rc = trf_gram_stage(p, scale_mode, nullptr, &nfb))) return rc;   // replicated: same verdict everywhere
+    if (nfb == 0) {
+      if ((rc = trf_finish(p))) return rc;
+      return put_scale();
+    }
+  }
+  // Householder route: this rank's triangle, all-gather, replicated merge
+  if ((rc = p->tree.run_levels(ctx, dJ_block, df_block, p->n, nullptr))) return rc;
+  if (p->nranks == 1) {
+    if ((rc = trf_after_triangle(p, p->tree.Rfinal(), scale_mode))) return rc;
+    return put_scale();
   }
   const size_t tri = (size_t)p->ld * p->ld;
   RCCLCHK(ctx, g_rccl.AllGather(p->tree.Rfinal(), p->Rstack.as<double>(), tri, ncclDouble, ctx->comm,
@@ -1582,8 +1712,7 @@ int outer_factor(blsq_outer* o, int scale_mode, const int* mask) {
   int rc;
   if (o->method == 0) {
     blsq_trf_plan* p = o->trf;
-    if ((rc = p->tree.run(ctx, o->J.as<double>(), o->st.f, p->n, mask))) return rc;
-    return trf_after_triangle(p, p->tree.Rfinal(), scale_mode);
+    return trf_factor_core(p, o->J.as<double>(), o->st.f, p->n, scale_mode, mask);
   }
   blsq_dogbox_plan* p = o->dog;
   if ((rc = p->tree.run(ctx, o->J.as<double>(), o->st.f, p->n, mask))) return rc;

@@ -117,9 +117,15 @@ hipError_t launch_jacobi(const JacobiArgs& a, int B, hipStream_t st);
 // ---------------------------------------------------------------- TRF -----
 struct TrfState {         // all device pointers, batch-major, vector stride ld
   int B, m, n, ld;        // ld == NPAD
-  const double* Rt;       // [B][ld*ld]   R~ = [R c; 0 rho] of [J f]
+  const double* Rt;       // [B][ld*ld]   R~ = [R c; 0 rho] of [J f]   (problems on the Householder path)
+  // Problems on the normal-equations path have NO triangle of J: everything the step needs from J
+  // comes from the Gram G = [J f]^T [J f] (g = G[:, n], ||J_j||^2 = G[j][j]) and from the factor X of
+  // H = D G D + E^2:  (J_h a).(J_h b) + a.diag_h.b = (X a).(X b).
+  const double* Gk;       // [B][ld*ld]   Grams (upper tile blocks), or nullptr
+  const int* path;        // [B] 0: normal-equations path, != 0: Householder path; nullptr: Householder for all
   double* X;              // [B][ld*ld]   R~_aug, then (Jacobi) rows s_i v_i^T | uf_i
   double *x, *lb, *ub, *scale;            // [B][ld]
+  double *scale_in;                       // [B][ld]  `scale` as it was before the last prep (redo after a gate failure)
   double *g, *v, *d, *g_h, *diag_h;       // [B][ld]
   double *ediag;                          // [B][ld]  sqrt(diag_h): diagonal of the Coleman-Li block E
   double *s, *uf;                         // [B][ld]
@@ -128,7 +134,11 @@ struct TrfState {         // all device pointers, batch-major, vector stride ld
 };
 // jac_scaling: 0 keep `scale`; 1 scale = 1/||J col|| (0 -> 1)  (trf.py:216-219);
 //              2 scale = min(scale, 1/||J col||)               (trf.py:239-242)
-hipError_t launch_trf_prep(const TrfState& st, int jac_scaling, hipStream_t s);
+// from_gram: g and the column norms come from st.Gk instead of st.Rt.  sel (optional [B]): only
+// problems with sel[b] > 1 are processed.  redo: the problem was prepared from its Gram already in
+// this factor call (its gate failed since): start again from scale_in.
+hipError_t launch_trf_prep(const TrfState& st, int jac_scaling, int from_gram, const int* sel,
+                           int redo, hipStream_t s);
 
 struct TrfStepOut {       // device pointers
   double* step_h;         // [B][ld]

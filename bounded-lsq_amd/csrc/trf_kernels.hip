@@ -19,16 +19,24 @@ static constexpr int NS_NW = NS_NT / WAVE;
 static constexpr double EPS = 2.220446049250313e-16;
 
 // ------------------------------------------------------------------ prep --
-__global__ __launch_bounds__(NS_NT) void trf_prep_kernel(TrfState st, int jac_scaling) {
+__global__ __launch_bounds__(NS_NT) void trf_prep_kernel(TrfState st, int jac_scaling, int from_gram,
+                                                         const int* sel, int redo) {
   __shared__ double red[32];
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (sel && sel[b] <= 1) return;
   const int n = st.n, ld = st.ld;
   const double* Rt = st.Rt + (long)b * ld * ld;
+  const double* Gk = from_gram ? st.Gk + (long)b * ld * ld : nullptr;
   const long vo = (long)b * ld;
   double gmax = 0.0;
   for (int j = tid; j < n; j += NS_NT) {
-    // g_j = sum_{i<=j} R[i][j] c_i ; column norm of R for 'jac' scaling
     double gj = 0.0, nn = 0.0;
+    if (from_gram) {
+      // g_j = (J^T f)_j and ||J_j||^2 straight from the Gram (trf.py:244; :216-219, :239-242)
+      gj = Gk[(long)j * ld + n];
+      nn = Gk[(long)j * ld + j];
+    } else {
+    // g_j = sum_{i<=j} R[i][j] c_i ; column norm of R for 'jac' scaling
     for (int i0 = 0; i0 <= j; i0 += 8) {      // 8 rows per pass, loads unconditional (clamped)
       double rv[8], cv[8];
 #pragma unroll
@@ -45,7 +53,9 @@ __global__ __launch_bounds__(NS_NT) void trf_prep_kernel(TrfState st, int jac_sc
         }
       }
     }
-    double sc = st.scale[vo + j];
+    }
+    double sc = redo ? st.scale_in[vo + j] : st.scale[vo + j];
+    if (!redo) st.scale_in[vo + j] = sc;
     if (jac_scaling == 1) {
       double jn = sqrt(nn);
       if (jn == 0.0) jn = 1.0;
@@ -80,8 +90,10 @@ __global__ __launch_bounds__(NS_NT) void trf_prep_kernel(TrfState st, int jac_sc
   // R in place, scales column j by d_j while loading and takes E from `ediag` (qr_panel.hip).
 }
 
-hipError_t launch_trf_prep(const TrfState& st, int jac_scaling, hipStream_t s) {
-  hipLaunchKernelGGL(trf_prep_kernel, dim3(st.B), dim3(NS_NT), 0, s, st, jac_scaling);
+hipError_t launch_trf_prep(const TrfState& st, int jac_scaling, int from_gram, const int* sel,
+                           int redo, hipStream_t s) {
+  hipLaunchKernelGGL(trf_prep_kernel, dim3(st.B), dim3(NS_NT), 0, s, st, jac_scaling, from_gram, sel,
+                     redo);
   return hipGetLastError();
 }
 
@@ -137,8 +149,37 @@ __device__ void tri_matvec(const double* R, const double* dvec, int n, int ld, c
         const int i = i0 + r * NS_NW;
         const int j = i + lane + jj;
         // (R[i][j] * d[j]) * s[j]: the same roundings as a materialised R_h = R D
-        if (i < n && j < n) acc[r] = fma(rv[r] * dvec[j], svec[j], acc[r]);
+        if (i < n && j < n) acc[r] = fma(dvec ? rv[r] * dvec[j] : rv[r], svec[j], acc[r]);
       }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int i = i0 + r * NS_NW;
+      const double t = wave_sum(acc[r]);
+      if (lane == 0 && i < n) u[i] = t;
+    }
+  }
+  __syncthreads();
+}
+
+// u = M s for a DENSE n x n block (row-major, stride ld): the Jacobi rows s_i v_i^T of a problem whose
+// factor went through the SVD.  One wave per row.
+__device__ void full_matvec(const double* M, int n, int ld, const double* svec, double* u) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int RB = 4;
+  for (int i0 = w; i0 < n; i0 += NS_NW * RB) {
+    double acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = 0.0;
+    for (int jj = lane; jj < n; jj += WAVE) {
+      double rv[RB];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int i = i0 + r * NS_NW;
+        rv[r] = M[(long)((i < n) ? i : n - 1) * ld + jj];
+      }
+#pragma unroll
+      for (int r = 0; r < RB; ++r) acc[r] = fma(rv[r], svec[jj], acc[r]);
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -200,6 +241,10 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
   const double* uf = st.uf + vo;
   const double* X = st.X + (long)b * ld * ld;
   const double* Rh = st.Rt + (long)b * ld * ld;           // R; R_h = R D is applied on the fly
+  // Normal-equations path: there is no R.  X^T X = H = J_h^T J_h + diag_h (X: the triangle R_aug, or
+  // after the SVD the rows s_i v_i^T — an orthogonal transformation of it), so every quadratic form
+  // of the model, (J_h a).(J_h b) + a.diag_h.b, is (X a).(X b): the diag_h terms below drop out.
+  const bool gp = st.path && st.path[b] == 0;
   const double* xg = st.x + vo;
   const double* dg = st.d + vo;
   const double* gh = st.g_h + vo;
@@ -218,6 +263,11 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
   int n_iter = 0;
   bool have_p = false;
   const bool fast = lm_fast && lm_fast[b];       // SVD-free path already produced p (lm_kernels.hip)
+  auto model_mv = [&](const double* svec, double* u) {    // u = J_h s  (resp. X s on the Gram path)
+    if (!gp) tri_matvec(Rh, dg, n, ld, svec, u);
+    else if (fast) tri_matvec(X, nullptr, n, ld, svec, u);
+    else full_matvec(X, n, ld, svec, u);
+  };
   if (fast) {
     for (int j = tid; j < n; j += NS_NT) ph[j] = lm_ph[vo + j];
     alpha = lm_sc[(long)b * 16];
@@ -336,7 +386,7 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     const double f = (tt < 1.0) ? tt : 1.0;                  // min(theta*to_bound, 1)
     for (int j = tid; j < n; j += NS_NT) ph[j] *= f;
     __syncthreads();
-    tri_matvec(Rh, dg, n, ld, ph, up);
+    model_mv(ph, up);
     const double q2 = dot_dev(up, up, n, red);
     double dq = 0.0, lin = 0.0;
     for (int j = tid; j < n; j += NS_NT) {
@@ -345,7 +395,7 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     }
     dq = block_sum(dq, red);
     lin = block_sum(lin, red);
-    qp[0] = 0.5 * (q2 + dq) + lin;
+    qp[0] = (gp ? 0.5 * q2 : 0.5 * (q2 + dq)) + lin;
     step_h = ph;
   } else {
     branch = 1;
@@ -385,18 +435,18 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     double r_lo;
     if (r_hi > 0.0) r_lo = (1.0 - theta) * p_stride / r_hi;
     else r_lo = -1.0;
-    tri_matvec(Rh, dg, n, ld, ph, up);                           // J_h p_h (stride-scaled)
+    model_mv(ph, up);                                            // J_h p_h (stride-scaled)
     bool have_r = false;
     double r_t = 0.0;
     if (status == 0 && r_lo <= r_hi) {
-      tri_matvec(Rh, dg, n, ld, rh, ur);
+      model_mv(rh, ur);
       const double vv = dot_dev(ur, ur, n, red);
       const double sds = dot3_dev(rh, dh, rh, n, red);
-      const double qa = 0.5 * (vv + sds);
+      const double qa = gp ? 0.5 * vv : 0.5 * (vv + sds);
       double qb = dot_dev(gh, rh, n, red);
       const double uv = dot_dev(up, ur, n, red);
       const double s0ds = dot3_dev(ph, dh, rh, n, red);
-      qb += uv + s0ds;
+      qb += gp ? uv : uv + s0ds;
       r_t = quad_min_dev(qa, qb, r_lo, r_hi);
       have_r = true;
     }
@@ -418,10 +468,10 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     double g_hi = (to_trg < to_bg) ? to_trg : to_bg;
     for (int j = tid; j < n; j += NS_NT) tmp[j] = -gh[j];
     __syncthreads();
-    tri_matvec(Rh, dg, n, ld, tmp, ug);                          // J_h (-g_h)
+    model_mv(tmp, ug);                                           // J_h (-g_h)
     const double gvv = dot_dev(ug, ug, n, red);
     const double gsds = dot3_dev(tmp, dh, tmp, n, red);
-    const double ga = 0.5 * (gvv + gsds);
+    const double ga = gp ? 0.5 * gvv : 0.5 * (gvv + gsds);
     const double gb = dot_dev(gh, tmp, n, red);
     const double g_t = quad_min_dev(ga, gb, 0.0, g_hi);
     for (int j = tid; j < n; j += NS_NT) tmp[j] = -g_t * gh[j];   // c_h
@@ -444,6 +494,7 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     }
     d0 = block_sum(d0, red); d1 = block_sum(d1, red); d2 = block_sum(d2, red);
     l0 = block_sum(l0, red); l1 = block_sum(l1, red); l2 = block_sum(l2, red);
+    if (gp) { d0 = 0.0; d1 = 0.0; d2 = 0.0; }                    // (already inside the X products)
     qp[0] = 0.5 * (q0 + d0) + l0;
     qp[1] = have_r ? (0.5 * (q1 + d1) + l1) : qp[0];
     qp[2] = 0.5 * (q2 + d2) + l2;

@@ -81,3 +81,24 @@ def test_exported_helpers_known_answers():
     np.testing.assert_array_equal(ub, [1, 2])
     assert bounded_lsq.CL_optimality(np.array([.2, .2, .2]), np.array([-1., 1., 0.]), 0.0,
                                      np.array([1., np.inf, 1.])) == pytest.approx(0.8)
+
+
+def test_step_status_maps_to_the_references_exceptions():
+    """BLSQ_STATUS_* -> the ValueError the reference raises (trust_region.py:28-29, 34-35); in a
+    batch the first offending ACTIVE problem is named."""
+    import numpy as np
+    import pytest
+    from bounded_lsq import _hip_step
+    _hip_step._raise_status(0)
+    with pytest.raises(ValueError, match="`s` is zero"):
+        _hip_step._raise_status(1)
+    with pytest.raises(ValueError, match="`x` is not within the trust region"):
+        _hip_step._raise_status(2)
+    _hip_step.raise_batch_status(np.array([0, 0, 0]))
+    _hip_step.raise_batch_status(np.array([0, 2, 0]), active=np.array([True, False, True]))
+    with pytest.raises(ValueError, match="problem 2: `x` is not within"):
+        _hip_step.raise_batch_status(np.array([0, 1, 2]), active=np.array([True, False, True]))
+    from bounded_lsq._outer import raise_step_errors
+    raise_step_errors(np.array([1, 3, 0, 4]))
+    with pytest.raises(ValueError, match="problem 1: `s` is zero"):
+        raise_step_errors(np.array([2, -1, -2]))

@@ -1,9 +1,17 @@
 """Normal-equations fast path of the factorisation (gram_kernels.hip) and its conditioning gate.
 
 The step must match the CPU oracle to 1e-10 / bit-exact masks WHICHEVER path factors a problem;
-the diagnostic counter (blsq_debug_gram_stats) shows which one ran.  Columns that all share a common
-component with cosine rho give an equilibrated Gram with sigma_min(R') = sqrt(1 - rho): the gate
-(pivots and inverse-power estimate >= 0.1) passes up to rho ~ 0.98-0.99 and must reject beyond."""
+the diagnostic counter (blsq_debug_gram_stats) shows which one ran.
+
+TRF: the gate looks at the system the step is solved from — the equilibrated H = D G D + E^2 of the
+Coleman-Li augmented Jacobian [J D; E] (trf.py:264-270), factored by Cholesky straight from the
+Gram; no triangle of J is formed for a problem that passes.  For an UNBOUNDED problem D = I, E = 0,
+H = J^T J: columns that all share a common component with cosine rho give sigma_min(R') =
+sqrt(1 - rho), and the gate (pivots and sigma_min estimate >= 0.1) passes up to rho ~ 0.98-0.99 and
+must reject beyond.  With bounds close to x the E^2 block dominates H and even a badly conditioned
+J is solved accurately through H — the routing tests therefore use unbounded problems, and
+`test_bounded_problems_are_gated_on_the_augmented_system` covers the other case.
+dogbox: the gate looks at the Gram of J itself (its free-column systems are principal sub-matrices)."""
 import numpy as np
 import pytest
 
@@ -88,7 +96,7 @@ def test_gate_around_its_threshold(bl, rho, n):
     (Measured: the fast path's step error stays below 3e-14 all the way to the gate.)"""
     from bounded_lsq import _synth
     B, m = 3, 2048
-    P = _synth.trf_batch(31, B, m, n)
+    P = _synth.trf_batch(31, B, m, n, unbounded=True)
     P["J"] = _equicorrelated(B, m, n, rho, 5)
     stats, worst = _check(bl, P, np.array([10.0, 0.5, 2.0]))
     if rho <= 0.9:
@@ -105,7 +113,7 @@ def test_logspaced_spectrum_across_the_gate(bl, kappa):
     values at once (the equicorrelated family has only one direction that matters)."""
     from bounded_lsq import _synth
     B, m, n = 3, 1200, 80
-    P = _synth.trf_batch(17, B, m, n)
+    P = _synth.trf_batch(17, B, m, n, unbounded=True)
     rng = np.random.default_rng(11)
     J = np.empty((B, m, n))
     for b in range(B):
@@ -139,7 +147,7 @@ def test_kahan_matrix_pivots_pass_but_sigma_min_does_not(bl, n, s_):
     assert np.min(np.abs(np.diag(np.linalg.qr(Kn)[1]))) > 0.1          # pivots of the unit-column matrix
     assert np.linalg.svd(Kn, compute_uv=False)[-1] < 0.02             # ... but a tiny sigma_min
     rng = np.random.default_rng(3)
-    P = _synth.trf_batch(23, B, m, n)
+    P = _synth.trf_batch(23, B, m, n, unbounded=True)
     J = np.empty((B, m, n))
     for b in range(B):
         Q, _ = np.linalg.qr(rng.standard_normal((m, n)))
@@ -152,7 +160,7 @@ def test_kahan_matrix_pivots_pass_but_sigma_min_does_not(bl, n, s_):
 def test_mixed_batch_splits_between_the_paths(bl):
     from bounded_lsq import _synth
     B, m, n = 8, 1024, 96
-    P = _synth.trf_batch(8, B, m, n)
+    P = _synth.trf_batch(8, B, m, n, unbounded=True)
     rho = np.where(np.arange(B) % 2 == 0, 0.3, 0.9999)
     P["J"] = _equicorrelated(B, m, n, rho, 3)
     stats, _ = _check(bl, P, np.full(B, 1.0))
@@ -165,7 +173,7 @@ def test_rank_deficient_zero_and_nonfinite_columns_go_to_the_tree(bl):
     rank-deficient fixtures is covered by the golden tests, which run with the front end on.)"""
     from bounded_lsq import _synth, _abi
     B, m, n = 4, 600, 40
-    P = _synth.trf_batch(4, B, m, n)
+    P = _synth.trf_batch(4, B, m, n, unbounded=True)
     P["J"][0][:, 7] = 0.0                               # zero column
     P["J"][1][:, 9] = P["J"][1][:, 3]                   # duplicate column
     P["J"][2][:, 11] = 2.0 * P["J"][2][:, 0] - P["J"][2][:, 5]   # dependent column
@@ -293,3 +301,18 @@ def test_static_tile_row_kernel_matches_the_generic_one_bit_for_bit(bl, monkeypa
         for o in outs[1:]:
             assert np.array_equal(outs[0][1], o[1])        # g = J^T f: the rhs column
             assert np.array_equal(outs[0][0], o[0])
+
+
+@pytest.mark.parametrize("rho", [0.99, 0.9999, 1 - 1e-8])
+def test_bounded_problems_are_gated_on_the_augmented_system(bl, rho):
+    """Bounds close to x: the Coleman-Li block E^2 = diag(g jv scale^2) dominates H = D G D + E^2
+    (D = diag(sqrt(v) scale), v = distance to the bound ~ 0.02), so H is well conditioned whatever
+    J is — the reference's own SVD sees the same augmented matrix.  Such problems stay on the
+    normal-equations path and still match the oracle to 1e-10 (asserted inside _check)."""
+    from bounded_lsq import _synth
+    B, m, n = 3, 2048, 64
+    P = _synth.trf_batch(33, B, m, n)
+    P["J"] = _equicorrelated(B, m, n, rho, 6)
+    stats, worst = _check(bl, P, np.array([10.0, 0.5, 2.0]))
+    assert stats == (B, 0), stats
+    assert worst < 1e-11

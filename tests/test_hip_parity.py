@@ -459,7 +459,7 @@ def test_correlated_panels_fast_path_and_fallback(bl, rho, fact_path):
         assert fast + slow > 0               #  problem may never reach the QR kernel at all)
         if rho <= 0.5:
             assert fast > 0                  # well conditioned panels take the fast path
-    if rho >= 1 - 1e-6:
+    if rho >= 1 - 1e-6 and (fact_path == "qr_tree_only" or fast + slow > 0):
         assert slow > 0                      # numerically dependent columns must not
     for b in range(B):
         _, So = orc.trf_step_solve(P["J"][b], P["f"][b], P["x"][b], P["lb"][b], P["ub"][b],
