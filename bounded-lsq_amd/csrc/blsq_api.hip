@@ -1282,7 +1282,7 @@ int dog_alloc_state(blsq_dogbox_plan* p) {
   } while (0)
   ALLOC(p->S, sizeof(double) * B * mat);
   ALLOC(p->X, sizeof(double) * B * mat);
-  ALLOC(p->vecs, sizeof(double) * vs * 9);
+  ALLOC(p->vecs, sizeof(double) * vs * 10);
   ALLOC(p->ivecs, sizeof(int) * (vs + B));
   ALLOC(p->scal2, sizeof(double) * (size_t)B * 4);
   ALLOC(p->sweeps, sizeof(int) * (size_t)B);
@@ -1309,6 +1309,7 @@ int dog_alloc_state(blsq_dogbox_plan* p) {
   st.S = p->S.as<double>(); st.X = p->X.as<double>();
   st.x = v; st.lb = v + vs; st.ub = v + 2 * vs; st.scale = v + 3 * vs; st.g = v + 4 * vs;
   st.s = v + 5 * vs; st.uf = v + 6 * vs; st.newton = v + 7 * vs; st.cauchy = v + 8 * vs;
+  st.scale_in = v + 9 * vs;
   st.on_bound = p->onb.as<long long>();
   st.free_idx = p->ivecs.as<int>(); st.ncols = p->ivecs.as<int>() + vs;
   st.srange = p->scal2.as<double>(); st.g_norm = p->scal2.as<double>() + 2 * (size_t)B;
@@ -1334,47 +1335,28 @@ int dog_put(blsq_dogbox_plan* p, const double* x, const double* lb, const double
   return 0;
 }
 
-int dog_after_triangle(blsq_dogbox_plan* p, int scale_mode) {
+// the free-column QR (Householder-path problems), rank gate + Newton step, SVD for the rest
+int dog_finish(blsq_dogbox_plan* p, const int* path, bool any_qr, bool any_gram) {
   blsq_ctx* ctx = p->ctx;
-  p->st.Rt = p->tree.Rfinal();
-  ctx->begin(K_PREP);
-  hipError_t e = launch_dog_prep(p->st, scale_mode, ctx->stream);
-  ctx->end();
-  if (e != hipSuccess) return ctx->fail(e, "launch_dog_prep");
-  // triangle of [R[:, free] | c]: for a problem on the Gram path it is the Cholesky factor of the
-  // principal sub-matrix G[free ++ rhs, free ++ rhs] (a principal sub-matrix of the equilibrated
-  // Gram is at least as well conditioned: no new gate); the others take the QR of the compacted
-  // columns.  Per problem, as in TRF.
-  const bool own = p->tree.gram && p->tree.path_valid;
-  const int* path = own ? p->tree.gram_path() : nullptr;
-  if (own && p->tree.any_gram) {
-    GramCholArgs c{};
-    c.Gsrc = p->tree.gram_keep.as<double>(); c.G = p->st.X; c.NPAD = p->ld; c.n = p->n;
-    c.ncols_dev = p->st.ncols; c.gather = p->st.free_idx; c.stride_vec = p->ld;
-    c.skip_path = path;
-    c.colinfo = p->colinfo.as<double>();
-    ctx->begin(K_AUG_CHOL);
-    e = launch_gram_chol(c, p->B, ctx->stream);
+  hipError_t e;
+  if (any_qr) {
+    QrArgs q = p->tree.base_args();
+    q.A = p->st.S; q.strideA = (long)p->ld * p->ld; q.ldA = p->ld; q.rowsA = p->n;
+    q.F = nullptr; q.strideF = 0; q.ncols_dev = p->st.ncols;
+    q.require_path = path;
+    q.rows_per_leaf = p->ld; q.RP = p->ld;
+    q.Rout = p->st.X;
+    ctx->begin(K_QR_AUG);
+    e = launch_qr(q, 1, p->B, ctx->stream);
     ctx->end();
-    if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(free block)");
-  }
-  if (!own || p->tree.any_qr) {
-  QrArgs q = p->tree.base_args();
-  q.A = p->st.S; q.strideA = (long)p->ld * p->ld; q.ldA = p->ld; q.rowsA = p->n;
-  q.F = nullptr; q.strideF = 0; q.ncols_dev = p->st.ncols;
-  q.require_path = path;
-  q.rows_per_leaf = p->ld; q.RP = p->ld;
-  q.Rout = p->st.X;
-  ctx->begin(K_QR_AUG);
-  e = launch_qr(q, 1, p->B, ctx->stream);
-  ctx->end();
-  if (e != hipSuccess) return ctx->fail(e, "launch_qr(free block)");
+    if (e != hipSuccess) return ctx->fail(e, "launch_qr(free block)");
   }
   int* gfast = p->gate_ints.as<int>();
   int* gmask = gfast + p->B;
+  p->st.fast = gfast;
   ctx->begin(K_LM_GATE);
   e = launch_dog_gate_solve(p->st, gfast, gmask, p->svdfree_enable, path,
-                            (own && p->tree.any_gram) ? p->colinfo.as<double>() : nullptr, ctx->stream);
+                            (path && any_gram) ? p->colinfo.as<double>() : nullptr, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_dog_gate_solve");
   JacobiArgs ja{};
@@ -1390,6 +1372,68 @@ int dog_after_triangle(blsq_dogbox_plan* p, int scale_mode) {
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_dog_solve");
   return 0;
+}
+
+// a triangle [R c] of [J f] for every problem (front end off)
+int dog_after_triangle(blsq_dogbox_plan* p, int scale_mode) {
+  blsq_ctx* ctx = p->ctx;
+  p->st.Rt = p->tree.Rfinal(); p->st.Gk = nullptr; p->st.path = nullptr;
+  p->tree.path_valid = false; p->tree.any_gram = false; p->tree.any_qr = true;
+  ctx->begin(K_PREP);
+  hipError_t e = launch_dog_prep(p->st, scale_mode, 0, nullptr, 0, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_dog_prep");
+  return dog_finish(p, nullptr, true, false);
+}
+
+// The whole factor call from device-resident [J f].  Normal-equations path (as TRF): g and the
+// column norms from the Gram, the triangle of [J[:, free] | f] as the Cholesky factor of the gathered
+// principal sub-matrix G[free ++ rhs, free ++ rhs], and the conditioning gate applied to THAT factor
+// — the system lstsq(J_free, -f) is solved from (dogbox.py:197).  No triangle of J is formed; a problem
+// the gate rejects goes through the Householder tree and is prepared again from its triangle.
+int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int ldJ, int scale_mode,
+                    const int* mask) {
+  blsq_ctx* ctx = p->ctx;
+  QrTree& t = p->tree;
+  int rc;
+  if (!t.gram) {
+    if ((rc = t.run_levels(ctx, dJ, df, ldJ, mask))) return rc;
+    return dog_after_triangle(p, scale_mode);
+  }
+  if ((rc = t.run_gram_only(ctx, dJ, df, ldJ, mask, false))) return rc;
+  HIPCHK(ctx, hipMemsetAsync(t.fb_count(), 0, sizeof(int), ctx->stream));
+  p->st.Rt = t.Rfinal(); p->st.Gk = t.gram_keep.as<double>(); p->st.path = t.path_rw();
+  ctx->begin(K_PREP);
+  hipError_t e = launch_dog_prep(p->st, scale_mode, 1, mask, 0, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_dog_prep(gram)");
+  GramCholArgs c{};
+  c.Gsrc = t.gram_keep.as<double>(); c.G = p->st.X; c.NPAD = p->ld; c.n = p->n;
+  c.ncols_dev = p->st.ncols; c.gather = p->st.free_idx; c.stride_vec = p->ld;
+  c.mask = mask; c.fb_mask = t.fb_mask(); c.fail_count = t.fb_count(); c.path_out = t.path_rw();
+  c.dsc = t.gram_dsc.as<double>();
+  c.colinfo = p->colinfo.as<double>();
+  ctx->begin(K_AUG_CHOL);
+  e = launch_gram_chol(c, p->B, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(free block)");
+  ctx->begin(K_GRAM_GATE);
+  e = launch_gram_gate(c, p->B, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_gram_gate");
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 1, t.fb_count(), sizeof(int), hipMemcpyDeviceToHost,
+                             ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const int nfb = ctx->pinned[1];
+  t.note_paths(ctx, nfb, mask != nullptr);
+  if (nfb > 0) {
+    if ((rc = t.run_levels(ctx, dJ, df, ldJ, t.fb_mask()))) return rc;
+    ctx->begin(K_PREP);
+    e = launch_dog_prep(p->st, scale_mode, 0, t.fb_mask(), 1, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_dog_prep(redo)");
+  }
+  return dog_finish(p, t.path_rw(), t.any_qr, t.any_gram);
 }
 
 }  // namespace
@@ -1440,8 +1484,7 @@ extern "C" int blsq_dogbox_factor_dev(blsq_dogbox_plan* p, const double* dJ, con
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc = dog_put(p, dx, dlb, dub, dscale_io, don_bound, hipMemcpyDeviceToDevice);
   if (rc) return rc;
-  if ((rc = p->tree.run(ctx, dJ, df, p->n))) return rc;
-  if ((rc = dog_after_triangle(p, scale_mode))) return rc;
+  if ((rc = dog_factor_core(p, dJ, df, p->n, scale_mode, nullptr))) return rc;
   if (scale_mode != BLSQ_SCALE_GIVEN) {
     HIPCHK(ctx, hipMemcpy2DAsync(dscale_io, sizeof(double) * p->n, p->st.scale,
                                  sizeof(double) * p->ld, sizeof(double) * p->n, p->B,
@@ -1559,8 +1602,8 @@ extern "C" int blsq_dogbox_factor(blsq_dogbox_plan* p, const double* J, const do
   HIPCHK(ctx, hipMemcpyAsync(p->in_f.p, f, fb, hipMemcpyHostToDevice, ctx->stream));
   int rc = dog_put(p, x, lb, ub, scale_io, on_bound, hipMemcpyHostToDevice);
   if (rc) return rc;
-  if ((rc = p->tree.run(ctx, p->in_J.as<double>(), p->in_f.as<double>(), p->n))) return rc;
-  if ((rc = dog_after_triangle(p, scale_mode))) return rc;
+  if ((rc = dog_factor_core(p, p->in_J.as<double>(), p->in_f.as<double>(), p->n, scale_mode, nullptr)))
+    return rc;
   return blsq_dogbox_fetch_factor(p, g, active_set, g_norm, all_active,
                                   scale_mode != BLSQ_SCALE_GIVEN ? scale_io : nullptr, nullptr,
                                   nullptr);
@@ -1708,15 +1751,12 @@ extern "C" int blsq_outer_start(blsq_outer* o, const double* x0, const double* x
 namespace {
 // factor the problems selected by `mask` (nullptr: all) from the driver's J / f buffers
 int outer_factor(blsq_outer* o, int scale_mode, const int* mask) {
-  blsq_ctx* ctx = o->ctx;
-  int rc;
   if (o->method == 0) {
     blsq_trf_plan* p = o->trf;
     return trf_factor_core(p, o->J.as<double>(), o->st.f, p->n, scale_mode, mask);
   }
   blsq_dogbox_plan* p = o->dog;
-  if ((rc = p->tree.run(ctx, o->J.as<double>(), o->st.f, p->n, mask))) return rc;
-  return dog_after_triangle(p, scale_mode);
+  return dog_factor_core(p, o->J.as<double>(), o->st.f, p->n, scale_mode, mask);
 }
 }  // namespace
 

@@ -184,6 +184,12 @@ hipError_t launch_lm_update(const LmState& lm, int active, hipStream_t s);   // 
 // -------------------------------------------------------------- dogbox ----
 struct DogState {
   int B, m, n, ld;
+  // normal-equations path (as TrfState): g and the column norms from the Gram, the free-column
+  // factor X from its gathered principal sub-matrix; (J_free a).(J_free b) = (X a).(X b)
+  const double* Gk;       // [B][ld*ld] Grams or nullptr
+  const int* path;        // [B] 0: normal-equations path, != 0: Householder; nullptr: Householder for all
+  const int* fast;        // [B] 1: X is still the triangle (Newton step solved without the SVD), 0: Jacobi rows
+  double* scale_in;       // [B][ld]
   const double* Rt;       // [B][ld*ld]
   double* S;              // [B][ld*ld]   R~[:, free ++ rhs], compacted columns
   double* X;              // [B][ld*ld]   its triangle, then Jacobi rows
@@ -197,7 +203,10 @@ struct DogState {
   double *g_norm;                         // [B]
   unsigned char* active;                  // [B][ld]
 };
-hipError_t launch_dog_prep(const DogState& st, int jac_scaling, hipStream_t s);
+// from_gram / sel / redo: as launch_trf_prep (a Gram-path problem gets neither the compacted
+// columns S nor — yet — its Cauchy step: that comes from X in dog_gate_solve)
+hipError_t launch_dog_prep(const DogState& st, int jac_scaling, int from_gram, const int* sel,
+                           int redo, hipStream_t s);
 hipError_t launch_dog_solve(const DogState& st, const int* skip, hipStream_t s);
 // path / colinfo (optional): Gram-path flags and the column-norm summary of the free block
 hipError_t launch_dog_gate_solve(const DogState& st, int* fast, int* ncols_jac, int enable,

@@ -31,21 +31,41 @@ __device__ static void tri_matvec_d(const double* R, int n, int ld, const double
   __syncthreads();
 }
 
+// u = M s for a dense nf x nf block (Jacobi rows of a factor that went through the SVD)
+__device__ static void full_matvec_d(const double* M, int n, int ld, const double* svec, double* u) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int i = w; i < n; i += DG_NW) {
+    const double* row = M + (long)i * ld;
+    double acc = 0.0;
+    for (int j = lane; j < n; j += WAVE) acc = fma(row[j], svec[j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) u[i] = acc;
+  }
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------ prep --
-__global__ __launch_bounds__(DG_NT) void dog_prep_kernel(DogState st, int jac_scaling) {
+__global__ __launch_bounds__(DG_NT) void dog_prep_kernel(DogState st, int jac_scaling, int from_gram,
+                                                         const int* sel, int redo) {
   extern __shared__ double sh[];
   __shared__ double red[32];
   __shared__ int nfree_s;
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (sel && sel[b] <= 1) return;
   const int n = st.n, ld = st.ld;
   const long vo = (long)b * ld;
   const double* Rt = st.Rt + (long)b * ld * ld;
+  const double* Gk = from_gram ? st.Gk + (long)b * ld * ld : nullptr;
   double* S = st.S + (long)b * ld * ld;
   double* gm = sh;              // g masked to the free set (full length)
   double* u = gm + ld;
 
   for (int j = tid; j < n; j += DG_NT) {
     double gj = 0.0, nn = 0.0;
+    if (from_gram) {                          // g = J^T f and ||J_j||^2 straight from the Gram
+      gj = Gk[(long)j * ld + n];
+      nn = Gk[(long)j * ld + j];
+    } else {
     for (int i0 = 0; i0 <= j; i0 += 8) {      // 8 rows per pass, loads unconditional (clamped)
       double rv[8], cv[8];
 #pragma unroll
@@ -62,7 +82,9 @@ __global__ __launch_bounds__(DG_NT) void dog_prep_kernel(DogState st, int jac_sc
         }
       }
     }
-    double sc = st.scale[vo + j];
+    }
+    double sc = redo ? st.scale_in[vo + j] : st.scale[vo + j];
+    if (!redo) st.scale_in[vo + j] = sc;
     if (jac_scaling == 1) {                                  // dogbox.py:141-144
       double jn = sqrt(nn);
       if (jn == 0.0) jn = 1.0;
@@ -92,6 +114,7 @@ __global__ __launch_bounds__(DG_NT) void dog_prep_kernel(DogState st, int jac_sc
   gmax = block_max(gmax, red);
   if (tid == 0) st.g_norm[b] = (nf > 0) ? gmax : 0.0;        // dogbox.py:182-188
   if (nf == 0) return;
+  if (from_gram) return;        // the free-column system comes from the gathered Gram, the Cauchy step from X
 
   // compacted  [R[:, free] | c]  (dogbox.py:175 on the triangle)
   const int N = nf + 1;
@@ -110,9 +133,11 @@ __global__ __launch_bounds__(DG_NT) void dog_prep_kernel(DogState st, int jac_sc
   for (int q = tid; q < nf; q += DG_NT) st.cauchy[vo + q] = fac * gm[st.free_idx[vo + q]];
 }
 
-hipError_t launch_dog_prep(const DogState& st, int jac_scaling, hipStream_t s) {
+hipError_t launch_dog_prep(const DogState& st, int jac_scaling, int from_gram, const int* sel,
+                           int redo, hipStream_t s) {
   const size_t lds = sizeof(double) * 2 * (size_t)st.ld;
-  hipLaunchKernelGGL(dog_prep_kernel, dim3(st.B), dim3(DG_NT), lds, s, st, jac_scaling);
+  hipLaunchKernelGGL(dog_prep_kernel, dim3(st.B), dim3(DG_NT), lds, s, st, jac_scaling, from_gram,
+                     sel, redo);
   return hipGetLastError();
 }
 
@@ -266,14 +291,24 @@ __global__ __launch_bounds__(DG_NT) void dog_step_kernel(DogState st, const doub
     return 0;
   };
 
-  // predicted reduction (dogbox.py:208-209)
-  for (int j = tid; j < n; j += DG_NT) full[j] = 0.0;
-  __syncthreads();
-  for (int q = tid; q < nf; q += DG_NT) full[fidx[q]] = stp[q];
-  __syncthreads();
-  tri_matvec_d(Rt, n, ld, full, u);
+  // predicted reduction (dogbox.py:208-209):  Js.Js and Js.f
+  const bool gp = st.path && st.path[b] == 0;
   double uu = 0.0, uc = 0.0;
-  for (int i = tid; i < n; i += DG_NT) { uu += u[i] * u[i]; uc += u[i] * Rt[(long)i * ld + n]; }
+  if (gp) {
+    // normal-equations path: |J_free s|^2 = |X s|^2 (X: triangle of the free columns, or its Jacobi
+    // rows), Js.f = s.g
+    const double* Xf = st.X + (long)b * ld * ld;
+    if (st.fast && st.fast[b]) tri_matvec_d(Xf, nf, ld, stp, u);
+    else full_matvec_d(Xf, nf, ld, stp, u);
+    for (int q = tid; q < nf; q += DG_NT) { uu += u[q] * u[q]; uc += stp[q] * st.g[vo + fidx[q]]; }
+  } else {
+    for (int j = tid; j < n; j += DG_NT) full[j] = 0.0;
+    __syncthreads();
+    for (int q = tid; q < nf; q += DG_NT) full[fidx[q]] = stp[q];
+    __syncthreads();
+    tri_matvec_d(Rt, n, ld, full, u);
+    for (int i = tid; i < n; i += DG_NT) { uu += u[i] * u[i]; uc += u[i] * Rt[(long)i * ld + n]; }
+  }
   uu = block_sum(uu, red);
   uc = block_sum(uc, red);
   const double pred = -uu - 2.0 * uc;

@@ -605,7 +605,10 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
   if (a.skip_path && a.skip_path[b] != 0) return;
   // columns of this problem: all n (+ rhs), or the gathered free columns (+ rhs)
   const int N = a.ncols_dev ? a.ncols_dev[b] : a.n + 1;
-  if (N <= 1) return;
+  if (N <= 1) {                                         // (dogbox: every variable active — nothing to factor)
+    if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
+    return;
+  }
   const int n = N - 1;
   const int NT = (N + 15) / 16;
   const int* gidx = a.gather ? a.gather + (long)b * a.stride_vec : nullptr;
@@ -660,8 +663,8 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
   psync();
   if (bad) {                                            // uniform: hand the problem to the QR tree
     if (tid == 0 && a.fb_mask) {
-      a.fb_mask[b] = N; atomicAdd(a.fail_count, 1);
-      if (a.path_out) a.path_out[b] = N;
+      a.fb_mask[b] = a.n + 1; atomicAdd(a.fail_count, 1);   // (the tree factors ALL n + 1 columns)
+      if (a.path_out) a.path_out[b] = a.n + 1;
     }
     return;
   }
@@ -785,8 +788,8 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
   }
   if (tid == 0 && a.fb_mask) {
     const bool fail = !(pminsh >= GRAM_SMIN * GRAM_SMIN);
-    a.fb_mask[b] = fail ? N : 0;
-    if (a.path_out) a.path_out[b] = fail ? N : 0;
+    a.fb_mask[b] = fail ? a.n + 1 : 0;
+    if (a.path_out) a.path_out[b] = fail ? a.n + 1 : 0;
     if (fail) atomicAdd(a.fail_count, 1);
   }
 }
@@ -817,7 +820,10 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
   }
   if (a.skip_path && a.skip_path[b] != 0) return;
   const int N = a.ncols_dev ? a.ncols_dev[b] : a.n + 1;
-  if (N <= 1) return;
+  if (N <= 1) {                                         // (dogbox: every variable active — nothing to factor)
+    if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
+    return;
+  }
   const int n = N - 1;
   const int NT = (N + 15) / 16;
   const int* gidx = a.gather ? a.gather + (long)b * a.stride_vec : nullptr;
@@ -866,8 +872,8 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
   __syncthreads();
   if (bad) {
     if (tid == 0 && a.fb_mask) {
-      a.fb_mask[b] = N; atomicAdd(a.fail_count, 1);
-      if (a.path_out) a.path_out[b] = N;
+      a.fb_mask[b] = a.n + 1; atomicAdd(a.fail_count, 1);   // (the tree factors ALL n + 1 columns)
+      if (a.path_out) a.path_out[b] = a.n + 1;
     }
     return;
   }
@@ -1033,8 +1039,8 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
   __syncthreads();
   if (tid == 0 && a.fb_mask) {
     const bool fail = !(pminsh >= GRAM_SMIN * GRAM_SMIN);
-    a.fb_mask[b] = fail ? N : 0;
-    if (a.path_out) a.path_out[b] = fail ? N : 0;
+    a.fb_mask[b] = fail ? a.n + 1 : 0;
+    if (a.path_out) a.path_out[b] = fail ? a.n + 1 : 0;
     if (fail) atomicAdd(a.fail_count, 1);
   }
 }
@@ -1046,7 +1052,8 @@ __global__ __launch_bounds__(TRI_NT) void gram_gate_kernel(GramCholArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x;
   if (a.mask && a.mask[b] <= 1) return;
   if (a.fb_mask[b] != 0) return;                        // already failed on a pivot
-  const int n = a.n, ld = a.NPAD;
+  const int n = a.ncols_dev ? a.ncols_dev[b] - 1 : a.n, ld = a.NPAD;
+  if (n <= 0) return;
   const double* R = a.G + (long)b * ld * ld;
   const double* d = a.dsc + (long)b * ld;
   double* v = sh;
@@ -1072,8 +1079,8 @@ __global__ __launch_bounds__(TRI_NT) void gram_gate_kernel(GramCholArgs a) {
     __syncthreads();
   }
   if (tid == 0 && !(smin >= GRAM_SMIN)) {
-    a.fb_mask[b] = n + 1;
-    if (a.path_out) a.path_out[b] = n + 1;
+    a.fb_mask[b] = a.n + 1;
+    if (a.path_out) a.path_out[b] = a.n + 1;
     atomicAdd(a.fail_count, 1);
   }
 }
@@ -1089,7 +1096,8 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_gate_wave_kernel(GramCholArgs a
   const int b = pidx;
   if (a.mask && a.mask[b] <= 1) return;
   if (a.fb_mask[b] != 0) return;
-  const int n = a.n, ld = a.NPAD;
+  const int n = a.ncols_dev ? a.ncols_dev[b] - 1 : a.n, ld = a.NPAD;
+  if (n <= 0) return;
   const double* R = a.G + (long)b * ld * ld;
   const int li = lane < n ? lane : n - 1;
   const double dsc = a.dsc[(long)b * ld + li];
@@ -1157,8 +1165,8 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_gate_wave_kernel(GramCholArgs a
     v *= inv;
   }
   if (lane == 0 && !(smin >= GRAM_SMIN)) {
-    a.fb_mask[b] = n + 1;
-    if (a.path_out) a.path_out[b] = n + 1;
+    a.fb_mask[b] = a.n + 1;
+    if (a.path_out) a.path_out[b] = a.n + 1;
     atomicAdd(a.fail_count, 1);
   }
 }

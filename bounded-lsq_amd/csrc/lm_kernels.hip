@@ -329,6 +329,19 @@ __global__ __launch_bounds__(TRI_NT) void dog_gate_solve_kernel(DogState st, int
   double* u = v + ld;
   double* invd = u + ld;
   double* pfbuf = invd + ld;                 // 2 x 16 x ld doubles: DMA staging of the solves
+  if (path && path[b] == 0) {
+    // normal-equations path: the Cauchy step (dogbox.py:198-199), -(g.g)/(Jg.Jg) g_free with
+    // |J_free g_free|^2 = |X g_free|^2 — the Householder path computed it in dog_prep from R
+    const int* fidx = st.free_idx + (long)b * ld;
+    for (int q = tid; q < nf; q += TRI_NT) v[q] = st.g[(long)b * ld + fidx[q]];
+    __syncthreads();
+    tri_mv(R, nf, ld, v, u);
+    const double gg = tri_dot(v, v, nf, red);
+    const double uu = tri_dot(u, u, nf, red);
+    const double fac = -gg / uu;
+    for (int q = tid; q < nf; q += TRI_NT) st.cauchy[(long)b * ld + q] = fac * v[q];
+    __syncthreads();
+  }
   int ok = (enable != 0) && (st.m >= nf);
   int bad = 0;
   for (int i = tid; i < nf; i += TRI_NT) {

@@ -11,7 +11,8 @@ sqrt(1 - rho), and the gate (pivots and sigma_min estimate >= 0.1) passes up to 
 must reject beyond.  With bounds close to x the E^2 block dominates H and even a badly conditioned
 J is solved accurately through H — the routing tests therefore use unbounded problems, and
 `test_bounded_problems_are_gated_on_the_augmented_system` covers the other case.
-dogbox: the gate looks at the Gram of J itself (its free-column systems are principal sub-matrices)."""
+dogbox: likewise the gate looks at the factor of the free-column system [J[:, free] | f]
+(dogbox.py:197), the Cholesky factor of the gathered principal sub-matrix of the Gram."""
 import numpy as np
 import pytest
 
