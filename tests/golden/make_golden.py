@@ -20,6 +20,10 @@ What is captured
                  dogbox.py:170-220 rather than a re-composition of them)
   e2e.json       end-to-end records (nfev, njev, status, x, ...) of the public
                  drivers on bounded Rosenbrock + a few small fitting problems
+  suite58.json   the reference's OWN benchmark problem set (benchmarks/lsq_problems.py:1003-1018; 57 of
+                 its 58 problems, families restated in tests/_suite58.py): per problem the start
+                 point and box of the reference's factory (data) and what its public drivers return;
+                 `python make_golden.py suite58` rebuilds it alone
   suite.json     the same for the 12-problem suite of tests/_suite.py (unbounded and
                  bounded variants, both methods, numeric and 'jac' scaling, and the public
                  front end with jac='2-point');  `python make_golden.py suite` rebuilds it alone
@@ -657,9 +661,99 @@ def make_suite():
         json.dump(dict(tol=tol.hex(), records=recs), fh, indent=0)
 
 
+def make_suite58():
+    """The reference's own 58-problem benchmark set, end to end.
+
+    The reference's benchmark module is imported HERE ONLY (build container) for two things that are
+    data, not code: (1) the start point and box of every problem of its factories, and (2) its own
+    residuals / Jacobians at a few points, against which the families restated in tests/_suite58.py
+    are checked (<= 1e-11) before anything is recorded.  The drivers then run on the RESTATED
+    functions — the ones the GPU tests will call."""
+    sys.path.insert(0, "/root/reference/benchmarks")
+    import lsq_problems as ref_problems          # noqa: E402  (THE REFERENCE's problem factories)
+    import _suite58
+    inf = np.inf
+    tol = float(np.finfo(float).eps ** 0.5)
+    unb, bnd = ref_problems.extract_lsq_problems()
+    rng = np.random.default_rng(58)
+    recs, problems, skipped = [], [], []
+    for name, rp in unb + bnd:
+        fam = _suite58.family_of(name)
+        if fam not in _suite58.FAMILIES:
+            skipped.append(name)
+            print("suite58", name, "NOT RESTATED:", _suite58.NOT_RESTATED.get(fam, "?"))
+            continue
+        fun, jac = _suite58.FAMILIES[fam]()
+        x0 = np.asarray(rp.x0, float)
+        n = x0.size
+        lb = np.full(n, -inf) if rp.bounds[0] is None else np.resize(np.asarray(rp.bounds[0], float), n)
+        ub = np.full(n, inf) if rp.bounds[1] is None else np.resize(np.asarray(rp.bounds[1], float), n)
+        # the restated family IS the reference's problem: same residuals and Jacobian
+        for trial in range(4):
+            x = x0 if trial == 0 else x0 * (1 + 0.05 * rng.standard_normal(n)) + 0.01 * rng.standard_normal(n)
+            fr, Jr = np.atleast_1d(rp.fun(x)), np.atleast_2d(rp.jac(x))
+            fm, Jm = fun(x), jac(x)
+            assert fr.shape == fm.shape and Jr.shape == Jm.shape, name
+            assert np.abs(fr - fm).max() <= 1e-11 * max(1.0, np.abs(fr).max()), name
+            assert np.abs(Jr - Jm).max() <= 1e-11 * max(1.0, np.abs(Jr).max()), name
+        m = fun(x0).size
+        problems.append(dict(name=name, family=fam, n=n, m=m, bounded=bool("_B" in name),
+                             x0=[float(v).hex() for v in x0], lb=[float(v).hex() for v in lb],
+                             ub=[float(v).hex() for v in ub]))
+
+        def fw(x, fun=fun):
+            return np.atleast_1d(fun(x))
+
+        def jw(x, f, jac=jac):
+            return np.atleast_2d(jac(x))
+        for method in ("trf", "dogbox"):
+            for scaling in (1.0, "jac"):
+                drv = ref.trf if method == "trf" else ref.dogbox
+                with np.errstate(all="ignore"):
+                    try:
+                        r = drv(fw, jw, x0.copy(), lb, ub, tol, tol, tol, None, shim(scaling, n))
+                    except Exception as exc:           # noqa: BLE001  the reference's own failure
+                        recs.append(dict(problem=name, method=method, scaling=scaling,
+                                         error=type(exc).__name__ + ": " + str(exc)[:120]))
+                        print("suite58 %-26s %-7s %-4s REFERENCE RAISES %s" % (
+                            name, method, scaling, recs[-1]["error"]))
+                        continue
+                    neigh = []
+                    for j, direction in ((0, inf), (0, -inf), (n - 1, inf), (n - 1, -inf)):
+                        xp = x0.copy()
+                        xp[j] = np.nextafter(xp[j], direction)
+                        if np.any(xp < lb) or np.any(xp > ub):
+                            continue
+                        try:
+                            rn = drv(fw, jw, xp, lb, ub, tol, tol, tol, None, shim(scaling, n))
+                        except Exception:              # noqa: BLE001
+                            neigh.append(dict(nfev=-1, njev=-1, status=-99, obj_value=float("nan").hex()))
+                            continue
+                        neigh.append(dict(nfev=int(rn.nfev), njev=int(rn.njev), status=int(rn.status),
+                                          obj_value=float(rn.obj_value).hex()))
+                stable = all((q["nfev"], q["njev"], q["status"]) ==
+                             (int(r.nfev), int(r.njev), int(r.status)) for q in neigh)
+                recs.append(dict(
+                    problem=name, method=method, scaling=scaling, nfev=int(r.nfev), njev=int(r.njev),
+                    status=int(r.status), x=[float(v).hex() for v in r.x],
+                    obj_value=float(r.obj_value).hex(), optimality=float(r.optimality).hex(),
+                    active_mask=[int(v) for v in r.active_mask], stable=bool(stable),
+                    neighbours=neigh))
+                print("suite58 %-26s %-7s %-4s nfev %4d status %d obj %.3e %s" % (
+                    name, method, scaling, r.nfev, r.status, r.obj_value,
+                    "" if stable else "UNSTABLE under 1-ulp start perturbations"))
+    with open(os.path.join(HERE, "suite58.json"), "w") as fh:
+        json.dump(dict(tol=tol.hex(), problems=problems, records=recs, not_restated=skipped,
+                       reference_problem_count=len(unb) + len(bnd)), fh, indent=0)
+    print("suite58: %d problems, %d records, not restated: %s" % (len(problems), len(recs), skipped))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dogfb":
         make_dog_fallback()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "suite58":
+        make_suite58()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "suite":
         make_suite()
@@ -673,4 +767,5 @@ if __name__ == "__main__":
     make_first_iter()
     make_e2e()
     make_suite()
+    make_suite58()
     print("golden fixtures written to", HERE)

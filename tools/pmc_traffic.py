@@ -32,7 +32,7 @@ def slot_of(kernel):
     """bench.py timing slot of a kernel name (the dominant ones only)."""
     if kernel is None:
         return None
-    if "gram_kernel" in kernel:
+    if "gram_kernel" in kernel or "gram16_kernel" in kernel:
         return "gram"
     if "qr_panel_kernel<8, false>" in kernel:
         return "qr_leaf"
@@ -41,6 +41,7 @@ def slot_of(kernel):
 
 def main():
     fdir, wdir, outp, m, n, B = sys.argv[1:7]
+    tag = sys.argv[7] if len(sys.argv) > 7 else os.path.basename(outp).split("_")[0]
     fetch, write = collect(fdir, "FETCH_SIZE"), collect(wdir, "WRITE_SIZE")
     kernels = {}
     for name in sorted(set(fetch) | set(write)):
@@ -52,6 +53,7 @@ def main():
                          "hbm_bytes": hbm, "hbm_bytes_per_launch": hbm / launches}
     dom = max(kernels, key=lambda k: kernels[k]["hbm_bytes"]) if kernels else None
     doc = {
+        "tag": tag,
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --steps 1 "
                    "--warmup 0 --no-cpu --check 0  (separate passes)",
         "units": "KB as reported by rocprofv3; summed over the launches of one step",
