@@ -47,6 +47,8 @@ SIGNATURES = {
     "blsq_debug_qr_stamps": (C.c_int, [vp]),
     "blsq_trf_debug_fast": (C.c_int, [vp, vp]),
     "blsq_trf_debug_sweeps": (C.c_int, [vp, vp]),
+    "blsq_trf_debug_cond": (C.c_int, [vp, vp]),
+    "blsq_dogbox_debug_cond": (C.c_int, [vp, vp]),
     "blsq_dogbox_plan_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "blsq_dogbox_plan_destroy": (C.c_int, [vp]),
     "blsq_dogbox_factor": (C.c_int, [vp] + [vp] * 6 + [C.c_int] + [vp] * 5),

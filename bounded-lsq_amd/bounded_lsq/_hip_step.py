@@ -137,6 +137,12 @@ class TrfStepSolver:
         self.ctx.check(self.lib.blsq_trf_debug_fast(self.h, ptr(fl)), "blsq_trf_debug_fast")
         return fl
 
+    def debug_cond(self):
+        """Proven bound K2 >= kappa_2 of the equilibrated system of the last factor call (0: none)."""
+        k2 = np.empty(self.B)
+        self.ctx.check(self.lib.blsq_trf_debug_cond(self.h, ptr(k2)), "blsq_trf_debug_cond")
+        return k2
+
     def debug_sweeps(self):
         sw = np.empty(self.B, np.int32)
         self.ctx.check(self.lib.blsq_trf_debug_sweeps(self.h, ptr(sw)), "blsq_trf_debug_sweeps")
@@ -205,6 +211,11 @@ class DogboxStepSolver:
             self.h, ptr(Delta), ptr(step), ptr(x_new), ptr(obn), ptr(tr_hit), ptr(pred),
             ptr(ssn), ptr(fb), ptr(status)), "blsq_dogbox_step")
         return DogStepOut(step, x_new, obn, tr_hit, pred, ssn, fb, status)
+
+    def debug_cond(self):
+        k2 = np.empty(self.B)
+        self.ctx.check(self.lib.blsq_dogbox_debug_cond(self.h, ptr(k2)), "blsq_dogbox_debug_cond")
+        return k2
 
     def factor_dev(self, dJ, df, dx, dlb, dub, dscale, don_bound, scale_mode=SCALE_GIVEN):
         self.ctx.check(self.lib.blsq_dogbox_factor_dev(self.h, dJ, df, dx, dlb, dub, dscale,

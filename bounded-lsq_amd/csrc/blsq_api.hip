@@ -185,6 +185,7 @@ struct QrTree {
   DevBuf gram_part, gram_dsc, gram_ints;   // partial Grams, column scales, [B] fallback mask + count
   DevBuf gram_keep;                 // [B][NPAD*NPAD] the Grams themselves (kept: the trust-region
                                     // systems are diagonal modifications of them)
+  DevBuf gram_rinv, gram_ywork, gram_k2;   // conditioning certificate: inverse diagonal tiles, Y = R'^-T, bound [B]
   // per-problem path of the CURRENT triangles: gram_path()[b] = n + 1 (Householder tree) or 0 (Gram).
   // any_gram / any_qr: whether a problem of either kind can exist (host-side upper bounds)
   bool any_gram = false, any_qr = true;
@@ -246,6 +247,14 @@ struct QrTree {
       if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Gram scales)");
       e = gram_keep.alloc(sizeof(double) * (size_t)B * NPAD * NPAD);
       if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Grams)");
+      e = gram_rinv.alloc(sizeof(double) * (size_t)B * NP * 256);
+      if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Gram tile inverses)");
+      e = gram_ywork.alloc(sizeof(double) * (size_t)B * NPAD * NPAD);
+      if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Gram gate work)");
+      e = gram_k2.alloc(sizeof(double) * (size_t)B);
+      if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Gram gate bound)");
+      e = hipMemsetAsync(gram_k2.p, 0, gram_k2.bytes, ctx->stream);
+      if (e != hipSuccess) return ctx->fail(e, "hipMemsetAsync(Gram gate bound)");
       e = gram_ints.alloc(sizeof(int) * (2 * (size_t)B + 4));     // launch mask, count, path
       if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Gram mask)");
       e = hipMemsetAsync(gram_keep.p, 0, gram_keep.bytes, ctx->stream);      // (lower tiles are never written)
@@ -259,6 +268,7 @@ struct QrTree {
     for (auto& L : levels) L.R.release();
     V.release(); T.release();
     gram_part.release(); gram_dsc.release(); gram_ints.release(); gram_keep.release();
+    gram_rinv.release(); gram_ywork.release(); gram_k2.release();
   }
   // [J f] -> triangle by the normal equations where the conditioning gate allows it.
   // Returns the number of problems left for the Householder tree in *nfallback; their indices
@@ -290,6 +300,7 @@ struct QrTree {
     c.Gsrc = Gk; c.G = Rf; c.NPAD = NPAD; c.n = n; c.mask = mask; c.fb_mask = fb; c.fail_count = cnt;
     c.path_out = fb + B + 4;
     c.dsc = gram_dsc.as<double>();
+    c.rinv = gram_rinv.as<double>(); c.ywork = gram_ywork.as<double>(); c.k2_out = gram_k2.as<double>();
     ctx->begin(K_GRAM_CHOL);
     e = launch_gram_chol(c, B, ctx->stream);
     ctx->end();
@@ -787,6 +798,7 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb) 
   c.colscale = p->st.d; c.diag_vec = p->st.ediag; c.stride_vec = p->ld;
   c.mask = mask; c.fb_mask = t.fb_mask(); c.fail_count = t.fb_count(); c.path_out = t.path_rw();
   c.dsc = t.gram_dsc.as<double>();
+  c.rinv = t.gram_rinv.as<double>(); c.ywork = t.gram_ywork.as<double>(); c.k2_out = t.gram_k2.as<double>();
   c.colinfo = p->aug_colinfo.as<double>();
   ctx->begin(K_AUG_CHOL);
   e = launch_gram_chol(c, p->B, ctx->stream);
@@ -1004,6 +1016,16 @@ extern "C" int blsq_trf_debug_fast(blsq_trf_plan* p, int32_t* fast) {
   blsq_ctx* ctx = p->ctx;
   if (!fast) return ctx->bad(2, "fast is NULL");
   HIPCHK(ctx, hipMemcpyAsync(fast, p->lm.fast, sizeof(int) * p->B, hipMemcpyDeviceToHost,
+                             ctx->stream));
+  return blsq_sync(ctx);
+}
+
+extern "C" int blsq_trf_debug_cond(blsq_trf_plan* p, double* k2) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!k2) return ctx->bad(2, "k2 is NULL");
+  if (!p->tree.gram) { for (int b = 0; b < p->B; ++b) k2[b] = 0.0; return 0; }
+  HIPCHK(ctx, hipMemcpyAsync(k2, p->tree.gram_k2.p, sizeof(double) * p->B, hipMemcpyDeviceToHost,
                              ctx->stream));
   return blsq_sync(ctx);
 }
@@ -1412,6 +1434,7 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
   c.ncols_dev = p->st.ncols; c.gather = p->st.free_idx; c.stride_vec = p->ld;
   c.mask = mask; c.fb_mask = t.fb_mask(); c.fail_count = t.fb_count(); c.path_out = t.path_rw();
   c.dsc = t.gram_dsc.as<double>();
+  c.rinv = t.gram_rinv.as<double>(); c.ywork = t.gram_ywork.as<double>(); c.k2_out = t.gram_k2.as<double>();
   c.colinfo = p->colinfo.as<double>();
   ctx->begin(K_AUG_CHOL);
   e = launch_gram_chol(c, p->B, ctx->stream);
@@ -1546,6 +1569,16 @@ extern "C" int blsq_dogbox_fetch_factor(blsq_dogbox_plan* p, double* g, uint8_t*
     }
   }
   return 0;
+}
+
+extern "C" int blsq_dogbox_debug_cond(blsq_dogbox_plan* p, double* k2) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!k2) return ctx->bad(2, "k2 is NULL");
+  if (!p->tree.gram) { for (int b = 0; b < p->B; ++b) k2[b] = 0.0; return 0; }
+  HIPCHK(ctx, hipMemcpyAsync(k2, p->tree.gram_k2.p, sizeof(double) * p->B, hipMemcpyDeviceToHost,
+                             ctx->stream));
+  return blsq_sync(ctx);
 }
 
 extern "C" int blsq_dogbox_fetch_step(blsq_dogbox_plan* p, double* step, double* x_new,

@@ -87,7 +87,16 @@ struct GramCholArgs {
   int* fail_count;        // [1] number of such problems (caller zeroes it)
   double* dsc;            // optional [B][NPAD] out: column scales 1 / ||J_j||
   double* colinfo;        // optional [B][2] out: min_j sqrt(h_jj), sum_j h_jj over the first n columns
+  double* rinv;           // optional [B][NPAD/16][256] out: inverses of the diagonal tiles of R' (row-major)
+  // conditioning certificate (launch_gram_gate)
+  double* ywork;          // [B][NPAD*NPAD] scratch: Y = R'^-T
+  double* k2_out;         // optional [B] out: the proven bound on kappa_2 of the equilibrated system
 };
+// A problem stays on the normal-equations path only if the PROVEN bound K2 >= kappa_2(R'^T R') of its
+// equilibrated system is at most GRAM_K2_MAX (gram_kernels.hip, gram_cond_kernel).  Consequence used
+// by the rank gates: lambda_max >= 1 (unit diagonal), so sigma_min(R') >= 1 / sqrt(GRAM_K2_MAX).
+constexpr double GRAM_K2_MAX = 2.5e5;
+constexpr double GRAM_SMIN_PROVEN = 2.0e-3;         // = 1 / sqrt(GRAM_K2_MAX)
 bool gram_supported(int m, int n);
 int gram_chunks(int B, int m);
 hipError_t launch_gram(const GramArgs& a, int chunks, int B, hipStream_t s);

@@ -10,9 +10,10 @@
 //
 // Half the flops of Householder QR, no reflector traffic, no per-panel latency chain — but the
 // error of R grows with kappa(J D)^2 instead of kappa(J D).  The path is therefore GATED per
-// problem: every Cholesky pivot of the equilibrated Gram and an inverse-power estimate of
-// sigma_min(R') must clear GRAM_SMIN (kappa(J D) <= sqrt(n) / GRAM_SMIN), otherwise the problem is
-// handed to the Householder tree (QrTree::run) through a launch mask, exactly as before.
+// problem by a PROVEN upper bound on the condition number of the equilibrated system that is
+// actually solved (gram_cond_kernel below: explicit inverse of the Cholesky factor, exact 1- and
+// inf-norms); a problem whose bound exceeds GRAM_K2_MAX is handed to the Householder tree through a
+// launch mask.
 // Non-finite input, zero columns, rank deficiency and m < n all fail the gate by construction.
 #include <atomic>
 #include <stdlib.h>
@@ -27,7 +28,7 @@ namespace blsq {
 static constexpr int GR_NT = 512;
 static constexpr int GR_NW = GR_NT / WAVE;
 static constexpr int GR_RC = 32;          // rows per staged chunk (8 MFMA k-steps)
-static constexpr double GRAM_SMIN = 0.1;  // lower limit for the pivots / sigma_min estimate of R'
+static constexpr double GRAM_SMIN = GRAM_SMIN_PROVEN;   // early reject: a pivot of R' below what the certificate could accept
 
 template <class K>
 static hipError_t gram_grant_lds(K kernel, size_t bytes, std::atomic<size_t>* granted_dev) {
@@ -754,6 +755,11 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
       if (lane == 0) pminsh = pmin;
     }
     psync();
+    if (a.rinv && w == NWP - 1) {                       // kept for the conditioning certificate (off the chain)
+      double* ro = a.rinv + ((long)b * (NPAD / 16) + kb) * 256;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ro[q * 64 + lane] = Ri[q * 64 + lane];
+    }
     // ---- C. R'_{kb,j} = R'_{kb,kb}^-T S_j, stored as R = R' D^-1 ----
 #pragma unroll
     for (int u = 0; u < UMAX; ++u) {
@@ -939,6 +945,11 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
       if (lane < TILE) {
 #pragma unroll
         for (int i = 0; i < TILE; ++i) { Dt[i * 16 + jc] = col[i]; Ri[jc * 16 + i] = yy[i]; }
+        if (a.rinv) {
+          double* ro = a.rinv + ((long)b * (NPAD / 16) + kb) * 256 + jc * 16;
+#pragma unroll
+          for (int i = 0; i < TILE; ++i) ro[i] = yy[i];
+        }
       }
       __syncthreads();                                  // B: R'_kk and its inverse are in LDS
       __syncthreads();                                  // C: (workers published the row block)
@@ -1045,129 +1056,163 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
   }
 }
 
-// ---- conditioning gate: inverse power iteration on R' = R D ---------------------------------
-__global__ __launch_bounds__(TRI_NT) void gram_gate_kernel(GramCholArgs a) {
-  extern __shared__ double sh[];
-  __shared__ double red[32];
-  const int b = blockIdx.x, tid = threadIdx.x;
+// ---- conditioning gate: a PROVEN bound on kappa_2 of the equilibrated system -----------------------
+// The normal-equations path loses kappa_2(C) eps where C = R'^T R' is the equilibrated system matrix
+// (unit diagonal) the step is solved from.  An estimate of sigma_min(R') by inverse iteration is a
+// LOWER bound on ||R'^-1||, i.e. it can only err on the unsafe side.  This kernel computes an UPPER
+// bound instead, from the explicit inverse:
+//     Y = R'^-T   (lower triangular; 16 x 16 tiles by FP64 MFMA, the inverses of the diagonal tiles
+//                  come from the Cholesky kernel:  Y_ii = R'_ii^-T,
+//                  Y_ij = -R'_ii^-T sum_{k=j}^{i-1} R'_ki^T Y_kj   for j < i)
+//     1 / lambda_min(C) = ||Y||_2^2 <= ||Y||_1 ||Y||_inf ,   lambda_max(C) = ||R'||_2^2 <= ||R'||_1 ||R'||_inf
+//     K2 = ||R'||_1 ||R'||_inf ||Y||_1 ||Y||_inf  >=  kappa_2(C)
+// (all four norms are exact sums of absolute values, accumulated in a fixed order) and keeps the
+// problem on the normal-equations path only if K2 <= GRAM_K2_MAX.  DESIGN.md 3.0 has the error bound
+// this gives for the step.  NWP waves per problem as in gram_chol_kernel.
+template <int NWP>
+__global__ __launch_bounds__(GR_NT, 4) void gram_cond_kernel(GramCholArgs a) {
+  constexpr int PT = WAVE * NWP;
+  constexpr int PPW = GR_NW / NWP;
+  constexpr int UMAX = (NWP == 8) ? 3 : 5;              // column tiles of a row block per wave
+  extern __shared__ double sh_all[];
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int pslot = wv / NWP;
+  const int pidx = (int)blockIdx.x * PPW + pslot;
+  if (pidx >= a.count) return;                          // (NWP == 1 only: wave-uniform)
+  const int b = pidx;
+  const int tid = (int)threadIdx.x % PT, lane = tid & 63;
+  const int w = wv % NWP;
+  const int lr = lane >> 4, lc = lane & 15;
   if (a.mask && a.mask[b] <= 1) return;
   if (a.fb_mask[b] != 0) return;                        // already failed on a pivot
-  const int n = a.ncols_dev ? a.ncols_dev[b] - 1 : a.n, ld = a.NPAD;
+  const int NPAD = a.NPAD;
+  const int n = a.ncols_dev ? a.ncols_dev[b] - 1 : a.n;
   if (n <= 0) return;
-  const double* R = a.G + (long)b * ld * ld;
-  const double* d = a.dsc + (long)b * ld;
-  double* v = sh;
-  double* invd = v + ld;
-  double* pfbuf = invd + ld;
-  tri_invdiag(R, n, ld, invd);
-  const double s0 = 1.0 / sqrt((double)n);
-  for (int i = tid; i < n; i += TRI_NT) v[i] = (i % 3 == 0) ? s0 : -0.5 * s0;
-  __syncthreads();
-  double smin = 0.0;
-  for (int it = 0; it < 3; ++it) {
-    // v <- R'^-1 R'^-T v  with  R' = R D:  R'^-T y = R^-T (y / d),  R'^-1 y = (R^-1 y) / d
-    for (int i = tid; i < n; i += TRI_NT) v[i] = v[i] / d[i];
-    __syncthreads();
-    tri_solve_upper_t_pf(R, n, ld, invd, v, pfbuf);
-    tri_solve_upper_pf(R, n, ld, invd, v, pfbuf);
-    for (int i = tid; i < n; i += TRI_NT) v[i] = v[i] / d[i];
-    __syncthreads();
-    const double nv = sqrt(tri_dot(v, v, n, red));
-    smin = (nv > 0.0 && is_finite(nv)) ? 1.0 / sqrt(nv) : 0.0;
-    const double inv = (nv > 0.0 && is_finite(nv)) ? 1.0 / nv : 0.0;
-    for (int i = tid; i < n; i += TRI_NT) v[i] *= inv;
-    __syncthreads();
+  const int NTn = (n + 15) / 16;
+  auto psync = [&]() {
+    if (NWP == 8) __syncthreads();
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  };
+  double* sh = sh_all + (size_t)pslot * (6 * (size_t)NPAD + 16 * NWP + 64);
+  double* dl = sh;                      // [NPAD] column scales: R'[i][j] = T[i][j] dl[j]
+  double* cs4 = dl + NPAD;              // [NPAD][4] column sums of |Y|, one slot per lane row
+  double* rs = cs4 + 4 * NPAD;          // [NWP][16] row-sum partials of the current block row
+  double* vals = rs + 16 * NWP;         // [64] reduction scratch
+  double* rowsR = vals + 64;            // [NPAD] row sums of |R'|
+  const double* T = a.G + (long)b * NPAD * NPAD;
+  double* Y = a.ywork + (long)b * NPAD * NPAD;
+  const double* Rinv = a.rinv + (long)b * (NPAD / 16) * 256;
+  for (int j = tid; j < NPAD; j += PT) dl[j] = a.dsc[(long)b * NPAD + j];
+  psync();
+  auto reduce_max = [&](double v) -> double {           // max over the threads of this problem
+    v = wave_max(v);
+    if (NWP == 1) return v;
+    psync();
+    if (lane == 0) vals[w] = v;
+    psync();
+    double t = vals[0];
+    for (int q = 1; q < NWP; ++q) t = fmax(t, vals[q]);
+    return t;
+  };
+  // ---- ||R'||_1 (thread per column) and ||R'||_inf (wave per row) ----
+  double r1 = 0.0;
+  for (int j = tid; j < n; j += PT) {
+    double sum = 0.0;
+    for (int i0 = 0; i0 <= j; i0 += 8) {
+      double rv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rv[u] = T[(long)((i0 + u <= j) ? i0 + u : j) * NPAD + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (i0 + u <= j) sum += fabs(rv[u]);
+    }
+    r1 = fmax(r1, sum * dl[j]);
   }
-  if (tid == 0 && !(smin >= GRAM_SMIN)) {
-    a.fb_mask[b] = a.n + 1;
-    if (a.path_out) a.path_out[b] = a.n + 1;
-    atomicAdd(a.fail_count, 1);
+  r1 = reduce_max(r1);
+  for (int i = w; i < n; i += NWP) {
+    double sum = 0.0;
+    for (int j = i + lane; j < n; j += WAVE) sum += fabs(T[(long)i * NPAD + j]) * dl[j];
+    sum = wave_sum(sum);
+    if (lane == 0) rowsR[i] = sum;
   }
-}
-
-// The same gate with ONE WAVE per problem for n <= 64 (eight problems per workgroup): lane i holds
-// component i of the vectors, both triangular solves walk the rows of R in order (R^T x = y is a
-// row axpy per step, R x = y a row dot product per step), rows are prefetched eight ahead straight
-// from memory — no LDS, no workgroup barrier, sixteen problems resident per CU.
-__global__ __launch_bounds__(GR_NT, 4) void gram_gate_wave_kernel(GramCholArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int pidx = (int)blockIdx.x * GR_NW + ((int)threadIdx.x >> 6);
-  if (pidx >= a.count) return;
-  const int b = pidx;
-  if (a.mask && a.mask[b] <= 1) return;
-  if (a.fb_mask[b] != 0) return;
-  const int n = a.ncols_dev ? a.ncols_dev[b] - 1 : a.n, ld = a.NPAD;
-  if (n <= 0) return;
-  const double* R = a.G + (long)b * ld * ld;
-  const int li = lane < n ? lane : n - 1;
-  const double dsc = a.dsc[(long)b * ld + li];
-  const double rdi = R[(long)li * ld + li];
-  double invd = __builtin_amdgcn_rcp(rdi);
-  invd = invd * fma(-rdi, invd, 2.0);
-  invd = invd * fma(-rdi, invd, 2.0);
-  const double s0 = 1.0 / sqrt((double)n);
-  double v = (lane < n) ? ((lane % 3 == 0) ? s0 : -0.5 * s0) : 0.0;
-  double smin = 0.0;
-  constexpr int PF = 8;
-  for (int it = 0; it < 3; ++it) {
-    // R'^-T: t = R^-T (v / d)  — forward over the rows, axpy per step
-    double t = (lane < n) ? v / dsc : 0.0;
-    double x = 0.0;
-    double nxt[PF];
+  psync();
+  double rinf = 0.0;
+  for (int i = tid; i < n; i += PT) rinf = fmax(rinf, rowsR[i]);
+  rinf = reduce_max(rinf);
+  // ---- Y = R'^-T by block rows; row and column sums of |Y| on the way ----
+  double csum[UMAX];
 #pragma unroll
-    for (int u = 0; u < PF; ++u) nxt[u] = R[(long)((u < n) ? u : n - 1) * ld + li];
-    for (int j0 = 0; j0 < n; j0 += PF) {
-      double row[PF];
+  for (int u = 0; u < UMAX; ++u) csum[u] = 0.0;
+  double rmax = 0.0;                                    // threads 0..15: max over block rows of "their" row
+  for (int i = 0; i < NTn; ++i) {
+    double rsum[4] = {0.0, 0.0, 0.0, 0.0};
+    const double* Ri = Rinv + (long)i * 256;
+    const double dli = dl[16 * i + lc];
 #pragma unroll
-      for (int u = 0; u < PF; ++u) row[u] = nxt[u];
+    for (int u = 0; u < UMAX; ++u) {
+      const int j = w + NWP * u;
+      if (j <= i) {
+        v4d Yt = {0.0, 0.0, 0.0, 0.0};
+        if (j == i) {
 #pragma unroll
-      for (int u = 0; u < PF; ++u) {                    // the next eight rows fly while these are used
-        const int j = (j0 + PF + u < n) ? j0 + PF + u : n - 1;
-        nxt[u] = R[(long)j * ld + li];
-      }
+          for (int g = 0; g < 4; ++g) Yt[g] = Ri[lc * 16 + lr + 4 * g];         // (R'_ii^-1)^T
+        } else {
+          v4d acc = {0.0, 0.0, 0.0, 0.0};
+          for (int k = j; k < i; ++k) {
+            double av[4], bv[4];
 #pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const int j = j0 + u;
-        if (j < n) {
-          const double xj = read_lane(t * invd, j);
-          x = (lane == j) ? xj : x;
-          t = (lane > j && lane < n) ? fma(-row[u], xj, t) : t;
+            for (int s = 0; s < 4; ++s) {
+              const long ro = (long)(16 * k + 4 * s + lr) * NPAD;
+              av[s] = T[ro + 16 * i + lc];
+              bv[s] = Y[ro + 16 * j + lc];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = gmfma(av[s] * dli, bv[s], acc);
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) Yt = gmfma(-Ri[(4 * s + lr) * 16 + lc], acc[s], Yt);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * i + lr + 4 * g, col = 16 * j + lc;
+          const double v = (row < n && col < n) ? Yt[g] : 0.0;
+          Y[(long)row * NPAD + col] = v;
+          const double av_ = fabs(v);
+          rsum[g] += row16_sum(av_);
+          csum[u] += av_;
         }
       }
     }
-    // R'^-1: y = (R^-1 x) / d  — backward over the rows, dot product per step
-    double y = 0.0;
+    if (lc == 0) {
 #pragma unroll
-    for (int u = 0; u < PF; ++u) nxt[u] = R[(long)((n - 1 - u >= 0) ? n - 1 - u : 0) * ld + li];
-    for (int j0 = n - 1; j0 >= 0; j0 -= PF) {
-      double row[PF];
-#pragma unroll
-      for (int u = 0; u < PF; ++u) row[u] = nxt[u];
-#pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const int j = (j0 - PF - u >= 0) ? j0 - PF - u : 0;
-        nxt[u] = R[(long)j * ld + li];
-      }
-#pragma unroll
-      for (int u = 0; u < PF; ++u) {
-        const int j = j0 - u;
-        if (j >= 0) {
-          const double sdot = wave_sum((lane > j && lane < n) ? row[u] * y : 0.0);
-          const double yj = (read_lane(x, j) - sdot) * read_lane(invd, j);
-          y = (lane == j) ? yj : y;
-        }
-      }
+      for (int g = 0; g < 4; ++g) rs[w * 16 + lr + 4 * g] = rsum[g];
     }
-    v = (lane < n) ? y / dsc : 0.0;
-    const double nv = sqrt(wave_sum(v * v));
-    smin = (nv > 0.0 && is_finite(nv)) ? 1.0 / sqrt(nv) : 0.0;
-    const double inv = (nv > 0.0 && is_finite(nv)) ? 1.0 / nv : 0.0;
-    v *= inv;
+    psync();                                            // row sums in LDS; Y row block i visible
+    if (tid < 16) {
+      double t = 0.0;
+      for (int q = 0; q < NWP; ++q) t += rs[q * 16 + tid];
+      rmax = fmax(rmax, t);
+    }
+    psync();
   }
-  if (lane == 0 && !(smin >= GRAM_SMIN)) {
-    a.fb_mask[b] = a.n + 1;
-    if (a.path_out) a.path_out[b] = a.n + 1;
-    atomicAdd(a.fail_count, 1);
+#pragma unroll
+  for (int u = 0; u < UMAX; ++u) {
+    const int j = w + NWP * u;
+    if (j < NTn) cs4[(16 * j + lc) * 4 + lr] = csum[u];
+  }
+  psync();
+  double y1 = 0.0;
+  for (int c = tid; c < n; c += PT)
+    y1 = fmax(y1, (cs4[4 * c] + cs4[4 * c + 1]) + (cs4[4 * c + 2] + cs4[4 * c + 3]));
+  y1 = reduce_max(y1);
+  const double yinf = reduce_max(tid < 16 ? rmax : 0.0);
+  if (tid == 0) {
+    const double k2 = (r1 * rinf) * (y1 * yinf);
+    if (a.k2_out) a.k2_out[b] = k2;
+    if (!(k2 <= GRAM_K2_MAX)) {                          // (NaN fails)
+      a.fb_mask[b] = a.n + 1;
+      if (a.path_out) a.path_out[b] = a.n + 1;
+      atomicAdd(a.fail_count, 1);
+    }
   }
 }
 
@@ -1317,16 +1362,15 @@ hipError_t launch_gram_chol(const GramCholArgs& a_in, int B, hipStream_t s) {
   return hipGetLastError();
 }
 hipError_t launch_gram_gate(const GramCholArgs& a_in, int B, hipStream_t s) {
-  if (a_in.n <= 64) {                                   // one wave per problem
-    GramCholArgs a = a_in;
-    a.count = B;
-    hipLaunchKernelGGL(gram_gate_wave_kernel, dim3((B + GR_NW - 1) / GR_NW), dim3(GR_NT), 0, s, a);
-    return hipGetLastError();
+  GramCholArgs a = a_in;
+  a.count = B;
+  const size_t per1 = sizeof(double) * (6 * (size_t)a.NPAD + 16 * 1 + 64);
+  const size_t per8 = sizeof(double) * (6 * (size_t)a.NPAD + 16 * 8 + 64);
+  if (a.NPAD <= 80) {                                   // one wave per problem, eight per workgroup
+    hipLaunchKernelGGL(gram_cond_kernel<1>, dim3((B + GR_NW - 1) / GR_NW), dim3(GR_NT), per1 * GR_NW, s, a);
+  } else {
+    hipLaunchKernelGGL(gram_cond_kernel<8>, dim3(B), dim3(GR_NT), per8, s, a);
   }
-  const GramCholArgs& a = a_in;
-  const size_t lds = sizeof(double) * (2 + 32) * (size_t)a.NPAD;
-  { static std::atomic<size_t> granted[64]; hipError_t ge = gram_grant_lds(gram_gate_kernel, lds, granted); if (ge != hipSuccess) return ge; }
-  hipLaunchKernelGGL(gram_gate_kernel, dim3(B), dim3(TRI_NT), lds, s, a);
   return hipGetLastError();
 }
 

@@ -62,12 +62,12 @@ __global__ __launch_bounds__(TRI_NT) void lm_gate_kernel(LmState lm, int enable)
   double* pfbuf = invd + ld;                 // 2 x 16 x ld doubles: DMA staging of the solves
   int ok = (enable != 0) && (lm.m >= n);
   // Gram-path problems (gram_kernels.hip): R_aug = R'_aug diag(sqrt h_jj) with sigma_min(R'_aug) >=
-  // sigma_min(R') >= GRAM gate (0.1), so  s_min >= 0.1 min_j sqrt(h_jj)  and  s_max <= sqrt(sum_j h_jj)
+  // sigma_min(R') >= GRAM_SMIN_PROVEN (the conditioning certificate), so  s_min >= that x min_j sqrt(h_jj)  and  s_max <= sqrt(sum_j h_jj)
   // (the exact Frobenius norm).  When that already clears the threshold below, the iteration is
   // not needed; otherwise (extreme column scaling near the bounds) the estimate runs as always.
   if (ok && lm.path && lm.colinfo && lm.path[b] == 0) {
     const double mn = lm.colinfo[2 * (long)b], sm = lm.colinfo[2 * (long)b + 1];
-    const double smin_lb = 0.1 * mn, smax_ub = sqrt(sm);
+    const double smin_lb = GRAM_SMIN_PROVEN * mn, smax_ub = sqrt(sm);
     if (is_finite(sm) && sm > 0.0 && smin_lb > LM_GATE_MARGIN * LM_EPS * lm.m * smax_ub) {
       if (tid == 0) {
         lm.fast[b] = 1;
@@ -353,13 +353,13 @@ __global__ __launch_bounds__(TRI_NT) void dog_gate_solve_kernel(DogState st, int
     tri_invdiag(R, nf, ld, invd);
     const double s0 = 1.0 / sqrt((double)nf);
     const int mx = (st.m > nf) ? st.m : nf;
-    // Gram-path problems: s_min >= 0.1 min_j ||J_free[:, j]||, s_max <= ||J_free||_F (column norms
+    // Gram-path problems: s_min >= GRAM_SMIN_PROVEN min_j ||J_free[:, j]||, s_max <= ||J_free||_F (column norms
     // from the Cholesky of the gathered Gram, as in lm_gate_kernel); the estimates below only run
     // when that bound does not already clear the threshold
     bool sure = false;
     if (path && colinfo && path[b] == 0) {
       const double mn = colinfo[2 * (long)b], sm = colinfo[2 * (long)b + 1];
-      sure = is_finite(sm) && sm > 0.0 && (0.1 * mn > LM_GATE_MARGIN * LM_EPS * mx * sqrt(sm));
+      sure = is_finite(sm) && sm > 0.0 && (GRAM_SMIN_PROVEN * mn > LM_GATE_MARGIN * LM_EPS * mx * sqrt(sm));
     }
     if (!sure) {
     for (int i = tid; i < nf; i += TRI_NT) v[i] = (i & 1) ? -s0 : s0;

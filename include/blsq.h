@@ -112,6 +112,13 @@ int blsq_debug_qr_stamps(void* dbuf);
  * (full-rank gate passed), 0 where it went through the Jacobi SVD */
 int blsq_trf_debug_fast(blsq_trf_plan* plan, int32_t* fast /*B*/);
 
+/* diagnostics: the conditioning certificate of the last factor call, per problem: the PROVEN upper
+ * bound K2 >= kappa_2 of the equilibrated system the step is solved from on the normal-equations
+ * path (0 where no bound was computed: front end off, or a Cholesky pivot failed before).  A
+ * problem stays on that path iff K2 <= 2.5e5. */
+int blsq_trf_debug_cond(blsq_trf_plan* plan, double* k2 /*B*/);
+int blsq_dogbox_debug_cond(blsq_dogbox_plan* plan, double* k2 /*B*/);
+
 /* diagnostics: Jacobi sweeps used by the last factor call, per problem */
 int blsq_trf_debug_sweeps(blsq_trf_plan* plan, int32_t* sweeps /*B*/);
 

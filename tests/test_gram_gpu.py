@@ -41,7 +41,29 @@ def _equicorrelated(B, m, n, rho, seed):
     return np.sqrt(1 - rho) * Z + np.sqrt(rho) * common
 
 
+K2_MAX = 2.5e5          # GRAM_K2_MAX of csrc/blsq_kernels.h
+
+
+def _certificate_holds(P, k2, stats):
+    """The gate's verdicts are consistent with its bound, and the bound IS one: for an unbounded TRF
+    problem the system solved is the column-equilibrated J^T J, whose true condition number must
+    not exceed K2 (k2 == 0: rejected on a Cholesky pivot before the bound was computed)."""
+    B = P["J"].shape[0]
+    fast = 0
+    for b in range(B):
+        Jn = P["J"][b] / np.linalg.norm(P["J"][b], axis=0)
+        sv = np.linalg.svd(Jn, compute_uv=False)
+        true_k2 = (sv[0] / sv[-1]) ** 2
+        if k2[b] > 0:
+            assert k2[b] >= true_k2 * (1 - 1e-6), (b, k2[b], true_k2)
+        else:
+            assert true_k2 > 1e5          # a pivot below 1e-3: sigma_min(R') is below it too
+        fast += 0 < k2[b] <= K2_MAX
+    assert stats == (fast, B - fast), (stats, k2)
+
+
 def _check(bl, P, Delta, kind="trf"):
+    """-> (path counts, worst step error); the proven bounds of the call are left in _check.k2"""
     from oracle import blsq_oracle as orc
     from bounded_lsq import _abi
     B, m, n = P["J"].shape
@@ -52,6 +74,7 @@ def _check(bl, P, Delta, kind="trf"):
         ctx.gram_stats(reset=True)
         sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
         stats = ctx.gram_stats()
+        _check.k2 = sol.debug_cond()
         S = sol.step(Delta, np.zeros(B))
         for b in range(B):
             _, So = orc.trf_step_solve(P["J"][b], P["f"][b], P["x"][b], P["lb"][b], P["ub"][b],
@@ -65,6 +88,7 @@ def _check(bl, P, Delta, kind="trf"):
         ctx.gram_stats(reset=True)
         sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"], P["on_bound"])
         stats = ctx.gram_stats()
+        _check.k2 = sol.debug_cond()
         S = sol.step(Delta)
         for b in range(B):
             _, So = orc.dogbox_step_solve(P["J"][b], P["f"][b], P["x"][b], P["lb"][b], P["ub"][b],
@@ -91,21 +115,25 @@ def test_well_conditioned_batches_take_the_fast_path(bl, B, m, n):
 
 
 @pytest.mark.parametrize("n", [48, 256])
-@pytest.mark.parametrize("rho", [0.5, 0.9, 0.96, 0.98, 0.988, 0.992, 0.999, 1 - 1e-8])
+@pytest.mark.parametrize("rho", [0.5, 0.9, 0.96, 0.98, 0.99, 0.995, 0.999, 1 - 1e-8])
 def test_gate_around_its_threshold(bl, rho, n):
-    """sigma_min(R') = sqrt(1 - rho): 0.71, 0.32, 0.2, 0.14, 0.11 | 0.089, 0.03, 1e-4.
-    (Measured: the fast path's step error stays below 3e-14 all the way to the gate.)"""
+    """Equicorrelated columns: kappa_2 of the equilibrated J^T J is (1 + (n - 1) rho) / (1 - rho).
+    Whatever the gate decides the step matches the oracle (inside _check); its bound K2 is a true
+    upper bound of that condition number; problems are on the fast path exactly when K2 <= 2.5e5.
+    (Measured, tools/gate_calib.py: K2 / kappa_2 = 7 .. 150 on this family; the fast path's step
+    error stays below 1e-12 up to the gate.)"""
     from bounded_lsq import _synth
     B, m = 3, 2048
     P = _synth.trf_batch(31, B, m, n, unbounded=True)
     P["J"] = _equicorrelated(B, m, n, rho, 5)
     stats, worst = _check(bl, P, np.array([10.0, 0.5, 2.0]))
-    if rho <= 0.9:
+    _certificate_holds(P, _check.k2, stats)
+    if rho <= 0.5:
         assert stats == (B, 0), stats                   # clearly inside: fast path
-    if rho >= 0.992:
+    if rho >= 1 - 1e-8:
         assert stats == (0, B), stats                   # clearly outside: Householder tree
     if stats[1] == 0:
-        assert worst < 1e-12                            # the fast path has a wide margin
+        assert worst < 1e-11                            # the fast path has a wide margin
 
 
 @pytest.mark.parametrize("kappa", [2.0, 10.0, 30.0, 100.0, 1e3, 1e5])
@@ -123,7 +151,8 @@ def test_logspaced_spectrum_across_the_gate(bl, kappa):
         J[b] = (U * np.logspace(0, -np.log10(kappa), n)) @ V.T
     P["J"] = J
     stats, worst = _check(bl, P, np.array([10.0, 0.5, 0.05]))
-    if kappa <= 2.0:
+    _certificate_holds(P, _check.k2, stats)
+    if kappa <= 10.0:
         assert stats == (B, 0)
     if kappa >= 1e3:
         assert stats == (0, B)
@@ -131,12 +160,50 @@ def test_logspaced_spectrum_across_the_gate(bl, kappa):
         assert worst < 1e-12
 
 
+def test_the_fast_path_at_the_edge_of_the_gate(bl):
+    """Problems tuned to land just inside the gate (K2 in the last decade below 2.5e5), from three
+    families: the worst step error of the normal-equations path there gives the empirical constant
+    of the bound  step error <= c eps K2  of DESIGN.md 3.0 (c <= 0.2 measured; 0.2 eps K2_MAX =
+    1.1e-11, a factor 9 under the bar even if K2 were exact — it overestimates kappa_2 by >= 7)."""
+    from bounded_lsq import _synth
+    rng = np.random.default_rng(4)
+    cases = []
+    m, n = 2048, 48
+    for rho in (0.99, 0.995, 0.997):                            # equicorrelated, n = 48
+        P = _synth.trf_batch(61, 2, m, n, unbounded=True)
+        P["J"] = _equicorrelated(2, m, n, rho, 9)
+        cases.append(P)
+    m, n = 1200, 80
+    for kappa in (20.0, 25.0, 30.0):                            # log-spaced spectrum
+        P = _synth.trf_batch(62, 2, m, n, unbounded=True)
+        for b in range(2):
+            U, _ = np.linalg.qr(rng.standard_normal((m, n)))
+            V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+            P["J"][b] = (U * np.logspace(0, -np.log10(kappa), n)) @ V.T
+        cases.append(P)
+    for (m, n) in ((380, 255), (420, 256)):                     # nearly square Gaussian
+        cases.append(_synth.trf_batch(63, 2, m, n, unbounded=True))
+    near, worst_all = 0, 0.0
+    for P in cases:
+        B = P["J"].shape[0]
+        stats, worst = _check(bl, P, np.full(B, 0.5))
+        _certificate_holds(P, _check.k2, stats)
+        k2 = _check.k2
+        for b in range(B):
+            if K2_MAX / 10 < k2[b] <= K2_MAX:
+                near += 1
+        if stats[1] == 0:
+            worst_all = max(worst_all, worst)
+    assert near >= 4, "the cases must probe the last decade below the gate"
+    assert worst_all < 2e-12, worst_all
+
+
 @pytest.mark.parametrize("n,s_", [(32, 0.95), (64, 0.97), (128, 0.992)])
 def test_kahan_matrix_pivots_pass_but_sigma_min_does_not(bl, n, s_):
-    """Adversarial for a pivot-only gate: J = Q K with K the n x n Kahan matrix (unit columns after
-    equilibration, every Cholesky pivot s^k stays above the gate's 0.1, yet sigma_min is orders of
-    magnitude smaller).  The inverse-power estimate must send it to the Householder tree, and the
-    step must match the oracle."""
+    """Adversarial for a pivot-only gate (and for estimates of sigma_min that start from an unlucky
+    vector): J = Q K with K the n x n Kahan matrix — unit columns after equilibration, every
+    Cholesky pivot moderate, yet sigma_min orders of magnitude smaller.  The certificate (explicit
+    inverse) must send it to the Householder tree, and the step must match the oracle."""
     from bounded_lsq import _synth
     B, m = 2, 1024
     c_ = np.sqrt(1 - s_ ** 2)
@@ -156,6 +223,7 @@ def test_kahan_matrix_pivots_pass_but_sigma_min_does_not(bl, n, s_):
     P["J"] = J
     stats, _ = _check(bl, P, np.array([10.0, 0.5]))
     assert stats == (0, B), stats
+    assert np.all((_check.k2 == 0) | (_check.k2 > 1e8))     # the proven bound sees what the pivots do not
 
 
 def test_mixed_batch_splits_between_the_paths(bl):
