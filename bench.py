@@ -480,10 +480,15 @@ def main():
     ndev = max(1, _abi.load().blsq_device_count())
     ctx = _abi.Context(local_rank % ndev)
 
+    def tdev():
+        """explicit torch device of this rank (a helper thread's current device is 0, not ours)"""
+        import torch
+        return torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
+
     def bcast_comm_id():
         """rank 0's RCCL rendezvous id to every rank, through the launcher's process group"""
         import torch
-        dev = "cuda" if backend == "nccl" else "cpu"
+        dev = tdev()
         nb = ctx.lib.blsq_comm_id_bytes()
         buf = torch.zeros(nb, dtype=torch.uint8, device=dev)
         if rank == 0:
@@ -496,16 +501,16 @@ def main():
         if dist is not None:
             import torch
             if backend == "nccl":
-                torch.cuda.synchronize()
+                torch.cuda.synchronize(tdev())
             dist.barrier()
             if backend == "nccl":
-                torch.cuda.synchronize()
+                torch.cuda.synchronize(tdev())
 
     def max_over_ranks(v):
         if dist is None:
             return v
         import torch
-        t = torch.tensor([v], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        t = torch.tensor([v], dtype=torch.float64, device=tdev())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -588,11 +593,16 @@ def main():
         c5, hung = with_timeout(c5_leg, 240, "c5 over RCCL")
         if rank == 0:
             extras["c5_tsqr"] = c5
-        if hung:                                   # a hung collective: report and leave without teardown
+        if hung or (isinstance(c5, dict) and "error" in c5):
+            # a hung or failed collective on SOME rank: report and leave without any further
+            # collective (teardown included) — the other ranks may be anywhere
             if rank == 0:
                 out.update(extras)
+                out["cpu_baseline"] = None
+                out["speedup_vs_cpu"] = None
                 out["parity"] = parity
                 print(json.dumps(out), flush=True)
+            sys.stdout.flush()
             os._exit(0)
 
     if rank == 0:
