@@ -476,7 +476,7 @@ __global__ __launch_bounds__(GR_NT, 2) void gram16_kernel(GramArgs a) {
 // So with few column tiles every wave takes its own k-steps (4 rows each, wave w: k-steps w, w + 8,
 // ...) for ALL output tiles, loads the NT fragments of several k-steps ahead, and never meets the
 // other waves until the final, fixed-order reduction of the eight partial Grams through LDS.
-template <int NTT>
+template <int NTT, bool RHS>
 __global__ __launch_bounds__(GR_NT, (NTT <= 2 ? 4 : 2)) void gram_direct_kernel(GramArgs a) {
   constexpr int NTILE = NTT * (NTT + 1) / 2;
   constexpr int KU = (NTT <= 2) ? 8 : 4;                // k-steps in flight per wave
@@ -495,20 +495,30 @@ __global__ __launch_bounds__(GR_NT, (NTT <= 2 ? 4 : 2)) void gram_direct_kernel(
   v4d acc[NTILE];
 #pragma unroll
   for (int t = 0; t < NTILE; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+  // RHS (n = 16 NTT exactly): the tiles cover J^T J only; the rhs column (J^T f, f^T f) is accumulated
+  // from the operand fragments a lane holds anyway (column 16 c + lc, rows lr mod 4 of this wave's
+  // k-steps) and reduced over the lane rows and the waves at the end, in a fixed order
+  double gf[NTT], gff = 0.0;
+#pragma unroll
+  for (int c = 0; c < NTT; ++c) gf[c] = 0.0;
   const int last = r_hi > r_lo ? r_hi - 1 : r_lo;
   for (int r0 = r_lo + 4 * w; r0 < r_hi; r0 += 4 * GR_NW * KU) {
-    double fr[KU][NTT];
+    double fr[KU][NTT], fv[KU];
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
       const int row = r0 + 4 * GR_NW * u + lr;
       const int rc = row < r_hi ? row : last;
+      if (RHS) {
+        const double t = Fb[rc];
+        fv[u] = row < r_hi ? t : 0.0;
+      }
 #pragma unroll
       for (int c = 0; c < NTT; ++c) {
         const int col = 16 * c + lc;
-        // (clamped unconditional loads, select afterwards; the rhs f is column n)
-        const double* ptr = (col < n) ? Jb + (long)rc * a.ldJ + col : Fb + rc;
+        // (clamped unconditional loads, select afterwards; without RHS the rhs f is column n)
+        const double* ptr = (RHS || col < n) ? Jb + (long)rc * a.ldJ + (col < n ? col : n - 1) : Fb + rc;
         const double v = __builtin_nontemporal_load(ptr);
-        fr[u][c] = (row < r_hi && col <= n) ? v : 0.0;
+        fr[u][c] = (row < r_hi && (RHS ? col < n : col <= n)) ? v : 0.0;
       }
     }
 #pragma unroll
@@ -518,6 +528,11 @@ __global__ __launch_bounds__(GR_NT, (NTT <= 2 ? 4 : 2)) void gram_direct_kernel(
       for (int i = 0; i < NTT; ++i)
 #pragma unroll
         for (int j = i; j < NTT; ++j, ++t) acc[t] = gmfma(fr[u][i], fr[u][j], acc[t]);
+      if (RHS) {
+#pragma unroll
+        for (int c = 0; c < NTT; ++c) gf[c] = fma(fr[u][c], fv[u], gf[c]);
+        gff = fma(fv[u], fv[u], gff);
+      }
     }
   }
   // cross-wave reduction, tile by tile through a 16 KB LDS buffer (fixed order: deterministic)
@@ -542,6 +557,26 @@ __global__ __launch_bounds__(GR_NT, (NTT <= 2 ? 4 : 2)) void gram_direct_kernel(
         __syncthreads();
       }
     }
+  }
+  if (!RHS) return;
+  // rhs column: [wave][lane row][column] partials -> column totals (wave-major, then lane row)
+#pragma unroll
+  for (int c = 0; c < NTT; ++c) lds[(w * 4 + lr) * 64 + 16 * c + lc] = gf[c];
+  if (lc == 0) lds[2048 + w * 4 + lr] = gff;
+  __syncthreads();
+  if (tid < n) {
+    double sum = 0.0;
+    for (int q = 0; q < 4 * GR_NW; ++q) sum += lds[q * 64 + tid];
+    G[(long)tid * a.NPAD + n] = sum;
+  }
+  if (tid == 0) {
+    double sum = 0.0;
+    for (int q = 0; q < 4 * GR_NW; ++q) sum += lds[2048 + q];
+    G[(long)n * a.NPAD + n] = sum;
+  }
+  for (int e = tid; e < a.NPAD * (16 * NT - (n + 1)); e += GR_NT) {   // padding of the rhs tile column
+    const int r = e / (16 * NT - (n + 1)), c = n + 1 + e % (16 * NT - (n + 1));
+    if ((r >> 4) <= (c >> 4)) G[(long)r * a.NPAD + c] = 0.0;
   }
 }
 
@@ -1220,19 +1255,22 @@ bool gram_supported(int m, int n) {
   const int NT = (n + 1 + 15) / 16;
   return NT <= 17 && m >= n && n >= 1;
 }
-// Row chunks of GRAM_CHUNK_ROWS rows whatever the batch size: the summation order of a problem's
-// Gram (and so every bit of its result) does not depend on how many problems share the launch.
-static constexpr int GRAM_CHUNK_ROWS = 2048;
+// Row chunks whose size is a function of m ALONE (never of the batch size): the summation order of
+// a problem's Gram (and so every bit of its result) does not depend on how many problems share the
+// launch.  2048 rows; 1024 for very tall problems (one 250 000 x 128 row block of BASELINE config 5:
+// 245 workgroups fill the 256 CUs, 123 leave half of them idle).
+static int gram_chunk_rows(int m) { return m > 131072 ? 1024 : 2048; }
 int gram_chunks(int B, int m) {
   (void)B;
-  const int c = (m + GRAM_CHUNK_ROWS - 1) / GRAM_CHUNK_ROWS;
+  const int r = gram_chunk_rows(m);
+  const int c = (m + r - 1) / r;
   return c < 1 ? 1 : c;
 }
 
 hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s) {
   GramArgs a = a_in;
   const int NT = (a.n + 1 + 15) / 16;
-  a.rows_per_chunk = chunks > 1 ? GRAM_CHUNK_ROWS : a.m;
+  a.rows_per_chunk = chunks > 1 ? gram_chunk_rows(a.m) : a.m;
   const size_t lds = sizeof(double) * 2 * GR_RC * (size_t)gram_ldx(NT);
   // slot variant a wave needs for `nt` column tiles
   auto slots_for = [](int nt) {
@@ -1252,24 +1290,31 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s) {
     if (ge != hipSuccess) return ge;                                                          \
     hipLaunchKernelGGL((gram_kernel<SL, CB>), dim3(chunks, B, tg), dim3(GR_NT), lds, s, a);   \
   } while (0)
-#define BLSQ_GRAM_DIRECT(NTT)                                                                 \
+#define BLSQ_GRAM_DIRECT(NTT, RHS)                                                            \
   do {                                                                                        \
-    const size_t dl_ = sizeof(double) * GR_NW * 256;                                          \
+    const size_t dl_ = sizeof(double) * (GR_NW * 256 + 64);                                   \
     static std::atomic<size_t> granted[64];                                                   \
-    hipError_t ge = gram_grant_lds(gram_direct_kernel<NTT>, dl_, granted);                    \
+    hipError_t ge = gram_grant_lds(gram_direct_kernel<NTT, RHS>, dl_, granted);               \
     if (ge != hipSuccess) return ge;                                                          \
-    hipLaunchKernelGGL((gram_direct_kernel<NTT>), dim3(chunks, B), dim3(GR_NT), dl_, s, a);   \
+    hipLaunchKernelGGL((gram_direct_kernel<NTT, RHS>), dim3(chunks, B), dim3(GR_NT), dl_, s, a); \
     return hipGetLastError();                                                                 \
   } while (0)
   {
     const char* env = getenv("BLSQ_GRAM_DIRECT_MAX_NT");     // tuning / tests: 0 disables
-    const int dmax = env ? atoi(env) : 4;                      // measured: direct wins up to 4 column tiles (n <= 62)
-    if (NT <= dmax) {
-      if (NT <= 1) BLSQ_GRAM_DIRECT(1);
-      else if (NT == 2) BLSQ_GRAM_DIRECT(2);
-      else if (NT == 3) BLSQ_GRAM_DIRECT(3);
-      else if (NT == 4) BLSQ_GRAM_DIRECT(4);
-      else if (NT == 5) BLSQ_GRAM_DIRECT(5);
+    const int dmax = env ? atoi(env) : 4;                      // measured: direct wins up to 4 column tiles
+    // n a multiple of 16: the tiles cover J^T J only (n / 16 column tiles), the rhs column is
+    // accumulated from the same fragments (n = 64: 10 tiles instead of 15, and still no LDS staging)
+    if (a.rhs_valu && NTJ <= dmax) {
+      if (NTJ == 1) BLSQ_GRAM_DIRECT(1, true);
+      else if (NTJ == 2) BLSQ_GRAM_DIRECT(2, true);
+      else if (NTJ == 3) BLSQ_GRAM_DIRECT(3, true);
+      else if (NTJ == 4) BLSQ_GRAM_DIRECT(4, true);
+    }
+    if (!a.rhs_valu && NT <= dmax) {
+      if (NT <= 1) BLSQ_GRAM_DIRECT(1, false);
+      else if (NT == 2) BLSQ_GRAM_DIRECT(2, false);
+      else if (NT == 3) BLSQ_GRAM_DIRECT(3, false);
+      else if (NT == 4) BLSQ_GRAM_DIRECT(4, false);
     }
   }
 #undef BLSQ_GRAM_DIRECT

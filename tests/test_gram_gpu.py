@@ -106,7 +106,9 @@ def _check(bl, P, Delta, kind="trf"):
                                    # n % 16 == 0 where the rhs column leaves the MFMA tiles
                                    (2, 1000, 112), (2, 2100, 160), (2, 3000, 208), (2, 5000, 256),
                                    # narrow: direct-from-global kernel, 1..4 column tiles
-                                   (4, 3000, 7), (4, 5000, 31), (3, 2500, 47), (3, 2200, 62)])
+                                   (4, 3000, 7), (4, 5000, 31), (3, 2500, 47), (3, 2200, 62),
+                                   # ... and n = 16, 32, 48, 64: rhs column from the operand fragments
+                                   (4, 900, 16), (3, 2000, 32), (3, 1000, 48), (5, 700, 64), (2, 5000, 64)])
 def test_well_conditioned_batches_take_the_fast_path(bl, B, m, n):
     from bounded_lsq import _synth
     P = _synth.trf_batch(77 + n, B, m, n)
