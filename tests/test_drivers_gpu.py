@@ -380,3 +380,65 @@ def test_least_squares_batch_fd_jacobian(method):
             r = res[b]
             assert (r.nfev, r.njev, r.status) == (ref.nfev, ref.njev, ref.status), (driver, b)
             np.testing.assert_allclose(r.x, ref.x, rtol=1e-9, atol=1e-12)
+
+
+# ---- the reference's records replayed DIRECTLY through the device-resident driver ---------------
+def _rosen_batch(X):
+    return np.stack([rosen(x) for x in X])
+
+
+def _rosen_jac_batch(X):
+    return np.stack([rosen_jac(x) for x in X])
+
+
+@pytest.mark.parametrize("method", ["trf", "dogbox"])
+@pytest.mark.parametrize("scaling", [1.0, "jac", [1.0, 5.0]], ids=["s1", "jac", "s15"])
+def test_reference_records_through_the_device_driver(method, scaling):
+    """The six bounded-Rosenbrock records of tests/golden/e2e.json (reference's own trf() /
+    dogbox()) as ONE batch of six problems with different start points and boxes through
+    least_squares_batch(driver='device'): every problem must return the reference's nfev, njev,
+    status, x, objective and active mask — the device-resident outer logic pinned to the
+    reference directly, not via the host driver."""
+    import bounded_lsq
+    want = [scaling] if isinstance(scaling, str) else [float(v) for v in np.atleast_1d(scaling)]
+    recs = [r for r in E2E["records"] if r["tag"].startswith("rosen_B") and r["method"] == method
+            and (r["scaling"] == scaling if isinstance(scaling, str) else r["scaling"] == want)]
+    recs.sort(key=lambda r: r["tag"])
+    assert len(recs) == 6
+    unh = lambda v: np.array([float.fromhex(s) for s in v])                     # noqa: E731
+    X0 = np.stack([unh(r["x0"]) for r in recs])
+    lb = np.stack([unh(r["lb"]) for r in recs])
+    ub = np.stack([unh(r["ub"]) for r in recs])
+    tol = float.fromhex(E2E["tol"])
+    for driver in ("device", "host"):
+        res = bounded_lsq.least_squares_batch(_rosen_batch, X0, _rosen_jac_batch, bounds=(lb, ub),
+                                              method=method, ftol=tol, xtol=tol, gtol=tol,
+                                              scaling=scaling, driver=driver)
+        for r, rec in zip(res, recs):
+            assert (r.nfev, r.njev, r.status) == (rec["nfev"], rec["njev"], rec["status"]), (driver, rec["tag"])
+            np.testing.assert_allclose(r.x, unh(rec["x"]), rtol=1e-8, atol=1e-11)
+            np.testing.assert_allclose(r.obj_value, float.fromhex(rec["obj_value"]), rtol=1e-7, atol=1e-18)
+            np.testing.assert_array_equal(r.active_mask, rec["active_mask"])
+
+
+def test_suite58_family_through_the_device_driver():
+    """One family of the reference's benchmark set with several start-point / box variants
+    (Rosenbrock_B_0..5 of tests/golden/suite58.json) as one batch on the device driver."""
+    import bounded_lsq
+    S = load_json("suite58.json")
+    probs = [p for p in S["problems"] if p["family"] == "Rosenbrock" and p["bounded"]]
+    unh = lambda v: np.array([float.fromhex(s) for s in v])                     # noqa: E731
+    X0 = np.stack([unh(p["x0"]) for p in probs])
+    lb = np.stack([unh(p["lb"]) for p in probs])
+    ub = np.stack([unh(p["ub"]) for p in probs])
+    tol = float.fromhex(S["tol"])
+    for method in ("trf", "dogbox"):
+        res = bounded_lsq.least_squares_batch(_rosen_batch, X0, _rosen_jac_batch, bounds=(lb, ub),
+                                              method=method, ftol=tol, xtol=tol, gtol=tol,
+                                              scaling=1.0, driver="device")
+        for r, p in zip(res, probs):
+            rec = [q for q in S["records"] if q["problem"] == p["name"] and q["method"] == method
+                   and q["scaling"] == 1.0][0]
+            if rec.get("stable"):
+                assert (r.nfev, r.njev, r.status) == (rec["nfev"], rec["njev"], rec["status"]), p["name"]
+                np.testing.assert_allclose(r.x, unh(rec["x"]), rtol=1e-7, atol=1e-10)
