@@ -38,12 +38,14 @@ def _bounds_2d(bounds, B, n):
 
 def least_squares_batch(fun, x0, jac, bounds=(-np.inf, np.inf), method='trf',
                         ftol=EPS ** 0.5, xtol=EPS ** 0.5, gtol=EPS ** 0.5, max_nfev=None,
-                        scaling=1.0, ctx=None, driver='host'):
+                        scaling=1.0, diff_step=None, args=(), kwargs={}, ctx=None, driver='host'):
     """Solve B bound-constrained least-squares problems of identical shape.
 
     fun : callable, ``fun(X) -> (B, m)`` residuals for ``X`` (B, n)
     x0  : (B, n) initial guesses;  jac : callable ``jac(X) -> (B, m, n)``, or '2-point' / '3-point' 
     bounds : pair broadcastable to (B, n);  scaling : 'jac' or broadcastable to (n,)
+    diff_step : relative step of the finite-difference Jacobian (as `least_squares`, least_squares.py:357-365)
+    args, kwargs : passed on to `fun` and `jac` (``fun(X, *args, **kwargs)``)
     driver : 'host' — the per-problem accept / update logic runs here in Python around batched
              C-ABI calls; 'device' — it runs on the GPU (``OuterDriver``, blsq_outer_*), x / f / J
              stay resident and only fresh Jacobians are uploaded and factored.
@@ -58,6 +60,14 @@ def least_squares_batch(fun, x0, jac, bounds=(-np.inf, np.inf), method='trf',
     lb, ub = _bounds_2d(bounds, B, n)
     if not callable(fun):
         raise ValueError("`fun` must be callable (vectorised over the batch).")
+    if args or kwargs:                                        # least_squares.py:351-355, 367-371
+        user_fun, user_jac = fun, jac
+
+        def fun(X):                                           # noqa: F811
+            return user_fun(X, *args, **kwargs)
+        if callable(user_jac):
+            def jac(X):                                       # noqa: F811
+                return user_jac(X, *args, **kwargs)
     fd_state = {}                                  # lazily created FdJacobian (+ ctx if we own it)
     if isinstance(jac, str) and jac in ('2-point', '3-point'):
         # the reference's FD Jacobian (third-party approx_derivative, least_squares.py:357-365)
@@ -75,7 +85,7 @@ def least_squares_batch(fun, x0, jac, bounds=(-np.inf, np.inf), method='trf',
                 if user_ctx is None:
                     fd_state["own_ctx"] = _abi.Context(0)
                 fd_state["fd"] = FdJacobian(user_ctx or fd_state["own_ctx"], B, F.shape[1], n,
-                                            fd_method, None)
+                                            fd_method, diff_step)
 
             def fun_points(Xp):
                 return np.stack([np.asarray(fun(np.ascontiguousarray(Xp[:, p, :])), dtype=float)

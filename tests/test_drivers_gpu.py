@@ -382,6 +382,31 @@ def test_least_squares_batch_fd_jacobian(method):
             np.testing.assert_allclose(r.x, ref.x, rtol=1e-9, atol=1e-12)
 
 
+def test_least_squares_batch_diff_step_args_kwargs():
+    """diff_step, args and kwargs reach the callbacks / the FD Jacobian of the batched entry exactly
+    as in least_squares (least_squares.py:351-371)."""
+    from bounded_lsq import least_squares, least_squares_batch
+    B = 3
+    _, _, Y, t = _expfit_batch(B)
+    X0 = np.tile(np.array([1.0, -0.1, 1.0, 1.0]), (B, 1))
+    X0[:, 0] += 0.05 * np.arange(B)
+    bounds = (np.array([0.0, -2.0, 0.0, 0.0]), np.array([1.8, 0.0, 3.0, 2.0]))
+
+    def fun(X, data, shift=0.0):
+        return X[:, :1] * np.exp(X[:, 1:2] * t) + X[:, 2:3] * np.cos(X[:, 3:4] * t) - data + shift
+
+    for driver in ("host", "device"):
+        res = least_squares_batch(fun, X0, '2-point', bounds=bounds, method='trf', diff_step=1e-6,
+                                  args=(Y,), kwargs=dict(shift=0.01), driver=driver)
+        for b in range(B):
+            def fun_b(p, data, shift=0.0, b=b):
+                return p[0] * np.exp(p[1] * t) + p[2] * np.cos(p[3] * t) - data[b] + shift
+            ref = least_squares(fun_b, X0[b], '2-point', bounds=bounds, method='trf', diff_step=1e-6,
+                                args=(Y,), kwargs=dict(shift=0.01))
+            assert (res[b].nfev, res[b].njev, res[b].status) == (ref.nfev, ref.njev, ref.status), (driver, b)
+            np.testing.assert_allclose(res[b].x, ref.x, rtol=1e-9, atol=1e-12)
+
+
 # ---- the reference's records replayed DIRECTLY through the device-resident driver ---------------
 def _rosen_batch(X):
     return np.stack([rosen(x) for x in X])
