@@ -1240,8 +1240,75 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_cond_kernel(GramCholArgs a) {
     y1 = fmax(y1, (cs4[4 * c] + cs4[4 * c + 1]) + (cs4[4 * c + 2] + cs4[4 * c + 3]));
   y1 = reduce_max(y1);
   const double yinf = reduce_max(tid < 16 ? rmax : 0.0);
+  double k2 = (r1 * rinf) * (y1 * yinf);
+  if (!(k2 <= GRAM_K2_MAX)) {                            // (uniform over the problem's threads)
+    // The 1- / inf-norm products overestimate kappa_2 by 10 ... 1000 (profiles/r02p_gate_calibration.txt).
+    // Second, tighter proven bound for a problem they reject:  lambda_max(C) <= ||C||_F  and
+    // 1 / lambda_min(C) = ||C^-1||_2 <= ||C^-1||_F  with  C^-1 = Y^T Y  formed tile by tile (MFMA; only
+    // its sum of squares is kept) and C rebuilt from the source Gram with the Cholesky's own scalings.
+    // Measured overestimate 4 ... 30 on the ill-conditioned families.  Sums in a fixed order.
+    const int* gidx = a.gather ? a.gather + (long)b * a.stride_vec : nullptr;
+    auto src = [&](int i) -> int { return gidx ? (i < n ? gidx[i] : a.n) : i; };
+    const double* Gs = a.Gsrc + (long)b * NPAD * NPAD;
+    const double* csv = a.colscale ? a.colscale + (long)b * a.stride_vec : nullptr;
+    const double* edv = a.diag_vec ? a.diag_vec + (long)b * a.stride_vec : nullptr;
+    double* scl = cs4;                  // [NPAD] cs_j dl_j   (cs4 is free now)
+    double* tdl = cs4 + NPAD;           // [NPAD] e_j^2 dl_j^2
+    psync();
+    for (int j = tid; j < NPAD; j += PT) {
+      const double cs = (csv && j < n) ? csv[j] : 1.0;
+      const double ej = (edv && j < n) ? edv[j] : 0.0;
+      scl[j] = cs * dl[j];
+      tdl[j] = (ej * ej) * dl[j] * dl[j];
+    }
+    psync();
+    double cf = 0.0, zf = 0.0;          // this wave's share of ||C||_F^2 / ||C^-1||_F^2
+    int q = 0;
+    for (int j = 0; j < NTn; ++j) {
+      for (int i = 0; i <= j; ++i, ++q) {
+        if (q % NWP != w) continue;     // (wave-uniform)
+        const double wgt = (i == j) ? 1.0 : 2.0;
+        double c2 = 0.0;
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * i + lr + 4 * g, col = 16 * j + lc;
+          double v = 0.0;
+          if (row < n && col < n) {
+            int sr_ = src(row), sc_ = src(col);
+            if (sr_ > sc_) { const int t_ = sr_; sr_ = sc_; sc_ = t_; }
+            v = Gs[(long)sr_ * NPAD + sc_] * scl[row] * scl[col];
+            if (row == col) v += tdl[row];
+          }
+          c2 = fma(v, v, c2);
+        }
+        for (int k = j; k < NTn; ++k) {
+          double av[4], bv[4];
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) {
+            const long ro = (long)(16 * k + 4 * s2 + lr) * NPAD;
+            av[s2] = Y[ro + 16 * i + lc];
+            bv[s2] = Y[ro + 16 * j + lc];
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) acc = gmfma(av[s2], bv[s2], acc);
+        }
+        const double z2 = (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]);
+        cf = fma(wgt, wave_sum(c2), cf);
+        zf = fma(wgt, wave_sum(z2), zf);
+      }
+    }
+    if (NWP > 1) {
+      psync();
+      if (lane == 0) { vals[w] = cf; vals[8 + w] = zf; }
+      psync();
+      cf = 0.0; zf = 0.0;
+      for (int qq = 0; qq < NWP; ++qq) { cf += vals[qq]; zf += vals[8 + qq]; }
+    }
+    const double k2f = sqrt(cf) * sqrt(zf);
+    if (k2f < k2) k2 = k2f;
+  }
   if (tid == 0) {
-    const double k2 = (r1 * rinf) * (y1 * yinf);
     if (a.k2_out) a.k2_out[b] = k2;
     if (!(k2 <= GRAM_K2_MAX)) {                          // (NaN fails)
       a.fb_mask[b] = a.n + 1;

@@ -122,7 +122,7 @@ def test_gate_around_its_threshold(bl, rho, n):
     """Equicorrelated columns: kappa_2 of the equilibrated J^T J is (1 + (n - 1) rho) / (1 - rho).
     Whatever the gate decides the step matches the oracle (inside _check); its bound K2 is a true
     upper bound of that condition number; problems are on the fast path exactly when K2 <= 2.5e5.
-    (Measured, tools/gate_calib.py: K2 / kappa_2 = 7 .. 150 on this family; the fast path's step
+    (Measured, tools/gate_calib.py: K2 / kappa_2 = 5 .. 150 on this family; the fast path's step
     error stays below 1e-12 up to the gate.)"""
     from bounded_lsq import _synth
     B, m = 3, 2048
@@ -185,6 +185,18 @@ def test_the_fast_path_at_the_edge_of_the_gate(bl):
         cases.append(P)
     for (m, n) in ((380, 255), (420, 256)):                     # nearly square Gaussian
         cases.append(_synth.trf_batch(63, 2, m, n, unbounded=True))
+    # ... and families that only the second (Frobenius) bound of the certificate admits
+    P = _synth.trf_batch(64, 2, 2048, 256, unbounded=True)
+    P["J"] = _equicorrelated(2, 2048, 256, 0.98, 10)
+    cases.append(P)
+    m, n = 1200, 80
+    for kappa in (150.0, 200.0):
+        P = _synth.trf_batch(65, 2, m, n, unbounded=True)
+        for b in range(2):
+            U, _ = np.linalg.qr(rng.standard_normal((m, n)))
+            V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+            P["J"][b] = (U * np.logspace(0, -np.log10(kappa), n)) @ V.T
+        cases.append(P)
     near, worst_all = 0, 0.0
     for P in cases:
         B = P["J"].shape[0]
@@ -196,7 +208,7 @@ def test_the_fast_path_at_the_edge_of_the_gate(bl):
                 near += 1
         if stats[1] == 0:
             worst_all = max(worst_all, worst)
-    assert near >= 4, "the cases must probe the last decade below the gate"
+    assert near >= 6, "the cases must probe the last decade below the gate"
     assert worst_all < 2e-12, worst_all
 
 
