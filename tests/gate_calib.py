@@ -1,7 +1,7 @@
 """Calibration of the conditioning certificate (gram_cond_kernel): for families of Jacobians with
 known spectra print the PROVEN bound K2 >= kappa_2(C), the true kappa_2 of the equilibrated system,
 which path the problem took, and the step error of BOTH paths against the oracle.
-usage: python tools/gate_calib.py   (GPU box; imports the oracle: a test tool, not product code)"""
+usage: python tests/gate_calib.py   (GPU box; lives under tests/: it drives the CPU oracle)"""
 import os
 import sys
 

@@ -122,7 +122,7 @@ def test_gate_around_its_threshold(bl, rho, n):
     """Equicorrelated columns: kappa_2 of the equilibrated J^T J is (1 + (n - 1) rho) / (1 - rho).
     Whatever the gate decides the step matches the oracle (inside _check); its bound K2 is a true
     upper bound of that condition number; problems are on the fast path exactly when K2 <= 2.5e5.
-    (Measured, tools/gate_calib.py: K2 / kappa_2 = 5 .. 150 on this family; the fast path's step
+    (Measured, tests/gate_calib.py: K2 / kappa_2 = 5 .. 150 on this family; the fast path's step
     error stays below 1e-12 up to the gate.)"""
     from bounded_lsq import _synth
     B, m = 3, 2048
