@@ -255,7 +255,7 @@ struct QrTree {
       if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Gram gate bound)");
       e = hipMemsetAsync(gram_k2.p, 0, gram_k2.bytes, ctx->stream);
       if (e != hipSuccess) return ctx->fail(e, "hipMemsetAsync(Gram gate bound)");
-      e = gram_ints.alloc(sizeof(int) * (2 * (size_t)B + 4));     // launch mask, count, path
+      e = gram_ints.alloc(sizeof(int) * (3 * (size_t)B + 4));     // launch mask, count, path, fallback list
       if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Gram mask)");
       e = hipMemsetAsync(gram_keep.p, 0, gram_keep.bytes, ctx->stream);      // (lower tiles are never written)
       if (e != hipSuccess) return ctx->fail(e, "hipMemsetAsync(Grams)");
@@ -334,11 +334,15 @@ struct QrTree {
     return 0;
   }
   // Householder TSQR tree only (problems selected by ncols_mask; nullptr: all)
-  int run_levels(blsq_ctx* ctx, const double* dJ, const double* df, int ldJ, const int* ncols_mask) {
+  // list / count (optional): compacted indices of the selected problems — a masked launch whose
+  // active workgroups alternate with idle ones lands on a fraction of the XCDs
+  int run_levels(blsq_ctx* ctx, const double* dJ, const double* df, int ldJ, const int* ncols_mask,
+                 const int* list = nullptr, int count = 0) {
     for (size_t l = 0; l < levels.size(); ++l) {
       const Level& L = levels[l];
       QrArgs q = base_args();
       q.ncols_dev = ncols_mask;
+      q.batch_list = list;
       if (l == 0) {
         q.A = dJ; q.strideA = (long)m * ldJ; q.ldA = ldJ; q.rowsA = m;
         q.F = df; q.strideF = m;
@@ -351,7 +355,7 @@ struct QrTree {
       q.rows_per_leaf = L.rows_per_leaf; q.RP = L.RP; q.LDP = L.LDP;
       q.Rout = L.R.as<double>();
       ctx->begin(l == 0 ? K_QR_LEAF : K_QR_MERGE);
-      hipError_t e = launch_qr(q, L.nleaf, B, ctx->stream);
+      hipError_t e = launch_qr(q, L.nleaf, list ? count : B, ctx->stream);
       ctx->end();
       if (e != hipSuccess) return ctx->fail(e, "launch_qr");
     }
@@ -360,6 +364,7 @@ struct QrTree {
   int* fb_mask() const { return gram_ints.as<int>(); }
   int* fb_count() const { return gram_ints.as<int>() + B; }
   int* path_rw() const { return gram_ints.as<int>() + B + 4; }
+  int* fb_list() const { return gram_ints.as<int>() + 2 * (size_t)B + 4; }
   // host bookkeeping after a gate verdict: nfb of the problems refreshed by this call failed
   void note_paths(blsq_ctx* ctx, int nfb, bool masked) {
     ctx->gram_fallback += nfb;
@@ -797,6 +802,7 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb) 
   c.Gsrc = t.gram_keep.as<double>(); c.G = p->st.X; c.NPAD = p->ld; c.n = p->n;
   c.colscale = p->st.d; c.diag_vec = p->st.ediag; c.stride_vec = p->ld;
   c.mask = mask; c.fb_mask = t.fb_mask(); c.fail_count = t.fb_count(); c.path_out = t.path_rw();
+  c.fail_list = t.fb_list();
   c.dsc = t.gram_dsc.as<double>();
   c.rinv = t.gram_rinv.as<double>(); c.ywork = t.gram_ywork.as<double>(); c.k2_out = t.gram_k2.as<double>();
   c.colinfo = p->aug_colinfo.as<double>();
@@ -822,9 +828,10 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb) 
 }
 
 // the problems the gate rejected: Householder tree on [J f], prep again from the triangle
-int trf_fallback_stage(blsq_trf_plan* p, const double* dJ, const double* df, int ldJ, int scale_mode) {
+int trf_fallback_stage(blsq_trf_plan* p, const double* dJ, const double* df, int ldJ, int scale_mode,
+                       int nfb) {
   blsq_ctx* ctx = p->ctx;
-  int rc = p->tree.run_levels(ctx, dJ, df, ldJ, p->tree.fb_mask());
+  int rc = p->tree.run_levels(ctx, dJ, df, ldJ, p->tree.fb_mask(), p->tree.fb_list(), nfb);
   if (rc) return rc;
   ctx->begin(K_PREP);
   hipError_t e = launch_trf_prep(p->st, scale_mode, 0, p->tree.fb_mask(), 1, ctx->stream);
@@ -845,7 +852,7 @@ int trf_factor_core(blsq_trf_plan* p, const double* dJ, const double* df, int ld
   if ((rc = p->tree.run_gram_only(ctx, dJ, df, ldJ, mask, false))) return rc;
   int nfb = 0;
   if ((rc = trf_gram_stage(p, scale_mode, mask, &nfb))) return rc;
-  if (nfb > 0 && (rc = trf_fallback_stage(p, dJ, df, ldJ, scale_mode))) return rc;
+  if (nfb > 0 && (rc = trf_fallback_stage(p, dJ, df, ldJ, scale_mode, nfb))) return rc;
   return trf_finish(p);
 }
 
@@ -1433,6 +1440,7 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
   c.Gsrc = t.gram_keep.as<double>(); c.G = p->st.X; c.NPAD = p->ld; c.n = p->n;
   c.ncols_dev = p->st.ncols; c.gather = p->st.free_idx; c.stride_vec = p->ld;
   c.mask = mask; c.fb_mask = t.fb_mask(); c.fail_count = t.fb_count(); c.path_out = t.path_rw();
+  c.fail_list = t.fb_list();
   c.dsc = t.gram_dsc.as<double>();
   c.rinv = t.gram_rinv.as<double>(); c.ywork = t.gram_ywork.as<double>(); c.k2_out = t.gram_k2.as<double>();
   c.colinfo = p->colinfo.as<double>();
@@ -1450,7 +1458,7 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
   const int nfb = ctx->pinned[1];
   t.note_paths(ctx, nfb, mask != nullptr);
   if (nfb > 0) {
-    if ((rc = t.run_levels(ctx, dJ, df, ldJ, t.fb_mask()))) return rc;
+    if ((rc = t.run_levels(ctx, dJ, df, ldJ, t.fb_mask(), t.fb_list(), nfb))) return rc;
     ctx->begin(K_PREP);
     e = launch_dog_prep(p->st, scale_mode, 0, t.fb_mask(), 1, ctx->stream);
     ctx->end();

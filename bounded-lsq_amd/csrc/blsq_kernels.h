@@ -85,6 +85,7 @@ struct GramCholArgs {
   const int* mask;        // optional, as above
   int* fb_mask;           // optional [B] out: n + 1 if the problem needs the Householder tree, else 0
   int* fail_count;        // [1] number of such problems (caller zeroes it)
+  int* fail_list;         // optional [B] out: their indices, compacted (order of arrival: launch lists only)
   double* dsc;            // optional [B][NPAD] out: column scales 1 / ||J_j||
   double* colinfo;        // optional [B][2] out: min_j sqrt(h_jj), sum_j h_jj over the first n columns
   double* rinv;           // optional [B][NPAD/16][256] out: inverses of the diagonal tiles of R' (row-major)

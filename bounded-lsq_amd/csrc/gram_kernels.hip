@@ -699,7 +699,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
   psync();
   if (bad) {                                            // uniform: hand the problem to the QR tree
     if (tid == 0 && a.fb_mask) {
-      a.fb_mask[b] = a.n + 1; atomicAdd(a.fail_count, 1);   // (the tree factors ALL n + 1 columns)
+      a.fb_mask[b] = a.n + 1; { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }   // (the tree factors ALL n + 1 columns)
       if (a.path_out) a.path_out[b] = a.n + 1;
     }
     return;
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
     const bool fail = !(pminsh >= GRAM_SMIN * GRAM_SMIN);
     a.fb_mask[b] = fail ? a.n + 1 : 0;
     if (a.path_out) a.path_out[b] = fail ? a.n + 1 : 0;
-    if (fail) atomicAdd(a.fail_count, 1);
+    if (fail) { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
   }
 }
 
@@ -913,7 +913,7 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
   __syncthreads();
   if (bad) {
     if (tid == 0 && a.fb_mask) {
-      a.fb_mask[b] = a.n + 1; atomicAdd(a.fail_count, 1);   // (the tree factors ALL n + 1 columns)
+      a.fb_mask[b] = a.n + 1; { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }   // (the tree factors ALL n + 1 columns)
       if (a.path_out) a.path_out[b] = a.n + 1;
     }
     return;
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
     const bool fail = !(pminsh >= GRAM_SMIN * GRAM_SMIN);
     a.fb_mask[b] = fail ? a.n + 1 : 0;
     if (a.path_out) a.path_out[b] = fail ? a.n + 1 : 0;
-    if (fail) atomicAdd(a.fail_count, 1);
+    if (fail) { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
   }
 }
 
@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_cond_kernel(GramCholArgs a) {
     if (!(k2 <= GRAM_K2_MAX)) {                          // (NaN fails)
       a.fb_mask[b] = a.n + 1;
       if (a.path_out) a.path_out[b] = a.n + 1;
-      atomicAdd(a.fail_count, 1);
+      { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
     }
   }
 }
