@@ -452,6 +452,8 @@ struct blsq_trf_plan {
   DevBuf lm_Xa, lm_ints, lm_sc, lm_ph, lm_sa;
   LmState lm{};
   int lm_enable = 1;
+  bool gate_done = false;           // lm_gate already ran in this factor call (no problem left the normal-equations path)
+  int njac = -1;                    // problems it sent to the Jacobi SVD (-1: unknown)
 };
 
 struct blsq_dogbox_plan {
@@ -461,6 +463,8 @@ struct blsq_dogbox_plan {
   DevBuf S, X, vecs, ivecs, scal2, sweeps, active, onb;
   DevBuf o_vec, o_onb, o_scal, o_info;
   DevBuf in_J, in_f, in_vec, in_scal;
+  bool gate_done = false;           // as blsq_trf_plan
+  int njac = -1;
   DevBuf gate_ints;                 // [2B] fast flags, Jacobi launch mask
   DevBuf colinfo;                   // [B][2] column-norm summary of the free block (Gram-path problems)
   int svdfree_enable = 1;
@@ -759,10 +763,16 @@ int trf_finish(blsq_trf_plan* p) {
     if (e != hipSuccess) return ctx->fail(e, "launch_qr(aug)");
   }
   // rank gate: clearly full-rank problems skip the SVD (lm_kernels.hip)
-  ctx->begin(K_LM_GATE);
-  e = launch_lm_gate(p->lm, p->lm_enable, ctx->stream);
-  ctx->end();
-  if (e != hipSuccess) return ctx->fail(e, "launch_lm_gate");
+  if (!p->gate_done) {
+    p->lm.jac_count = nullptr;
+    ctx->begin(K_LM_GATE);
+    e = launch_lm_gate(p->lm, p->lm_enable, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_lm_gate");
+    p->njac = -1;
+  }
+  p->gate_done = false;
+  if (p->njac == 0) return 0;             // nobody needs the SVD: no launch
   JacobiArgs ja{};
   ja.X = p->st.X; ja.strideX = (long)p->ld * p->ld; ja.ld = p->ld; ja.ncols_dev = p->lm.ncols_jac;
   ja.N = p->n + 1; ja.s = p->st.s; ja.uf = p->st.uf; ja.srange = p->st.srange;
@@ -780,6 +790,7 @@ int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode) {
   p->path = nullptr; p->use_chol = false; p->use_qr = true;
   p->lm.path = nullptr; p->lm.colinfo = nullptr;
   p->tree.path_valid = false; p->tree.any_gram = false; p->tree.any_qr = true;
+  p->gate_done = false;
   ctx->begin(K_PREP);
   hipError_t e = launch_trf_prep(p->st, scale_mode, 0, nullptr, 0, ctx->stream);
   ctx->end();
@@ -792,7 +803,7 @@ int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode) {
 int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb) {
   blsq_ctx* ctx = p->ctx;
   QrTree& t = p->tree;
-  HIPCHK(ctx, hipMemsetAsync(t.fb_count(), 0, sizeof(int), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(t.fb_count(), 0, 2 * sizeof(int), ctx->stream));
   p->st.Rt = t.Rfinal(); p->st.Gk = t.gram_keep.as<double>(); p->st.path = t.path_rw();
   ctx->begin(K_PREP);
   hipError_t e = launch_trf_prep(p->st, scale_mode, 1, mask, 0, ctx->stream);
@@ -814,10 +825,22 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb) 
   e = launch_gram_gate(c, p->B, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_gram_gate");
-  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 1, t.fb_count(), sizeof(int), hipMemcpyDeviceToHost,
+  // The rank gate of the trust-region solver runs BEFORE the verdict is read back: in the common case
+  // (no problem leaves this path) its result stands, and the same read-back tells whether anybody
+  // needs the Jacobi SVD at all.  (The step counters of the memset above: [0] failed, [1] to the SVD.)
+  p->lm.path = t.path_rw();
+  p->lm.colinfo = p->aug_colinfo.as<double>();
+  p->lm.jac_count = t.fb_count() + 1;
+  ctx->begin(K_LM_GATE);
+  e = launch_lm_gate(p->lm, p->lm_enable, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_lm_gate");
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 1, t.fb_count(), 2 * sizeof(int), hipMemcpyDeviceToHost,
                              ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   *nfb = ctx->pinned[1];
+  p->gate_done = (*nfb == 0);
+  p->njac = p->gate_done ? ctx->pinned[2] : -1;
   t.note_paths(ctx, *nfb, mask != nullptr);
   p->path = t.path_rw();
   p->use_chol = t.any_gram;
@@ -1383,19 +1406,25 @@ int dog_finish(blsq_dogbox_plan* p, const int* path, bool any_qr, bool any_gram)
   int* gfast = p->gate_ints.as<int>();
   int* gmask = gfast + p->B;
   p->st.fast = gfast;
-  ctx->begin(K_LM_GATE);
-  e = launch_dog_gate_solve(p->st, gfast, gmask, p->svdfree_enable, path,
-                            (path && any_gram) ? p->colinfo.as<double>() : nullptr, ctx->stream);
-  ctx->end();
-  if (e != hipSuccess) return ctx->fail(e, "launch_dog_gate_solve");
-  JacobiArgs ja{};
-  ja.X = p->st.X; ja.strideX = (long)p->ld * p->ld; ja.ld = p->ld; ja.ncols_dev = gmask;
-  ja.N = p->n + 1; ja.s = p->st.s; ja.uf = p->st.uf; ja.srange = p->st.srange;
-  ja.sweeps = p->sweeps.as<int>(); ja.max_sweeps = 40;
-  ctx->begin(K_JACOBI);
-  e = launch_jacobi(ja, p->B, ctx->stream);
-  ctx->end();
-  if (e != hipSuccess) return ctx->fail(e, "launch_jacobi");
+  if (!p->gate_done) {
+    ctx->begin(K_LM_GATE);
+    e = launch_dog_gate_solve(p->st, gfast, gmask, p->svdfree_enable, path,
+                              (path && any_gram) ? p->colinfo.as<double>() : nullptr, nullptr, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_dog_gate_solve");
+    p->njac = -1;
+  }
+  p->gate_done = false;
+  if (p->njac != 0) {
+    JacobiArgs ja{};
+    ja.X = p->st.X; ja.strideX = (long)p->ld * p->ld; ja.ld = p->ld; ja.ncols_dev = gmask;
+    ja.N = p->n + 1; ja.s = p->st.s; ja.uf = p->st.uf; ja.srange = p->st.srange;
+    ja.sweeps = p->sweeps.as<int>(); ja.max_sweeps = 40;
+    ctx->begin(K_JACOBI);
+    e = launch_jacobi(ja, p->B, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_jacobi");
+  }
   ctx->begin(K_STEP);
   e = launch_dog_solve(p->st, gfast, ctx->stream);
   ctx->end();
@@ -1408,6 +1437,7 @@ int dog_after_triangle(blsq_dogbox_plan* p, int scale_mode) {
   blsq_ctx* ctx = p->ctx;
   p->st.Rt = p->tree.Rfinal(); p->st.Gk = nullptr; p->st.path = nullptr;
   p->tree.path_valid = false; p->tree.any_gram = false; p->tree.any_qr = true;
+  p->gate_done = false;
   ctx->begin(K_PREP);
   hipError_t e = launch_dog_prep(p->st, scale_mode, 0, nullptr, 0, ctx->stream);
   ctx->end();
@@ -1430,7 +1460,7 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
     return dog_after_triangle(p, scale_mode);
   }
   if ((rc = t.run_gram_only(ctx, dJ, df, ldJ, mask, false))) return rc;
-  HIPCHK(ctx, hipMemsetAsync(t.fb_count(), 0, sizeof(int), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(t.fb_count(), 0, 2 * sizeof(int), ctx->stream));
   p->st.Rt = t.Rfinal(); p->st.Gk = t.gram_keep.as<double>(); p->st.path = t.path_rw();
   ctx->begin(K_PREP);
   hipError_t e = launch_dog_prep(p->st, scale_mode, 1, mask, 0, ctx->stream);
@@ -1452,10 +1482,21 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
   e = launch_gram_gate(c, p->B, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_gram_gate");
-  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 1, t.fb_count(), sizeof(int), hipMemcpyDeviceToHost,
+  {                                         // rank gate + Newton / Cauchy steps before the read-back (as TRF)
+    int* gfast = p->gate_ints.as<int>();
+    p->st.fast = gfast;
+    ctx->begin(K_LM_GATE);
+    e = launch_dog_gate_solve(p->st, gfast, gfast + p->B, p->svdfree_enable, t.path_rw(),
+                              p->colinfo.as<double>(), t.fb_count() + 1, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_dog_gate_solve");
+  }
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 1, t.fb_count(), 2 * sizeof(int), hipMemcpyDeviceToHost,
                              ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   const int nfb = ctx->pinned[1];
+  p->gate_done = (nfb == 0);
+  p->njac = p->gate_done ? ctx->pinned[2] : -1;
   t.note_paths(ctx, nfb, mask != nullptr);
   if (nfb > 0) {
     if ((rc = t.run_levels(ctx, dJ, df, ldJ, t.fb_mask(), t.fb_list(), nfb))) return rc;

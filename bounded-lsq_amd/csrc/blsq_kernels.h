@@ -179,6 +179,7 @@ struct LmState {
   int* st;                // [B][4]  it, phase, n_iter
   double* ph;             // [B][ld] p_h of the SVD-free path
   int* active_count;      // [1] problems that need another evaluation
+  int* jac_count;         // optional [1]: lm_gate adds the number of problems it sends to the Jacobi SVD
   int* active_list;       // [2][B] their indices, compacted (list r & 1 feeds evaluation r)
   const double* colinfo;  // optional [B][2] from the augmented Cholesky (Gram-path problems): min / sum of
                           // the squared column norms of R_aug — a cheap sufficient test for the rank gate
@@ -220,7 +221,7 @@ hipError_t launch_dog_prep(const DogState& st, int jac_scaling, int from_gram, c
 hipError_t launch_dog_solve(const DogState& st, const int* skip, hipStream_t s);
 // path / colinfo (optional): Gram-path flags and the column-norm summary of the free block
 hipError_t launch_dog_gate_solve(const DogState& st, int* fast, int* ncols_jac, int enable,
-                                 const int* path, const double* colinfo, hipStream_t s);
+                                 const int* path, const double* colinfo, int* jac_count, hipStream_t s);
 
 struct DogStepOut {
   double* step;           // [B][ld]  full length

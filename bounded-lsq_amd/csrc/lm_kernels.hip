@@ -130,6 +130,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_gate_kernel(LmState lm, int enable)
   }
   if (tid == 0) {
     lm.fast[b] = ok;
+    if (!ok && lm.jac_count) atomicAdd(lm.jac_count, 1);
     lm.ncols_jac[b] = ok ? 0 : N;
     lm.sc[(long)b * 16 + SC_SMAX] = smax;
     lm.sc[(long)b * 16 + SC_SMIN] = smin;
@@ -313,7 +314,7 @@ hipError_t launch_lm_update(const LmState& lm, int active, hipStream_t s) {
 __global__ __launch_bounds__(TRI_NT) void dog_gate_solve_kernel(DogState st, int* fast,
                                                                 int* ncols_jac, int enable,
                                                                 const int* path,
-                                                                const double* colinfo) {
+                                                                const double* colinfo, int* jac_count) {
   extern __shared__ double sh[];
   __shared__ double red[32];
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -394,15 +395,18 @@ __global__ __launch_bounds__(TRI_NT) void dog_gate_solve_kernel(DogState st, int
     tri_solve_upper_pf(R, nf, ld, invd, v, pfbuf);
     for (int i = tid; i < nf; i += TRI_NT) st.newton[(long)b * ld + i] = -v[i];
   }
-  if (tid == 0) { fast[b] = ok; ncols_jac[b] = ok ? 0 : N; }
+  if (tid == 0) {
+    fast[b] = ok; ncols_jac[b] = ok ? 0 : N;
+    if (!ok && jac_count) atomicAdd(jac_count, 1);
+  }
 }
 
 hipError_t launch_dog_gate_solve(const DogState& st, int* fast, int* ncols_jac, int enable,
-                                 const int* path, const double* colinfo, hipStream_t s) {
+                                 const int* path, const double* colinfo, int* jac_count, hipStream_t s) {
   const size_t lds = sizeof(double) * (3 + 32) * (size_t)st.ld;
   { static std::atomic<size_t> granted[64]; hipError_t ge = grant_lds(dog_gate_solve_kernel, lds, granted); if (ge != hipSuccess) return ge; }
   hipLaunchKernelGGL(dog_gate_solve_kernel, dim3(st.B), dim3(TRI_NT), lds, s, st, fast,
-                     ncols_jac, enable, path, colinfo);
+                     ncols_jac, enable, path, colinfo, jac_count);
   return hipGetLastError();
 }
 
