@@ -49,7 +49,9 @@ struct blsq_ctx {
   struct Pending { int slot; hipEvent_t a, b; };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> pool;
-  int* pinned = nullptr;            // 4 pinned host ints: device -> host counters without staging
+  int* pinned = nullptr;            // 32 pinned host ints: device -> host counters without staging
+                                    // ([0..3] one-shot read-backs, [8 + r] Newton-round counters)
+  hipEvent_t lm_ev[2] = {nullptr, nullptr};   // read-back of the counter of round r has landed (r & 1)
   long long gram_fast = 0, gram_fallback = 0;   // problems factored by the normal equations / handed to the QR tree
   // collective over the ranks of one tall problem (RCCL over xGMI; blsq_comm_*)
   ncclComm_t comm = nullptr;
@@ -453,6 +455,7 @@ struct blsq_trf_plan {
   LmState lm{};
   int lm_enable = 1;
   bool gate_done = false;           // lm_gate already ran in this factor call (no problem left the normal-equations path)
+  int lm_expect0 = 0;               // problems the first Newton round of the last step call worked on (kernel choice hint)
   int njac = -1;                    // problems it sent to the Jacobi SVD (-1: unknown)
 };
 
@@ -494,8 +497,10 @@ extern "C" int blsq_ctx_create(int device_id, blsq_ctx** out) {
   c->device = device_id;
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return (int)e; }
-  e = hipHostMalloc((void**)&c->pinned, 4 * sizeof(int), hipHostMallocDefault);
+  e = hipHostMalloc((void**)&c->pinned, 32 * sizeof(int), hipHostMallocDefault);
   if (e != hipSuccess) { hipStreamDestroy(c->stream); delete c; return (int)e; }
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->lm_ev[i], hipEventDisableTiming);
+  if (e != hipSuccess) { hipHostFree(c->pinned); hipStreamDestroy(c->stream); delete c; return (int)e; }
   *out = c;
   return 0;
 }
@@ -508,6 +513,7 @@ extern "C" int blsq_ctx_destroy(blsq_ctx* ctx) {
   if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
   ctx->comm = nullptr;
   for (auto e : ctx->pool) hipEventDestroy(e);
+  for (auto e : ctx->lm_ev) if (e) hipEventDestroy(e);
   hipStreamDestroy(ctx->stream);
   if (ctx->pinned) hipHostFree(ctx->pinned);
   delete ctx;
@@ -697,7 +703,7 @@ int trf_alloc_state(blsq_trf_plan* p) {
   p->out.info = p->o_info.as<int>();
   ALLOC(p->lm_sa, sizeof(double) * (size_t)B);
   ALLOC(p->lm_Xa, sizeof(double) * B * mat);
-  ALLOC(p->lm_ints, sizeof(int) * ((size_t)B * 9 + 4));
+  ALLOC(p->lm_ints, sizeof(int) * ((size_t)B * 9 + 16));
   ALLOC(p->aug_colinfo, sizeof(double) * (size_t)B * 2);
   ALLOC(p->lm_sc, sizeof(double) * (size_t)B * 16);
   ALLOC(p->lm_ph, sizeof(double) * vs);
@@ -710,7 +716,7 @@ int trf_alloc_state(blsq_trf_plan* p) {
     int* ii = p->lm_ints.as<int>();
     lm.fast = ii; lm.ncols_jac = ii + B; lm.ncols_lm = ii + 2 * (size_t)B; lm.st = ii + 3 * (size_t)B;
     lm.active_count = ii + 7 * (size_t)B;
-    lm.active_list = ii + 7 * (size_t)B + 4; lm.round = 0;
+    lm.active_list = ii + 7 * (size_t)B + 16; lm.round = 0;
     lm.sc = p->lm_sc.as<double>(); lm.ph = p->lm_ph.as<double>();
     // The SVD-free Newton iteration costs one small stacked QR per iteration.  Measured
     // (8192..16384 problems per launch, Delta mix 10/0.5; SVD-free vs Jacobi-SVD step-solves/s):
@@ -880,31 +886,75 @@ int trf_factor_core(blsq_trf_plan* p, const double* dJ, const double* df, int ld
 }
 
 // Safeguarded Newton iteration of the SVD-free problems: lock-step rounds of
-// (stacked QR of [R_aug; sqrt(alpha) I]) + (two triangular solves + update).
+// (factor of the system at the current alpha) + (two triangular solves + update).
+//
+// The kernels of round r run over the compacted list of the problems still iterating and leave
+// when their index is beyond the DEVICE counter of that round, so the host does not have to know
+// the count to launch them — only an upper bound (the previous round's count).  When every problem
+// is on the normal-equations path the host therefore runs one round AHEAD of what it knows: it
+// enqueues round r, then waits for the counter of round r (written by round r - 1, i.e. while
+// round r executes).  The GPU never idles on a host round trip; the price is one round of empty
+// launches at the end.  Problems on the Householder path (stacked QR per round: several launches
+// sized by the count) keep the synchronous loop.
 int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_in) {
   blsq_ctx* ctx = p->ctx;
-  int active = 0;
-  HIPCHK(ctx, hipMemsetAsync(p->lm.active_count, 0, sizeof(int), ctx->stream));
+  int* counts = p->lm.active_count;
+  HIPCHK(ctx, hipMemsetAsync(counts, 0, 16 * sizeof(int), ctx->stream));
   ctx->begin(K_LM_SOLVE);
   hipError_t e = launch_lm_start(p->lm, dDelta, dalpha_in, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_lm_start");
-  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, p->lm.active_count, sizeof(int), hipMemcpyDeviceToHost,
-                             ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  active = ctx->pinned[0];
-  for (int round = 0; round < 12 && active > 0; ++round) {
-    HIPCHK(ctx, hipMemsetAsync(p->lm.active_count, 0, sizeof(int), ctx->stream));
-    if (p->use_chol) {
-      // R_alpha = chol(D G D + E^2 + alpha I) straight from the Gram, active Gram-path problems
-      GramCholArgs c{};
-      c.Gsrc = p->tree.gram_keep.as<double>(); c.G = p->lm.Xa; c.NPAD = p->ld; c.n = p->n;
-      c.colscale = p->st.d; c.diag_vec = p->st.ediag; c.diag_sqrt = p->lm.sa; c.stride_vec = p->ld;
-      c.batch_list = p->lm.active_list + (size_t)(round & 1) * p->B;
-      c.skip_path = p->path;
-      ctx->begin(K_LM_CHOL);
-      e = launch_gram_chol(c, active, ctx->stream);
+  int* pin = ctx->pinned + 8;
+  auto read_back = [&](int r) -> hipError_t {            // counter of round r -> pin[r], event r & 1
+    hipError_t ee = hipMemcpyAsync(pin + r, counts + r, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (ee == hipSuccess) ee = hipEventRecord(ctx->lm_ev[r & 1], ctx->stream);
+    return ee;
+  };
+  auto chol_round = [&](int round, int grid, int expect, const int* count_dev) -> hipError_t {
+    // R_alpha = chol(D G D + E^2 + alpha I) straight from the Gram, active Gram-path problems
+    GramCholArgs c{};
+    c.Gsrc = p->tree.gram_keep.as<double>(); c.G = p->lm.Xa; c.NPAD = p->ld; c.n = p->n;
+    c.colscale = p->st.d; c.diag_vec = p->st.ediag; c.diag_sqrt = p->lm.sa; c.stride_vec = p->ld;
+    c.batch_list = p->lm.active_list + (size_t)(round & 1) * p->B;
+    c.skip_path = p->path;
+    c.count_dev = count_dev; c.expect = expect;
+    ctx->begin(K_LM_CHOL);
+    hipError_t ee = launch_gram_chol(c, grid, ctx->stream);
+    ctx->end();
+    return ee;
+  };
+  HIPCHK(ctx, read_back(0));
+  if (!p->use_qr && p->use_chol && p->lm_enable) {
+    int bound = p->B;                                   // upper bound of the count of the round being enqueued
+    int expect = p->lm_expect0 > 0 ? p->lm_expect0 : p->B;   // (kernel choice only: last call's first count)
+    if (p->lm_expect0 < 0) {
+      // the last call needed no round at all: look before launching an empty one
+      HIPCHK(ctx, hipEventSynchronize(ctx->lm_ev[0]));
+      if (pin[0] == 0) return 0;
+      bound = expect = pin[0];
+    }
+    for (int round = 0; round < 12; ++round) {
+      e = chol_round(round, bound, expect, counts + round);
+      if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(lm)");
+      ctx->begin(K_LM_SOLVE);
+      p->lm.round = round;
+      e = launch_lm_update(p->lm, bound, ctx->stream);
       ctx->end();
+      if (e != hipSuccess) return ctx->fail(e, "launch_lm_update");
+      HIPCHK(ctx, read_back(round + 1));
+      HIPCHK(ctx, hipEventSynchronize(ctx->lm_ev[round & 1]));
+      const int active = pin[round];                    // what round `round` really worked on
+      if (round == 0) p->lm_expect0 = active > 0 ? active : -1;
+      if (active == 0) break;                           // (the round just enqueued is empty)
+      bound = expect = active;
+    }
+    return 0;
+  }
+  HIPCHK(ctx, hipEventSynchronize(ctx->lm_ev[0]));
+  int active = pin[0];
+  for (int round = 0; round < 12 && active > 0; ++round) {
+    if (p->use_chol) {
+      e = chol_round(round, active, active, nullptr);
       if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(lm)");
     }
     if (p->use_qr) {
@@ -928,10 +978,9 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
     e = launch_lm_update(p->lm, active, ctx->stream);
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_lm_update");
-    HIPCHK(ctx, hipMemcpyAsync(ctx->pinned, p->lm.active_count, sizeof(int), hipMemcpyDeviceToHost,
-                               ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    active = ctx->pinned[0];
+    HIPCHK(ctx, read_back(round + 1));
+    HIPCHK(ctx, hipEventSynchronize(ctx->lm_ev[(round + 1) & 1]));
+    active = pin[round + 1];
   }
   return 0;
 }

@@ -76,6 +76,8 @@ struct GramCholArgs {
   long stride_vec;
   const int* batch_list;  // optional compacted problem indices (grid = their number)
   int count;              // problems of this launch (set by launch_gram_chol)
+  const int* count_dev;   // optional [1]: the launch is over an upper bound; entries beyond *count_dev leave
+  int expect;             // > 0: number of problems the launch is expected to work on (kernel choice; default: its size)
   // optional principal sub-matrix (dogbox: free columns ++ rhs): H = Gsrc[idx, idx] with
   // idx = gather[b][0 .. N_b-2] ++ [n], N_b = ncols_dev[b] (0: nothing to do); gather is increasing
   const int* ncols_dev;   // [B]
@@ -178,7 +180,9 @@ struct LmState {
   double* sc;             // [B][16] alpha, lo, hi, phi, dphi, Delta, smax_est, smin_est
   int* st;                // [B][4]  it, phase, n_iter
   double* ph;             // [B][ld] p_h of the SVD-free path
-  int* active_count;      // [1] problems that need another evaluation
+  int* active_count;      // [16] active_count[r] = problems that need evaluation r (zeroed per step call);
+                          // the kernels of evaluation r leave when their index is beyond it, so the
+                          // host may launch them over an upper bound without knowing the count
   int* jac_count;         // optional [1]: lm_gate adds the number of problems it sends to the Jacobi SVD
   int* active_list;       // [2][B] their indices, compacted (list r & 1 feeds evaluation r)
   const double* colinfo;  // optional [B][2] from the augmented Cholesky (Gram-path problems): min / sum of
@@ -190,7 +194,7 @@ struct LmState {
 hipError_t launch_lm_gate(const LmState& lm, int enable, hipStream_t s);
 hipError_t launch_lm_start(const LmState& lm, const double* Delta, const double* alpha_in,
                            hipStream_t s);
-hipError_t launch_lm_update(const LmState& lm, int active, hipStream_t s);   // grid = active problems of lm.round
+hipError_t launch_lm_update(const LmState& lm, int active, hipStream_t s);   // grid = (upper bound of the) active problems of lm.round
 
 // -------------------------------------------------------------- dogbox ----
 struct DogState {

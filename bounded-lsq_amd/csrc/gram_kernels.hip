@@ -470,6 +470,205 @@ __global__ __launch_bounds__(GR_NT, 2) void gram16_kernel(GramArgs a) {
   }
 }
 
+// ---- 8 column tiles (n = 113 .. 128): static tile rows per wave, k-steps split over two groups ----
+// The scheme of gram16_kernel for half the width: the 36 upper tiles of an 8 x 8 tile grid are four
+// pairs of tile rows (P, 7 - P) of 9 tiles each — four waves' worth.  The other four waves take the
+// same tiles for the OTHER k-steps: wave W = P + 4 K works on k-steps s with s % 2 == K (K = 0, 1), so
+// every wave has 9 MFMAs per k-step it owns and 8 - P operand fragments to fetch for them (the
+// generic kernel runs these widths as 8 slots per wave and k-step with two reads per MFMA and idle
+// slots recomputing a tile).  A tile is therefore the sum of two partial accumulations — even and odd
+// k-steps — added in that order at the end (through LDS, once per row chunk).  This order is the
+// DEFINITION of the result for these widths: the kernel serves every batch size (no tile groups), so
+// a problem's bits still do not depend on its batch.  Row chunks, staging and the rhs column are
+// those of the generic kernel.
+template <int W, bool RHS>
+__device__ __forceinline__ void gram8_wave(const GramArgs& a, double* lds) {
+  constexpr int NTJ = 8, NCB = 2;
+  constexpr int P = W % 4, K = W / 4;
+  constexpr int NF = NTJ - P;                           // fragments per k-step: column tiles P .. 7
+  constexpr int N0 = NTJ - P, N1 = P + 1;               // tiles of tile row P / of tile row 7 - P
+  constexpr int A1 = NTJ - 1 - 2 * P;                   // fragment index of tile row 7 - P
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int lr = lane >> 4, lc = lane & 15;
+  const int n = a.n, N = n + 1;
+  const int NT = (N + 15) / 16;                        // 8 or 9
+  constexpr int LDX = 144;                              // gram_ldx(8) == gram_ldx(9)
+  const int r_lo = blockIdx.x * a.rows_per_chunk;
+  int r_hi = r_lo + a.rows_per_chunk;
+  if (r_hi > a.m) r_hi = a.m;
+  const int m = r_hi;
+  const double* Jb = a.J + (long)b * a.strideJ;
+  const double* Fb = a.F + (long)b * a.strideF;
+
+  constexpr int HR = GR_RC / GR_NW / 2;                 // rows per wave per half chunk
+  double pre[HR][NCB], fpre[HR];
+  double gf[NCB] = {0.0, 0.0}, gff = 0.0;
+  auto issue = [&](int row0, int h) {
+#pragma unroll
+    for (int rr = 0; rr < HR; ++rr) {
+      const int row = row0 + W + GR_NW * (HR * h + rr);
+      const int rc = row < m ? row : m - 1;
+      fpre[rr] = Fb[rc];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int col = lane + 64 * cb;
+        const int cc = col < n ? col : n - 1;
+        pre[rr][cb] = __builtin_nontemporal_load(Jb + (long)rc * a.ldJ + cc);
+      }
+    }
+  };
+  auto commit = [&](int row0, int h, double* X) {
+#pragma unroll
+    for (int rr = 0; rr < HR; ++rr) {
+      const int lrow = W + GR_NW * (HR * h + rr);
+      const bool in = row0 + lrow < m;
+      const double fv = in ? fpre[rr] : 0.0;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int col = lane + 64 * cb;
+        if (col < n) X[lrow * LDX + col] = in ? pre[rr][cb] : 0.0;
+        if (RHS) gf[cb] = fma(pre[rr][cb], fv, gf[cb]);
+      }
+      if (RHS) gff = fma(fv, fv, gff);
+      else if (lane == 0) X[lrow * LDX + n] = fv;
+    }
+  };
+
+  v4d acc0[N0], acc1[N1];
+#pragma unroll
+  for (int t = 0; t < N0; ++t) acc0[t] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int t = 0; t < N1; ++t) acc1[t] = v4d{0.0, 0.0, 0.0, 0.0};
+
+  double* X0 = lds;
+  double* X1 = lds + GR_RC * LDX;
+  for (int idx = tid; idx < 2 * GR_RC * (LDX - N); idx += GR_NT) {   // padding columns stay zero
+    const int r = idx / (LDX - N), c = idx - r * (LDX - N);
+    lds[r * LDX + N + c] = 0.0;
+  }
+  if (RHS) {
+    for (int r = tid; r < 2 * GR_RC; r += GR_NT) lds[r * LDX + n] = 0.0;
+  }
+  if (r_lo < m) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { issue(r_lo, h); commit(r_lo, h, X0); }
+  }
+  __syncthreads();
+
+  double fr[2][NF];
+  auto wait_set = [&](double (&f)[NF]) {
+    if constexpr (NF == 8)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]),
+                   "+v"(f[5]), "+v"(f[6]), "+v"(f[7]));
+    else if constexpr (NF == 7)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]),
+                   "+v"(f[5]), "+v"(f[6]));
+    else if constexpr (NF == 6)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]),
+                   "+v"(f[5]));
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]));
+  };
+  int cidx = 0;
+  for (int row0 = r_lo; row0 < m; row0 += GR_RC, ++cidx) {
+    const bool more = row0 + GR_RC < m;
+    const double* X = (cidx & 1) ? X1 : X0;
+    double* Xn = (cidx & 1) ? X0 : X1;
+    const unsigned xb = lds_addr(X) + 8u * (unsigned)(lr * LDX + lc);
+    static_for<0, NF>([&](auto ic) {
+      constexpr int c = decltype(ic)::value;
+      lds_read64_off<8 * (4 * K * LDX + 16 * (P + c))>(fr[0][c], xb);
+    });
+    static_for<0, 4>([&](auto iq) {
+      constexpr int q = decltype(iq)::value;            // this wave's q-th k-step of the chunk: s = 2 q + K
+      constexpr int cur = q & 1, nxt = cur ^ 1;
+      if constexpr (q == 0 || q == 2) {
+        if (more) issue(row0 + GR_RC, q / 2);
+      }
+      wait_set(fr[cur]);
+      static_for<0, N0 + N1>([&](auto it) {
+        constexpr int t = decltype(it)::value;
+        if constexpr (t < N0) acc0[t] = gmfma(fr[cur][0], fr[cur][t], acc0[t]);
+        else acc1[t - N0] = gmfma(fr[cur][A1], fr[cur][A1 + (t - N0)], acc1[t - N0]);
+        if constexpr (q < 3 && t < NF)
+          lds_read64_off<8 * (4 * (2 * (q + 1) + K) * LDX + 16 * (P + t))>(fr[nxt][t], xb);
+      });
+      if constexpr (q == 1 || q == 3) {
+        if (more) commit(row0 + GR_RC, q / 2, Xn);
+      }
+    });
+    __syncthreads();
+  }
+
+  // the odd k-steps' partial tiles -> LDS, the even group adds them (even first) and stores
+  double* part = lds + (size_t)P * (NTJ + 1) * 256;     // [pair][tile][256]
+  if (K == 1) {
+#pragma unroll
+    for (int t = 0; t < N0; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) part[t * 256 + g * 64 + lane] = acc0[t][g];
+#pragma unroll
+    for (int t = 0; t < N1; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) part[(N0 + t) * 256 + g * 64 + lane] = acc1[t][g];
+  }
+  __syncthreads();
+  double* G = a.G + ((long)b * gridDim.x + blockIdx.x) * (long)a.NPAD * a.NPAD;
+  if (K == 0) {
+#pragma unroll
+    for (int t = 0; t < N0; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        G[(long)(16 * P + lr + 4 * g) * a.NPAD + 16 * (P + t) + lc] = acc0[t][g] + part[t * 256 + g * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < N1; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        G[(long)(16 * (NTJ - 1 - P) + lr + 4 * g) * a.NPAD + 16 * (NTJ - 1 - P + t) + lc] =
+            acc1[t][g] + part[(N0 + t) * 256 + g * 64 + lane];
+  }
+  if (!RHS) return;
+  __syncthreads();                                      // (the partial tiles have been consumed)
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) lds[W * 128 + 64 * cb + lane] = gf[cb];
+  if (lane == 0) lds[GR_NW * 128 + W] = gff;
+  __syncthreads();
+  if (tid < n) {
+    double sum = 0.0;
+#pragma unroll
+    for (int ww = 0; ww < GR_NW; ++ww) sum += lds[ww * 128 + tid];
+    G[(long)tid * a.NPAD + n] = sum;
+  }
+  if (tid == 0) {
+    double sum = 0.0;
+#pragma unroll
+    for (int ww = 0; ww < GR_NW; ++ww) sum += lds[GR_NW * 128 + ww];
+    G[(long)n * a.NPAD + n] = sum;
+  }
+  for (int e = tid; e < a.NPAD * (16 * NT - N); e += GR_NT) {   // padding columns of the rhs tile column
+    const int r = e / (16 * NT - N), c = N + e % (16 * NT - N);
+    if ((r >> 4) <= (c >> 4)) G[(long)r * a.NPAD + c] = 0.0;
+  }
+}
+
+template <bool RHS>
+__global__ __launch_bounds__(GR_NT, 2) void gram8_kernel(GramArgs a) {
+  extern __shared__ double lds[];
+  if (a.mask && a.mask[blockIdx.y] <= 1) return;
+  const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  switch (w) {
+    case 0: gram8_wave<0, RHS>(a, lds); break;
+    case 1: gram8_wave<1, RHS>(a, lds); break;
+    case 2: gram8_wave<2, RHS>(a, lds); break;
+    case 3: gram8_wave<3, RHS>(a, lds); break;
+    case 4: gram8_wave<4, RHS>(a, lds); break;
+    case 5: gram8_wave<5, RHS>(a, lds); break;
+    case 6: gram8_wave<6, RHS>(a, lds); break;
+    default: gram8_wave<7, RHS>(a, lds); break;
+  }
+}
+
 // ---- narrow problems (NT <= 5 column tiles): no LDS staging ------------------------------------
 // The MFMA operand fragment of column tile c at k-step s is X[4 s + lr][16 c + lc]: 16 lanes read
 // 128 contiguous bytes of a row — a coalesced global load straight into the operand register.
@@ -595,6 +794,36 @@ __global__ void gram_reduce_kernel(const double* Gpart, int chunks, int NPAD, do
   for (int k = 0; k < chunks; ++k) s += src[(long)k * sz];
   Gout[(long)b * sz + idx] = s;
 }
+// Many row chunks (one very tall problem): eight thread groups sum eight contiguous ranges of the
+// chunks, the eight partial sums are added in range order.  (The order depends on the chunk count
+// only, i.e. on m — never on the batch.)
+constexpr int GRED_G = 8, GRED_W = 32;
+__global__ __launch_bounds__(GRED_G * GRED_W) void gram_reduce_wide_kernel(
+    const double* Gpart, int chunks, int NPAD, double* Gout, const int* mask) {
+  __shared__ double part[GRED_G][GRED_W];
+  const int b = blockIdx.y;
+  if (mask && mask[b] <= 1) return;
+  const long sz = (long)NPAD * NPAD;
+  const int e = threadIdx.x % GRED_W, g = threadIdx.x / GRED_W;
+  const long idx = (long)blockIdx.x * GRED_W + e;
+  const int r = (int)(idx / NPAD), c = (int)(idx % NPAD);
+  const bool live = idx < sz && (r >> 4) <= (c >> 4);
+  const int per = (chunks + GRED_G - 1) / GRED_G;
+  const int k0 = g * per, k1 = min(chunks, k0 + per);
+  double s0 = 0.0;
+  if (live) {
+    const double* src = Gpart + (long)b * chunks * sz + idx;
+    for (int k = k0; k < k1; ++k) s0 += __builtin_nontemporal_load(src + (long)k * sz);
+  }
+  part[g][e] = s0;
+  __syncthreads();
+  if (g == 0 && live) {
+    double s = part[0][e];
+#pragma unroll
+    for (int q = 1; q < GRED_G; ++q) s += part[q][e];
+    Gout[(long)b * sz + idx] = s;
+  }
+}
 
 // ---- equilibrated blocked Cholesky, in place in the triangle slot -------------------------------
 // Row block kb of R' :  S_j = C_{kb,j} - sum_{k<kb} R'_{k,kb}^T R'_{k,j}   (MFMA, operands from the
@@ -622,6 +851,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
   const int pslot = wv / NWP;                           // problem slot inside the workgroup
   const int pidx = (int)blockIdx.x * PPW + pslot;
   if (pidx >= a.count) return;                          // (NWP == 1 only: wave-uniform)
+  if (a.count_dev && pidx >= *a.count_dev) return;
   const int b = a.batch_list ? a.batch_list[pidx] : pidx;
   const int tid = (int)threadIdx.x % PT, lane = tid & 63;
   const int w = wv % NWP;
@@ -850,6 +1080,7 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
   __shared__ double pminsh;
   __shared__ int flagsh;                                // last diagonal tile handed to wave 0
   const int pidx = (int)blockIdx.x;
+  if (a.count_dev && pidx >= *a.count_dev) return;
   const int b = a.batch_list ? a.batch_list[pidx] : pidx;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1043,10 +1274,9 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
           } else {
 #pragma unroll
             for (int s = 0; s < 4; ++s) X = gmfma(Ri[(4 * s + lr) * 16 + lc], acc[t][s], X);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) Rrow[j * 256 + (lr + 4 * g) * 16 + lc] = X[g];
           }
           const double sj = sq[16 * j + lc];
+          const double dj = dl[16 * j + lc];
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int row = 16 * kb + lr + 4 * g;
@@ -1054,6 +1284,9 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
             double val = X[g] * sj;
             if (row >= n || row > colg || colg > n) val = 0.0;
             Gb[(unsigned)(row * NPAD + colg)] = val;
+            // the operand of the trailing updates is what the left-looking kernel reads back: the
+            // STORED entry times its column's equilibration — the two kernels agree bit for bit
+            if (j != kb) Rrow[j * 256 + (lr + 4 * g) * 16 + lc] = val * dj;
           }
         }
       }
@@ -1326,7 +1559,10 @@ bool gram_supported(int m, int n) {
 // a problem's Gram (and so every bit of its result) does not depend on how many problems share the
 // launch.  2048 rows; 1024 for very tall problems (one 250 000 x 128 row block of BASELINE config 5:
 // 245 workgroups fill the 256 CUs, 123 leave half of them idle).
-static int gram_chunk_rows(int m) { return m > 131072 ? 1024 : 2048; }
+static int gram_chunk_rows(int m) {
+  static const int tall_env = [] { const char* e = getenv("BLSQ_GRAM_TALL_ROWS"); return e ? atoi(e) : 0; }();
+  return m > 131072 ? (tall_env > 0 ? tall_env : 1024) : 2048;
+}
 int gram_chunks(int B, int m) {
   (void)B;
   const int r = gram_chunk_rows(m);
@@ -1385,6 +1621,27 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s) {
     }
   }
 #undef BLSQ_GRAM_DIRECT
+  {
+    // 8 column tiles of J^T J (n = 113 .. 128): the k-split static-tile kernel, for EVERY batch size
+    // (its summation order defines the result for these widths).  BLSQ_GRAM8 = 0: the generic kernel.
+    const char* g8e = getenv("BLSQ_GRAM8");
+    if (NTJ == 8 && !(g8e && g8e[0] == '0')) {
+      const size_t need = sizeof(double) * 4 * 9 * 256;          // partial tiles of the odd k-steps
+      const size_t l8 = lds > need ? lds : need;
+      if (a.rhs_valu) {
+        static std::atomic<size_t> granted[64];
+        hipError_t ge = gram_grant_lds(gram8_kernel<true>, l8, granted);
+        if (ge != hipSuccess) return ge;
+        hipLaunchKernelGGL((gram8_kernel<true>), dim3(chunks, B, 1), dim3(GR_NT), l8, s, a);
+      } else {
+        static std::atomic<size_t> granted[64];
+        hipError_t ge = gram_grant_lds(gram8_kernel<false>, l8, granted);
+        if (ge != hipSuccess) return ge;
+        hipLaunchKernelGGL((gram8_kernel<false>), dim3(chunks, B, 1), dim3(GR_NT), l8, s, a);
+      }
+      return hipGetLastError();
+    }
+  }
   const int ncb = (a.n + 63) / 64;
   // tile groups: enough workgroups to occupy the CUs when the batch is small (results identical)
   int tg = 1;
@@ -1442,8 +1699,12 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s) {
 hipError_t launch_gram_reduce(const double* Gpart, int chunks, int NPAD, double* Gout,
                               const int* mask, int B, hipStream_t s) {
   const long sz = (long)NPAD * NPAD;
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)((sz + 255) / 256), B), dim3(256), 0, s,
-                     Gpart, chunks, NPAD, Gout, mask);
+  if (chunks > 32)
+    hipLaunchKernelGGL(gram_reduce_wide_kernel, dim3((unsigned)((sz + GRED_W - 1) / GRED_W), B),
+                       dim3(GRED_G * GRED_W), 0, s, Gpart, chunks, NPAD, Gout, mask);
+  else
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)((sz + 255) / 256), B), dim3(256), 0, s,
+                       Gpart, chunks, NPAD, Gout, mask);
   return hipGetLastError();
 }
 hipError_t launch_gram_chol(const GramCholArgs& a_in, int B, hipStream_t s) {
@@ -1458,9 +1719,11 @@ hipError_t launch_gram_chol(const GramCholArgs& a_in, int B, hipStream_t s) {
     // the left-looking kernel, but one workgroup per CU instead of two — so it serves the launches
     // that cannot fill the CUs twice anyway (the Newton rounds), the left-looking one the rest.
     // BLSQ_CHOL_RL = 0 / 1 forces either.
-    static const int rl_env = [] { const char* e = getenv("BLSQ_CHOL_RL"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    // The two kernels agree bit for bit (same operands, same order), so the choice is speed only.
+    const char* rle = getenv("BLSQ_CHOL_RL");          // (read per launch: tests compare the two)
+    const int rl_env = rle ? (rle[0] == '0' ? 0 : 1) : -1;
     constexpr int ncu = 256;                           // MI355X: 8 XCDs x 32 CUs
-    const bool rl = rl_env >= 0 ? rl_env != 0 : B <= ncu;
+    const bool rl = rl_env >= 0 ? rl_env != 0 : (a.expect > 0 ? a.expect : B) <= ncu;
     if (rl) {
       const size_t lds = per + sizeof(double) * 256 * (size_t)(a.NPAD / 16);
       static std::atomic<size_t> granted[64];

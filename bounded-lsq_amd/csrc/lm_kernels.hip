@@ -225,6 +225,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_update_kernel(LmState lm) {
   extern __shared__ double sh[];
   __shared__ double red[32];
   // launched over the compacted list of evaluation lm.round; writes the next one
+  if ((int)blockIdx.x >= lm.active_count[lm.round]) return;   // (launched over an upper bound)
   const int b = lm.active_list[(long)(lm.round & 1) * lm.B + blockIdx.x], tid = threadIdx.x;
   if (!lm.fast[b]) return;
   int* st = lm.st + (long)b * 4;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_update_kernel(LmState lm) {
     lm.sa[b] = sqrt(alpha);
     lm.ncols_lm[b] = (next_phase != LM_IDLE && (!lm.path || lm.path[b] != 0)) ? n + 1 : 0;
     if (next_phase != LM_IDLE)
-      lm.active_list[(long)((lm.round + 1) & 1) * lm.B + atomicAdd(lm.active_count, 1)] = b;
+      lm.active_list[(long)((lm.round + 1) & 1) * lm.B + atomicAdd(lm.active_count + lm.round + 1, 1)] = b;
   }
 }
 

@@ -386,6 +386,74 @@ def test_static_tile_row_kernel_matches_the_generic_one_bit_for_bit(bl, monkeypa
             assert np.array_equal(outs[0][0], o[0])
 
 
+def test_both_cholesky_kernels_agree_bit_for_bit(bl, monkeypatch):
+    """N > 80: launches of at most 256 problems use the right-looking register kernel, larger ones the
+    left-looking one (BLSQ_CHOL_RL forces either).  Both apply the same operands in the same order —
+    the right-looking kernel publishes the STORED entry times its equilibration, exactly what the
+    left-looking one reads back — so which one ran (i.e. how many problems shared the launch, or were
+    still active in a Newton round) never shows in the results."""
+    from bounded_lsq import _synth, _abi
+    for (B, m, n, kind) in [(4, 1000, 200, "trf"), (3, 2100, 128, "trf"), (2, 4096, 256, "trf"),
+                            (4, 600, 100, "trf"), (4, 900, 120, "dogbox")]:
+        P = _synth.trf_batch(70 + n, B, m, n) if kind == "trf" else _synth.dogbox_batch(70 + n, B, m, n)
+        outs = []
+        for rl in ("0", "1"):
+            monkeypatch.setenv("BLSQ_CHOL_RL", rl)
+            ctx = _abi.Context(0)
+            got = []
+            if kind == "trf":
+                sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
+                sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+                for D in (0.7, 0.05, 5.0):
+                    S = sol.step(np.full(B, D), np.zeros(B))
+                    got += [S.step.copy(), np.asarray(S.alpha).copy(), S.predicted_reduction.copy()]
+            else:
+                sol = bl.DogboxStepSolver(B, m, n, ctx=ctx)
+                sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"], P["on_bound"])
+                for D in (0.7, 0.05):
+                    S = sol.step(np.full(B, D))
+                    got += [S.step.copy(), S.predicted_reduction.copy()]
+            sol.close(); ctx.close()
+            outs.append(got)
+        for x0, x1 in zip(*outs):
+            assert np.array_equal(x0, x1)
+
+
+def test_k_split_kernel_for_eight_column_tiles(bl, monkeypatch):
+    """n = 113 .. 128 (8 column tiles) runs gram8_kernel for EVERY batch size: static tile rows per
+    wave, the k-steps of a row chunk split between two wave groups whose partial tiles are added in
+    a fixed order.  That order differs from the generic kernel's (BLSQ_GRAM8 = 0), so the two agree
+    to rounding only; what must hold bit for bit is that a problem's result does not depend on the
+    batch it is in, nor on a tile-group request."""
+    from bounded_lsq import _synth, _abi
+    for (B, m, n) in [(5, 2100, 128), (4, 1000, 113), (3, 4096, 127), (3, 700, 120), (2, 33, 128)]:
+        P = _synth.trf_batch(61 + n, B, m, n, unbounded=(m < 200))
+        Delta = np.full(B, 0.7)
+
+        def run(idx, g8="1", tg=None):
+            monkeypatch.setenv("BLSQ_GRAM8", g8)
+            if tg: monkeypatch.setenv("BLSQ_GRAM_TILE_GROUPS", tg)
+            else: monkeypatch.delenv("BLSQ_GRAM_TILE_GROUPS", raising=False)
+            ctx = _abi.Context(0)
+            sol = bl.TrfStepSolver(len(idx), m, n, ctx=ctx)
+            sol.factor(*(P[k][idx] for k in ("J", "f", "x", "lb", "ub", "scale")))
+            S = sol.step(Delta[idx], np.zeros(len(idx)))
+            out = (S.step.copy(), sol.fetch_factor().g.copy())
+            sol.close(); ctx.close()
+            return out
+
+        full = run(np.arange(B))
+        alone = run(np.array([B - 1]))
+        assert np.array_equal(full[0][B - 1], alone[0][0]) and np.array_equal(full[1][B - 1], alone[1][0])
+        grouped = run(np.arange(B), tg="4")
+        assert np.array_equal(full[0], grouped[0]) and np.array_equal(full[1], grouped[1])
+        generic = run(np.arange(B), g8="0")
+        for b in range(B):
+            gref = P["J"][b].T @ P["f"][b]
+            assert rel(full[1][b], gref) < 1e-13
+            assert rel(full[0][b], generic[0][b]) < 1e-11
+
+
 @pytest.mark.parametrize("rho", [0.99, 0.9999, 1 - 1e-8])
 def test_bounded_problems_are_gated_on_the_augmented_system(bl, rho):
     """Bounds close to x: the Coleman-Li block E^2 = diag(g jv scale^2) dominates H = D G D + E^2
