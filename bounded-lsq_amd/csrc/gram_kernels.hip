@@ -22,6 +22,7 @@
 #include "blsq_device.h"
 #include "blsq_kernels.h"
 #include "tri_ops.h"
+#include "chol16.h"
 
 namespace blsq {
 
@@ -972,52 +973,11 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
         }
       }
     }
+    // ---- B. wave 0: Cholesky of the diagonal tile and its inverse (chol16.h), straight from the
+    // accumulators of its Schur complement ----
     if (w == 0) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) Dt[(lr + 4 * g) * 16 + lc] = S[0][g];
-    }
-    psync();
-    // ---- B. wave 0: Cholesky of the diagonal tile and its inverse ----
-    if (w == 0) {
-      const int jc = lc;
-      double col[TILE];
-#pragma unroll
-      for (int i = 0; i < TILE; ++i) col[i] = Dt[i * 16 + jc];
-      double pmin = pminsh;
-      double pnv = 0.0;                                 // lane k: 1 / R'[k][k]
-      double yy[TILE];
-#pragma unroll
-      for (int kk = 0; kk < TILE; ++kk) {
-        const double d = read_lane(col[kk], kk);
-        const bool live = (16 * kb + kk) < n;           // the rhs / padding columns are not gated
-        if (live && !(d >= pmin)) pmin = d;             // also catches NaN
-        const bool pos = d > 1e-300;
-        const double ds = pos ? d : 1.0;
-        double ri = __builtin_amdgcn_rsq(ds);
-        ri = ri * fma(-0.5 * ds * ri, ri, 1.5);
-        ri = ri * fma(-0.5 * ds * ri, ri, 1.5);
-        if (!pos) ri = 0.0;                             // zero row (rho = 0, padding)
-        const double rkj = col[kk] * ri;
-        col[kk] = (jc >= kk) ? rkj : 0.0;
-        pnv = (jc == kk) ? ri : pnv;
-#pragma unroll
-        for (int i = kk + 1; i < TILE; ++i) col[i] = fma(-read_lane(rkj, i), rkj, col[i]);
-        // the inverse rides along: Y = R'^-T by forward substitution, row kk as soon as row kk of
-        // R' exists (lane c holds column c of Y = row c of R'^-1) — its sums are independent of the
-        // next pivot's rsq chain, so the two latency chains overlap instead of running back to back
-        double ay0 = (jc == kk) ? 1.0 : 0.0, ay1 = 0.0;
-#pragma unroll
-        for (int p = 0; p < kk; p += 2) {
-          ay0 = fma(-read_lane(col[p], kk), yy[p], ay0);
-          if (p + 1 < kk) ay1 = fma(-read_lane(col[p + 1], kk), yy[p + 1], ay1);
-        }
-        yy[kk] = (jc <= kk) ? (ay0 + ay1) * ri : 0.0;
-      }
-      if (lane < TILE) {
-#pragma unroll
-        for (int i = 0; i < TILE; ++i) { Dt[i * 16 + jc] = col[i]; Ri[jc * 16 + i] = yy[i]; }
-      }
-      if (lane == 0) pminsh = pmin;
+      const double pm = chol16_blocked3(S[0], Dt, Ri, n - 16 * kb, pminsh);
+      if (lane == 0) pminsh = pm;
     }
     psync();
     if (a.rinv && w == NWP - 1) {                       // kept for the conditioning certificate (off the chain)
@@ -1175,47 +1135,11 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
           __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
       }
-      const int jc = lc;
-      double col[TILE];
+      pmin = chol16_blocked3(Dt, Ri, n - 16 * kb, pmin);   // (chol16.h)
+      if (a.rinv) {                                     // kept for the conditioning certificate
+        double* ro = a.rinv + ((long)b * (NPAD / 16) + kb) * 256;
 #pragma unroll
-      for (int i = 0; i < TILE; ++i) col[i] = Dt[i * 16 + jc];
-      double pnv = 0.0;
-      double yy[TILE];
-#pragma unroll
-      for (int kk = 0; kk < TILE; ++kk) {
-        const double d = read_lane(col[kk], kk);
-        const bool live = (16 * kb + kk) < n;
-        if (live && !(d >= pmin)) pmin = d;
-        const bool pos = d > 1e-300;
-        const double ds = pos ? d : 1.0;
-        double ri = __builtin_amdgcn_rsq(ds);
-        ri = ri * fma(-0.5 * ds * ri, ri, 1.5);
-        ri = ri * fma(-0.5 * ds * ri, ri, 1.5);
-        if (!pos) ri = 0.0;
-        const double rkj = col[kk] * ri;
-        col[kk] = (jc >= kk) ? rkj : 0.0;
-        pnv = (jc == kk) ? ri : pnv;
-#pragma unroll
-        for (int i = kk + 1; i < TILE; ++i) col[i] = fma(-read_lane(rkj, i), rkj, col[i]);
-        // the inverse rides along: Y = R'^-T by forward substitution, row kk as soon as row kk of
-        // R' exists (lane c holds column c of Y = row c of R'^-1) — its sums are independent of the
-        // next pivot's rsq chain, so the two latency chains overlap instead of running back to back
-        double ay0 = (jc == kk) ? 1.0 : 0.0, ay1 = 0.0;
-#pragma unroll
-        for (int p = 0; p < kk; p += 2) {
-          ay0 = fma(-read_lane(col[p], kk), yy[p], ay0);
-          if (p + 1 < kk) ay1 = fma(-read_lane(col[p + 1], kk), yy[p + 1], ay1);
-        }
-        yy[kk] = (jc <= kk) ? (ay0 + ay1) * ri : 0.0;
-      }
-      if (lane < TILE) {
-#pragma unroll
-        for (int i = 0; i < TILE; ++i) { Dt[i * 16 + jc] = col[i]; Ri[jc * 16 + i] = yy[i]; }
-        if (a.rinv) {
-          double* ro = a.rinv + ((long)b * (NPAD / 16) + kb) * 256 + jc * 16;
-#pragma unroll
-          for (int i = 0; i < TILE; ++i) ro[i] = yy[i];
-        }
+        for (int q = 0; q < 4; ++q) ro[q * 64 + lane] = Ri[q * 64 + lane];
       }
       __syncthreads();                                  // B: R'_kk and its inverse are in LDS
       __syncthreads();                                  // C: (workers published the row block)
