@@ -1024,6 +1024,12 @@ static int trf_put_bounds(blsq_trf_plan* p, const double* x, const double* lb, c
                           const double* scale, hipMemcpyKind kind) {
   blsq_ctx* ctx = p->ctx;
   int rc;
+  if (kind == hipMemcpyDeviceToDevice) {                // one launch instead of four strided copies
+    PackVecs pv{{x, lb, ub, scale, nullptr}, {p->st.x, p->st.lb, p->st.ub, p->st.scale, nullptr}};
+    hipError_t e = launch_pack_vecs(pv, p->n, p->ld, p->B, ctx->stream);
+    if (e != hipSuccess) return ctx->fail(e, "launch_pack_vecs");
+    return 0;
+  }
   if ((rc = put_vec(ctx, p->st.x, p->ld, x, p->n, p->B, kind))) return rc;
   if ((rc = put_vec(ctx, p->st.lb, p->ld, lb, p->n, p->B, kind))) return rc;
   if ((rc = put_vec(ctx, p->st.ub, p->ld, ub, p->n, p->B, kind))) return rc;
@@ -1426,6 +1432,12 @@ int dog_put(blsq_dogbox_plan* p, const double* x, const double* lb, const double
             const double* scale, const int64_t* on_bound, hipMemcpyKind kind) {
   blsq_ctx* ctx = p->ctx;
   int rc;
+  if (kind == hipMemcpyDeviceToDevice) {
+    PackVecs pv{{x, lb, ub, scale, on_bound}, {p->st.x, p->st.lb, p->st.ub, p->st.scale, p->st.on_bound}};
+    hipError_t e = launch_pack_vecs(pv, p->n, p->ld, p->B, ctx->stream);
+    if (e != hipSuccess) return ctx->fail(e, "launch_pack_vecs");
+    return 0;
+  }
   if ((rc = put_vec(ctx, p->st.x, p->ld, x, p->n, p->B, kind))) return rc;
   if ((rc = put_vec(ctx, p->st.lb, p->ld, lb, p->n, p->B, kind))) return rc;
   if ((rc = put_vec(ctx, p->st.ub, p->ld, ub, p->n, p->B, kind))) return rc;

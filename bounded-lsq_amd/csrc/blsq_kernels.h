@@ -149,6 +149,9 @@ struct TrfState {         // all device pointers, batch-major, vector stride ld
 // from_gram: g and the column norms come from st.Gk instead of st.Rt.  sel (optional [B]): only
 // problems with sel[b] > 1 are processed.  redo: the problem was prepared from its Gram already in
 // this factor call (its gate failed since): start again from scale_in.
+// up to five caller vectors [B][n] (8-byte elements; nullptr: skipped) -> the [B][ld] state layout, one launch
+struct PackVecs { const void* src[5]; void* dst[5]; };
+hipError_t launch_pack_vecs(const PackVecs& pv, int n, int ld, int B, hipStream_t s);
 hipError_t launch_trf_prep(const TrfState& st, int jac_scaling, int from_gram, const int* sel,
                            int redo, hipStream_t s);
 

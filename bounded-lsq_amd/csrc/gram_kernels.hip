@@ -674,12 +674,13 @@ __global__ __launch_bounds__(GR_NT, 2) void gram8_kernel(GramArgs a) {
 // The MFMA operand fragment of column tile c at k-step s is X[4 s + lr][16 c + lc]: 16 lanes read
 // 128 contiguous bytes of a row — a coalesced global load straight into the operand register.
 // So with few column tiles every wave takes its own k-steps (4 rows each, wave w: k-steps w, w + 8,
-// ...) for ALL output tiles, loads the NT fragments of several k-steps ahead, and never meets the
-// other waves until the final, fixed-order reduction of the eight partial Grams through LDS.
+// ...) for ALL output tiles, keeps two rounds of four k-steps of loads in flight (the loads of round
+// i + 1 are issued before round i is consumed: 512 x 64, 1024 problems 181 -> 95 us), and never meets
+// the other waves until the final, fixed-order reduction of the eight partial Grams through LDS.
 template <int NTT, bool RHS>
 __global__ __launch_bounds__(GR_NT, (NTT <= 2 ? 4 : 2)) void gram_direct_kernel(GramArgs a) {
   constexpr int NTILE = NTT * (NTT + 1) / 2;
-  constexpr int KU = (NTT <= 2) ? 8 : 4;                // k-steps in flight per wave
+  constexpr int KU = 4;                                 // k-steps per round (two rounds in flight per wave)
   extern __shared__ double lds[];                       // [GR_NW][256]
   const int b = blockIdx.y;
   if (a.mask && a.mask[b] <= 1) return;
@@ -702,27 +703,34 @@ __global__ __launch_bounds__(GR_NT, (NTT <= 2 ? 4 : 2)) void gram_direct_kernel(
 #pragma unroll
   for (int c = 0; c < NTT; ++c) gf[c] = 0.0;
   const int last = r_hi > r_lo ? r_hi - 1 : r_lo;
-  for (int r0 = r_lo + 4 * w; r0 < r_hi; r0 += 4 * GR_NW * KU) {
-    double fr[KU][NTT], fv[KU];
+  constexpr int RSTEP = 4 * GR_NW * KU;                 // rows the workgroup consumes per round
+  // raw loads of one round (clamped, unconditional — nothing here waits for the data) ...
+  auto load_round = [&](int r0, double (&fr)[KU][NTT], double (&fv)[KU]) {
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
       const int row = r0 + 4 * GR_NW * u + lr;
       const int rc = row < r_hi ? row : last;
-      if (RHS) {
-        const double t = Fb[rc];
-        fv[u] = row < r_hi ? t : 0.0;
-      }
+      if (RHS) fv[u] = Fb[rc];
 #pragma unroll
       for (int c = 0; c < NTT; ++c) {
         const int col = 16 * c + lc;
-        // (clamped unconditional loads, select afterwards; without RHS the rhs f is column n)
+        // (without RHS the rhs f is column n)
         const double* ptr = (RHS || col < n) ? Jb + (long)rc * a.ldJ + (col < n ? col : n - 1) : Fb + rc;
-        const double v = __builtin_nontemporal_load(ptr);
-        fr[u][c] = (row < r_hi && (RHS ? col < n : col <= n)) ? v : 0.0;
+        fr[u][c] = __builtin_nontemporal_load(ptr);
       }
     }
+  };
+  // ... and their use: rows / columns outside the problem count as zeros
+  auto use_round = [&](int r0, double (&fr)[KU][NTT], double (&fv)[KU]) {
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
+      const bool rin = r0 + 4 * GR_NW * u + lr < r_hi;
+      if (RHS) fv[u] = rin ? fv[u] : 0.0;
+#pragma unroll
+      for (int c = 0; c < NTT; ++c) {
+        const int col = 16 * c + lc;
+        fr[u][c] = (rin && (RHS ? col < n : col <= n)) ? fr[u][c] : 0.0;
+      }
       int t = 0;
 #pragma unroll
       for (int i = 0; i < NTT; ++i)
@@ -734,29 +742,53 @@ __global__ __launch_bounds__(GR_NT, (NTT <= 2 ? 4 : 2)) void gram_direct_kernel(
         gff = fma(fv[u], fv[u], gff);
       }
     }
+  };
+  // two rounds in flight: the loads of round i + 1 are issued before round i is consumed
+  {
+    double frA[KU][NTT], fvA[KU], frB[KU][NTT], fvB[KU];
+    int r0 = r_lo + 4 * w;
+    if (r0 < r_hi) load_round(r0, frA, fvA);
+    while (r0 < r_hi) {
+      if (r0 + RSTEP < r_hi) load_round(r0 + RSTEP, frB, fvB);
+      use_round(r0, frA, fvA);
+      r0 += RSTEP;
+      if (r0 >= r_hi) break;
+      if (r0 + RSTEP < r_hi) load_round(r0 + RSTEP, frA, fvA);
+      use_round(r0, frB, fvB);
+      r0 += RSTEP;
+    }
   }
-  // cross-wave reduction, tile by tile through a 16 KB LDS buffer (fixed order: deterministic)
+  // cross-wave reduction through LDS (fixed order: deterministic)
   double* G = a.G + ((long)b * gridDim.x + blockIdx.x) * (long)a.NPAD * a.NPAD;
   const int NT = (n + 1 + 15) / 16;
-  {
-    int t = 0;
+  // (PH tiles per pass through LDS — [tile][wave][256] — and two barriers per pass)
+  constexpr int PH = NTILE < 5 ? NTILE : 5;
 #pragma unroll
-    for (int i = 0; i < NTT; ++i) {
+  for (int t0 = 0; t0 < NTILE; t0 += PH) {
 #pragma unroll
-      for (int j = i; j < NTT; ++j, ++t) {
+    for (int tt = 0; tt < PH; ++tt) {
+      if (t0 + tt < NTILE) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) lds[w * 256 + g * 64 + lane] = acc[t][g];
-        __syncthreads();
-        if (tid < 256 && j < NT) {
-          double sum = 0.0;
-#pragma unroll
-          for (int ww = 0; ww < GR_NW; ++ww) sum += lds[ww * 256 + tid];
-          const int g = tid >> 6, ln = tid & 63;
-          G[(long)(16 * i + (ln >> 4) + 4 * g) * a.NPAD + 16 * j + (ln & 15)] = sum;
-        }
-        __syncthreads();
+        for (int g = 0; g < 4; ++g) lds[(tt * GR_NW + w) * 256 + g * 64 + lane] = acc[t0 + tt][g];
       }
     }
+    __syncthreads();
+    for (int e = tid; e < PH * 256; e += GR_NT) {
+      const int tt = e >> 8, el = e & 255;
+      int q = t0 + tt, i = 0;
+      if (q < NTILE) {
+        while (q >= NTT - i) { q -= NTT - i; ++i; }
+        const int j = i + q;
+        if (j < NT) {
+          double sum = 0.0;
+#pragma unroll
+          for (int ww = 0; ww < GR_NW; ++ww) sum += lds[(tt * GR_NW + ww) * 256 + el];
+          const int g = el >> 6, ln = el & 63;
+          G[(long)(16 * i + (ln >> 4) + 4 * g) * a.NPAD + 16 * j + (ln & 15)] = sum;
+        }
+      }
+    }
+    __syncthreads();
   }
   if (!RHS) return;
   // rhs column: [wave][lane row][column] partials -> column totals (wave-major, then lane row)
@@ -1519,7 +1551,8 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s) {
   } while (0)
 #define BLSQ_GRAM_DIRECT(NTT, RHS)                                                            \
   do {                                                                                        \
-    const size_t dl_ = sizeof(double) * (GR_NW * 256 + 64);                                   \
+    constexpr int nt_ = (NTT) * ((NTT) + 1) / 2;                                              \
+    const size_t dl_ = sizeof(double) * ((nt_ < 5 ? nt_ : 5) * GR_NW * 256 + 64);            \
     static std::atomic<size_t> granted[64];                                                   \
     hipError_t ge = gram_grant_lds(gram_direct_kernel<NTT, RHS>, dl_, granted);               \
     if (ge != hipSuccess) return ge;                                                          \

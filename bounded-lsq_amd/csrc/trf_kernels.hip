@@ -553,4 +553,26 @@ hipError_t launch_trf_step(const TrfState& st, const LmState* lm, const double* 
   return hipGetLastError();
 }
 
+// ---- caller vectors -> state layout (device to device) -----------------------------------------
+__global__ void pack_vecs_kernel(PackVecs pv, int n, int ld, int B) {
+  const long total = (long)B * n;
+  const int v = blockIdx.y;
+  const unsigned long long* src = (const unsigned long long*)pv.src[v];
+  unsigned long long* dst = (unsigned long long*)pv.dst[v];
+  if (!src || !dst) return;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long b = e / n;
+    const int i = (int)(e - b * n);
+    dst[b * ld + i] = src[e];
+  }
+}
+hipError_t launch_pack_vecs(const PackVecs& pv, int n, int ld, int B, hipStream_t s) {
+  const long total = (long)B * n;
+  int gx = (int)((total + 255) / 256);
+  if (gx > 1024) gx = 1024;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(pack_vecs_kernel, dim3(gx, 5), dim3(256), 0, s, pv, n, ld, B);
+  return hipGetLastError();
+}
+
 }  // namespace blsq

@@ -1,7 +1,8 @@
 """Workload for the SQ MFMA-counter passes (run under rocprofv3 --pmc ... --kernel-trace):
   1. the FP64 MFMA probe, one and two waves per SIMD  (mfma_f64_probe_kernel: a launch that
      executes a KNOWN number of v_mfma_f64_16x16x4_f64 back to back — the calibration point)
-  2. one TRF step-solve of the bench workload (4096 x 256, 512 problems) per factorisation path
+  2. one TRF step-solve of the bench workload (4096 x 256, 512 problems; PMC_B / PMC_M / PMC_N
+     override the shape) per factorisation path
 Prints what the probe launches executed so that tools/pmc_mfma.py can price the counters."""
 import json
 import os
@@ -12,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "bounded-lsq_amd"))
 import numpy as np  # noqa: E402
 from bounded_lsq import TrfStepSolver, _abi, _synth  # noqa: E402
 
-B, m, n = int(os.environ.get("PMC_B", "512")), 4096, 256
+B, m, n = (int(os.environ.get(k, d)) for k, d in (("PMC_B", "512"), ("PMC_M", "4096"), ("PMC_N", "256")))
 ctx = _abi.Context(0)
 info = {}
 for w in (1, 2):
