@@ -290,8 +290,9 @@ struct QrTree {
     double* Gk = gram_keep.as<double>();
     g.G = gram_nchunk > 1 ? gram_part.as<double>() : Gk;
     ctx->begin(K_GRAM);
-    hipError_t e = launch_gram(g, gram_nchunk, B, ctx->stream);
-    if (e == hipSuccess && gram_nchunk > 1)
+    bool fused = false;
+    hipError_t e = launch_gram(g, gram_nchunk, B, ctx->stream, Gk, &fused);
+    if (e == hipSuccess && gram_nchunk > 1 && !fused)
       e = launch_gram_reduce(gram_part.as<double>(), gram_nchunk, NPAD, Gk, mask, B, ctx->stream);
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_gram");
@@ -325,8 +326,9 @@ struct QrTree {
     double* Gk = gram_keep.as<double>();
     g.G = gram_nchunk > 1 ? gram_part.as<double>() : Gk;
     ctx->begin(K_GRAM);
-    hipError_t e = launch_gram(g, gram_nchunk, B, ctx->stream);
-    if (e == hipSuccess && gram_nchunk > 1)
+    bool fused = false;
+    hipError_t e = launch_gram(g, gram_nchunk, B, ctx->stream, Gk, &fused);
+    if (e == hipSuccess && gram_nchunk > 1 && !fused)
       e = launch_gram_reduce(gram_part.as<double>(), gram_nchunk, NPAD, Gk, mask, B, ctx->stream);
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_gram");

@@ -63,6 +63,7 @@ struct GramArgs {
   const int* mask;        // optional: problems with mask[b] <= 1 are skipped
   int rows_per_chunk;     // set by launch_gram
   int rhs_valu;           // set by launch_gram: J^T f / f^T f accumulated by the vector ALUs
+  double* Gscr;           // set by launch_gram (pair mode): the chunk-partials buffer, used as scratch
 };
 struct GramCholArgs {
   const double* Gsrc;     // [B][NPAD*NPAD] Gram (upper tile blocks); may alias G (in place)
@@ -102,7 +103,10 @@ constexpr double GRAM_K2_MAX = 2.5e5;
 constexpr double GRAM_SMIN_PROVEN = 2.0e-3;         // = 1 / sqrt(GRAM_K2_MAX)
 bool gram_supported(int m, int n);
 int gram_chunks(int B, int m);
-hipError_t launch_gram(const GramArgs& a, int chunks, int B, hipStream_t s);
+// Gfinal / fused (optional): where the reduced Gram belongs; *fused = true means the launch produced it
+// there itself (two chunks summed in the kernel) and launch_gram_reduce must not follow
+hipError_t launch_gram(const GramArgs& a, int chunks, int B, hipStream_t s, double* Gfinal = nullptr,
+                       bool* fused = nullptr);
 hipError_t launch_gram_reduce(const double* Gpart, int chunks, int NPAD, double* Gout,
                               const int* mask, int B, hipStream_t s);
 hipError_t launch_gram_chol(const GramCholArgs& a, int B, hipStream_t s);

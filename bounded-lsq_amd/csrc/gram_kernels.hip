@@ -276,7 +276,11 @@ __device__ __forceinline__ void lds_read64_off(double& dst, unsigned byte_addr) 
   asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(byte_addr), "n"(OFF));
 }
 
-template <int W, bool RHS>
+// PAIR: one workgroup takes BOTH row chunks of a problem of two chunks, one after the other: at the
+// chunk boundary the accumulators go to the output slot and restart from zero, at the end the first
+// chunk's tiles are read back and added — (0 + P0) + P1, exactly what gram_reduce_kernel computes
+// from two partial Grams, without writing the second one, reading both and a launch in between.
+template <int W, bool RHS, bool PAIR>
 __device__ __forceinline__ void gram16_wave(const GramArgs& a, double* lds) {
   constexpr int LDX = 272, NCB = 4;
   constexpr int NF = 16 - W;                            // fragments per k-step: column tiles W .. 15
@@ -286,16 +290,19 @@ __device__ __forceinline__ void gram16_wave(const GramArgs& a, double* lds) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int lr = lane >> 4, lc = lane & 15;
   const int n = a.n, N = n + 1;
-  const int r_lo = blockIdx.x * a.rows_per_chunk;
-  int r_hi = r_lo + a.rows_per_chunk;
+  const int r_lo = PAIR ? 0 : blockIdx.x * a.rows_per_chunk;
+  int r_hi = PAIR ? a.m : r_lo + a.rows_per_chunk;
   if (r_hi > a.m) r_hi = a.m;
   const int m = r_hi;
+  const int boundary = a.rows_per_chunk;                // (PAIR) first row of the second chunk
   const double* Jb = a.J + (long)b * a.strideJ;
   const double* Fb = a.F + (long)b * a.strideF;
 
   constexpr int HR = GR_RC / GR_NW / 2;                 // rows per wave per half chunk
   double pre[HR][NCB], fpre[HR];
   double gf[NCB] = {0.0, 0.0, 0.0, 0.0}, gff = 0.0;     // this wave's rows of J^T f / f^T f
+  // (PAIR) at the chunk boundary the first chunk's sums are parked in the scratch slot of the problem
+  double* scr = PAIR ? a.Gscr + (long)b * 2 * a.NPAD * a.NPAD : nullptr;
   auto issue = [&](int row0, int h) {
 #pragma unroll
     for (int rr = 0; rr < HR; ++rr) {
@@ -311,6 +318,12 @@ __device__ __forceinline__ void gram16_wave(const GramArgs& a, double* lds) {
     }
   };
   auto commit = [&](int row0, int h, double* X) {
+    if (PAIR && RHS && h == 0 && row0 == boundary) {    // (uniform) the rows of the second chunk start here
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) { scr[W * 256 + 64 * cb + lane] = gf[cb]; gf[cb] = 0.0; }
+      if (lane == 0) scr[GR_NW * 256 + W] = gff;
+      gff = 0.0;
+    }
 #pragma unroll
     for (int rr = 0; rr < HR; ++rr) {
       const int lrow = W + GR_NW * (HR * h + rr);
@@ -381,8 +394,25 @@ __device__ __forceinline__ void gram16_wave(const GramArgs& a, double* lds) {
                    "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]));
   };
 
+  double* G = a.G + ((long)b * gridDim.x + blockIdx.x) * (long)a.NPAD * a.NPAD;
+  auto tile_ptr0 = [&](int t, int g) { return G + (long)(16 * W + lr + 4 * g) * a.NPAD + 16 * (W + t) + lc; };
+  auto tile_ptr1 = [&](int t, int g) { return G + (long)(16 * (15 - W) + lr + 4 * g) * a.NPAD + 16 * (15 - W + t) + lc; };
   int cidx = 0;
   for (int row0 = r_lo; row0 < m; row0 += GR_RC, ++cidx) {
+    if (PAIR && row0 == boundary) {                     // first chunk done: park its tiles in the output slot
+#pragma unroll
+      for (int t = 0; t < N0; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *tile_ptr0(t, g) = acc0[t][g];
+        acc0[t] = v4d{0.0, 0.0, 0.0, 0.0};
+      }
+#pragma unroll
+      for (int t = 0; t < N1; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *tile_ptr1(t, g) = acc1[t][g];
+        acc1[t] = v4d{0.0, 0.0, 0.0, 0.0};
+      }
+    }
     const bool more = row0 + GR_RC < m;
     const double* X = (cidx & 1) ? X1 : X0;
     double* Xn = (cidx & 1) ? X0 : X1;
@@ -418,35 +448,57 @@ __device__ __forceinline__ void gram16_wave(const GramArgs& a, double* lds) {
     __syncthreads();
   }
 
-  double* G = a.G + ((long)b * gridDim.x + blockIdx.x) * (long)a.NPAD * a.NPAD;
+  const bool two = PAIR && m > boundary;                // (a second chunk was accumulated)
+  if (two) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (this lane's own stores of the first chunk)
 #pragma unroll
   for (int t = 0; t < N0; ++t)
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      G[(long)(16 * W + lr + 4 * g) * a.NPAD + 16 * (W + t) + lc] = acc0[t][g];
+    for (int g = 0; g < 4; ++g) {
+      double* q = tile_ptr0(t, g);
+      *q = two ? (0.0 + *q) + acc0[t][g] : acc0[t][g];
+    }
 #pragma unroll
   for (int t = 0; t < N1; ++t)
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      G[(long)(16 * (15 - W) + lr + 4 * g) * a.NPAD + 16 * (15 - W + t) + lc] = acc1[t][g];
+    for (int g = 0; g < 4; ++g) {
+      double* q = tile_ptr1(t, g);
+      *q = two ? (0.0 + *q) + acc1[t][g] : acc1[t][g];
+    }
   if (!RHS) return;
-  // rhs column: the eight per-wave partials, added in wave order (the last barrier is behind us)
+  // rhs column: the eight per-wave partials, added in wave order (the last barrier is behind us);
+  // PAIR: the two chunks' columns one after the other, then (0 + first) + second
 #pragma unroll
-  for (int cb = 0; cb < NCB; ++cb) lds[W * 256 + 64 * cb + lane] = gf[cb];
-  if (lane == 0) lds[GR_NW * 256 + W] = gff;
+  for (int cb = 0; cb < NCB; ++cb) lds[W * 256 + 64 * cb + lane] = two ? scr[W * 256 + 64 * cb + lane] : gf[cb];
+  if (lane == 0) lds[GR_NW * 256 + W] = two ? scr[GR_NW * 256 + W] : gff;
   __syncthreads();
+  double sum = 0.0, sumf = 0.0;
   if (tid < n) {
-    double sum = 0.0;
 #pragma unroll
     for (int ww = 0; ww < GR_NW; ++ww) sum += lds[ww * 256 + tid];
-    G[(long)tid * a.NPAD + n] = sum;
   }
   if (tid == 0) {
-    double sum = 0.0;
 #pragma unroll
-    for (int ww = 0; ww < GR_NW; ++ww) sum += lds[GR_NW * 256 + ww];
-    G[(long)n * a.NPAD + n] = sum;
+    for (int ww = 0; ww < GR_NW; ++ww) sumf += lds[GR_NW * 256 + ww];
   }
+  if (two) {
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) lds[W * 256 + 64 * cb + lane] = gf[cb];
+    if (lane == 0) lds[GR_NW * 256 + W] = gff;
+    __syncthreads();
+    double s2 = 0.0, s2f = 0.0;
+    if (tid < n) {
+#pragma unroll
+      for (int ww = 0; ww < GR_NW; ++ww) s2 += lds[ww * 256 + tid];
+    }
+    if (tid == 0) {
+#pragma unroll
+      for (int ww = 0; ww < GR_NW; ++ww) s2f += lds[GR_NW * 256 + ww];
+    }
+    sum = (0.0 + sum) + s2; sumf = (0.0 + sumf) + s2f;
+  }
+  if (tid < n) G[(long)tid * a.NPAD + n] = sum;
+  if (tid == 0) G[(long)n * a.NPAD + n] = sumf;
   const int NT = (N + 15) / 16;
   for (int e = tid; e < a.NPAD * (16 * NT - N); e += GR_NT) {   // padding columns of the rhs tile column
     const int r = e / (16 * NT - N), c = N + e % (16 * NT - N);
@@ -454,20 +506,20 @@ __device__ __forceinline__ void gram16_wave(const GramArgs& a, double* lds) {
   }
 }
 
-template <bool RHS>
+template <bool RHS, bool PAIR>
 __global__ __launch_bounds__(GR_NT, 2) void gram16_kernel(GramArgs a) {
   extern __shared__ double lds[];
   if (a.mask && a.mask[blockIdx.y] <= 1) return;
   const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   switch (w) {
-    case 0: gram16_wave<0, RHS>(a, lds); break;
-    case 1: gram16_wave<1, RHS>(a, lds); break;
-    case 2: gram16_wave<2, RHS>(a, lds); break;
-    case 3: gram16_wave<3, RHS>(a, lds); break;
-    case 4: gram16_wave<4, RHS>(a, lds); break;
-    case 5: gram16_wave<5, RHS>(a, lds); break;
-    case 6: gram16_wave<6, RHS>(a, lds); break;
-    default: gram16_wave<7, RHS>(a, lds); break;
+    case 0: gram16_wave<0, RHS, PAIR>(a, lds); break;
+    case 1: gram16_wave<1, RHS, PAIR>(a, lds); break;
+    case 2: gram16_wave<2, RHS, PAIR>(a, lds); break;
+    case 3: gram16_wave<3, RHS, PAIR>(a, lds); break;
+    case 4: gram16_wave<4, RHS, PAIR>(a, lds); break;
+    case 5: gram16_wave<5, RHS, PAIR>(a, lds); break;
+    case 6: gram16_wave<6, RHS, PAIR>(a, lds); break;
+    default: gram16_wave<7, RHS, PAIR>(a, lds); break;
   }
 }
 
@@ -1057,6 +1109,194 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
   }
 }
 
+// ---- N <= 80, one wave per problem, the whole matrix in registers -------------------------------
+// At most 5 x 5 tiles: the 15 upper tiles of the equilibrated matrix are loaded ONCE into
+// accumulators and never leave the wave until their row block is final.  Per row block: the chain of
+// the diagonal tile straight from its accumulator (chol16.h), R'_{kb,j} = R'_kk^-T S_j by MFMA, and
+// the right-looking update of the remaining tiles — whose MFMA operands are the rows just solved,
+// already in the right layout (register s of a tile in the accumulator layout holds rows 4 s + lr:
+// the operand fragment of k-step s).  No L2 round trip inside the factorisation (the left-looking
+// kernel above pays one per tile and finished row block: 20 exposed latencies at N = 65), no barrier.
+// Same arguments, outputs and gate bookkeeping as gram_chol_kernel<1>; eight problems per workgroup.
+__global__ __launch_bounds__(GR_NT, 2) void gram_chol_reg_kernel(GramCholArgs a) {
+  constexpr int MT = 5;                                 // tile rows at most (N <= 80)
+  extern __shared__ double sh_all[];
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int pidx = (int)blockIdx.x * GR_NW + wv;
+  if (pidx >= a.count) return;                          // (wave-uniform)
+  if (a.count_dev && pidx >= *a.count_dev) return;
+  const int b = a.batch_list ? a.batch_list[pidx] : pidx;
+  const int lane = threadIdx.x & 63, tid = lane;
+  const int lr = lane >> 4, lc = lane & 15;
+  const int NPAD = a.NPAD;
+  double* sh = sh_all + (size_t)wv * (4 * (size_t)NPAD + 512);
+  auto wsync = []() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); };
+  if (a.mask && a.mask[b] <= 1) {
+    if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
+    return;
+  }
+  if (a.skip_path && a.skip_path[b] != 0) return;
+  const int N = a.ncols_dev ? a.ncols_dev[b] : a.n + 1;
+  if (N <= 1) {                                         // (dogbox: every variable active — nothing to factor)
+    if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
+    return;
+  }
+  const int n = N - 1;
+  const int NT = (N + 15) / 16;
+  const int* gidx = a.gather ? a.gather + (long)b * a.stride_vec : nullptr;
+  auto src = [&](int i) -> int { return gidx ? (i < n ? gidx[i] : a.n) : i; };
+  const double* Gs = a.Gsrc + (long)b * NPAD * NPAD;    // source Gram (may alias the output)
+  double* Gb = a.G + (long)b * NPAD * NPAD;             // output triangle
+  double* dl = sh;                 // [NPAD] equilibration 1 / sqrt(h_jj)
+  double* sq = dl + NPAD;          // [NPAD] sqrt(h_jj)
+  double* sc = sq + NPAD;          // [NPAD] colscale_j * dl_j
+  double* Dt = sc + NPAD;          // [256]  diagonal tile (row-major)
+  double* Ri = Dt + 256;           // [256]  its inverse
+  double* td = Ri + 256;           // [NPAD] (e_j^2 + alpha) * dl_j^2
+  const double* csv = a.colscale ? a.colscale + (long)b * a.stride_vec : nullptr;
+  const double* edv = a.diag_vec ? a.diag_vec + (long)b * a.stride_vec : nullptr;
+  const double sa = a.diag_sqrt ? a.diag_sqrt[b] : 0.0;
+  int* sidx = (int*)Ri;            // [NPAD] source indices — only until the tiles are loaded (Ri is free till then)
+  // 0. column scales from the diagonal of H
+  int bad = 0;
+  for (int j = tid; j < NPAD; j += WAVE) {
+    const double cs = (csv && j < n) ? csv[j] : 1.0;
+    const double ej = (edv && j < n) ? edv[j] : 0.0;
+    const double add = (j < n) ? fma(ej, ej, sa * sa) : 0.0;
+    const int sj_ = (j < N) ? src(j) : j;
+    const double g = (j < N) ? fma(Gs[(long)sj_ * NPAD + sj_] * cs, cs, add) : 0.0;
+    const bool okc = (g > 0.0) && is_finite(g);
+    if (j < n && !okc) bad = 1;
+    double d = 1.0, s_ = 1.0;
+    if (j < N && okc) {
+      d = __builtin_amdgcn_rsq(g);
+      d = d * fma(-0.5 * g * d, d, 1.5);
+      d = d * fma(-0.5 * g * d, d, 1.5);
+      s_ = g * d;
+    }
+    dl[j] = d; sq[j] = s_; sc[j] = cs * d; td[j] = add * d * d;
+    sidx[j] = sj_ < NPAD ? sj_ : 0;                     // source row / column of index j (always a valid one)
+    if (a.dsc) a.dsc[(long)b * NPAD + j] = d;
+  }
+  wsync();
+  if (a.colinfo && tid == 0) {                          // column-norm summary for the rank gate
+    double mn = __builtin_inf(), sm = 0.0;
+    for (int j = 0; j < n; ++j) { const double v = sq[j]; mn = v < mn ? v : mn; sm = fma(v, v, sm); }
+    a.colinfo[2 * (long)b] = mn; a.colinfo[2 * (long)b + 1] = sm;
+  }
+  bad = __any(bad);
+  // 1. the scaled source tiles -> accumulators (the source may alias the output: every read comes
+  //    before any write)
+  v4d acc[MT * (MT + 1) / 2];
+  auto tix = [](int i, int j) { return i * MT - i * (i - 1) / 2 + (j - i); };   // upper tile (i, j) of a 5 x 5 grid
+  if (!bad) {
+    // (unconditional loads from clamped indices, all in flight together; selected afterwards)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      int srow[4];
+      double scr_[4];
+      if (i < NT) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * i + lr + 4 * g;
+          srow[g] = sidx[row < N ? row : N - 1];
+          scr_[g] = sc[row];
+        }
+      }
+#pragma unroll
+      for (int j = i; j < MT; ++j) {
+        v4d v4 = {0.0, 0.0, 0.0, 0.0};
+        if (j < NT) {
+          const int col = 16 * j + lc;
+          const int scol = sidx[col < N ? col : N - 1];
+          const double scj = sc[col];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row = 16 * i + lr + 4 * g;
+            const int lo_ = srow[g] < scol ? srow[g] : scol, hi_ = srow[g] < scol ? scol : srow[g];   // symmetric: upper tiles
+            double v = Gs[(long)lo_ * NPAD + hi_];
+            v = (row < N && col < N) ? v * scr_[g] * scj : 0.0;
+            if (j == i && lr + 4 * g == lc) v += td[row];
+            v4[g] = v;
+          }
+        }
+        acc[tix(i, j)] = v4;
+      }
+    }
+  }
+  wsync();
+  if (bad) {                                            // hand the problem to the QR tree
+    if (tid == 0 && a.fb_mask) {
+      a.fb_mask[b] = a.n + 1; { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }   // (the tree factors ALL n + 1 columns)
+      if (a.path_out) a.path_out[b] = a.n + 1;
+    }
+    return;
+  }
+  // strictly lower tiles and everything beyond 16 NT are part of the triangle's image: zero
+  for (int r = 0; r < NPAD; ++r) {
+    const int cend = (r < 16 * NT) ? (r & ~15) : NPAD;
+    for (int c = lane; c < cend; c += WAVE) Gb[(long)r * NPAD + c] = 0.0;
+    if (r < 16 * NT)
+      for (int c = 16 * NT + lane; c < NPAD; c += WAVE) Gb[(long)r * NPAD + c] = 0.0;
+  }
+  double pmin = 1.0;
+#pragma unroll
+  for (int kb = 0; kb < MT; ++kb) {
+    if (kb < NT) {
+      // 2. chain of the diagonal tile: R'_kk -> Dt, its inverse -> Ri
+      pmin = chol16_blocked3(acc[tix(kb, kb)], Dt, Ri, n - 16 * kb, pmin);
+      if (a.rinv) {                                     // kept for the conditioning certificate
+        double* ro = a.rinv + ((long)b * (NPAD / 16) + kb) * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ro[q * 64 + lane] = Ri[q * 64 + lane];
+      }
+      // 3. the row block: R'_{kb,j} = R'_kk^-T S_j (kept in the accumulators of row kb), stored as R = R' D^-1
+#pragma unroll
+      for (int j = kb; j < MT; ++j) {
+        if (j < NT) {
+          v4d X = {0.0, 0.0, 0.0, 0.0};
+          if (j == kb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) X[g] = Dt[(lr + 4 * g) * 16 + lc];
+          } else {
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) X = gmfma(Ri[(4 * s_ + lr) * 16 + lc], acc[tix(kb, j)][s_], X);
+            acc[tix(kb, j)] = X;
+          }
+          const double sj = sq[16 * j + lc];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row = 16 * kb + lr + 4 * g;
+            const int colg = 16 * j + lc;
+            double val = X[g] * sj;
+            if (row >= n || row > colg || colg > n) val = 0.0;
+            Gb[(long)row * NPAD + colg] = val;
+          }
+        }
+      }
+      // 4. right-looking update of the tiles below: (i, j) -= R'_{kb,i}^T R'_{kb,j}
+#pragma unroll
+      for (int i = kb + 1; i < MT; ++i) {
+#pragma unroll
+        for (int j = i; j < MT; ++j) {
+          if (j < NT) {
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+              acc[tix(i, j)] = gmfma(-acc[tix(kb, i)][s_], acc[tix(kb, j)][s_], acc[tix(i, j)]);
+          }
+        }
+      }
+      wsync();                                          // (Dt / Ri are rewritten by the next chain)
+    }
+  }
+  if (tid == 0 && a.fb_mask) {
+    const bool fail = !(pmin >= GRAM_SMIN * GRAM_SMIN);
+    a.fb_mask[b] = fail ? a.n + 1 : 0;
+    if (a.path_out) a.path_out[b] = fail ? a.n + 1 : 0;
+    if (fail) { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
+  }
+}
+
 // ---- right-looking variant: the whole (scaled) matrix lives in accumulators ----------------------
 // The NT (NT + 1) / 2 <= 153 upper tiles are dealt CYCLICALLY (row-major tile q -> wave q % 8, slot
 // q / 8) so that the shrinking trailing matrix stays balanced, and never leave the registers until
@@ -1526,8 +1766,9 @@ int gram_chunks(int B, int m) {
   return c < 1 ? 1 : c;
 }
 
-hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s) {
+hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s, double* Gfinal, bool* fused) {
   GramArgs a = a_in;
+  if (fused) *fused = false;
   const int NT = (a.n + 1 + 15) / 16;
   a.rows_per_chunk = chunks > 1 ? gram_chunk_rows(a.m) : a.m;
   const size_t lds = sizeof(double) * 2 * GR_RC * (size_t)gram_ldx(NT);
@@ -1618,17 +1859,23 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s) {
     const char* g16e = getenv("BLSQ_GRAM16");
     const int g16_env = g16e ? atoi(g16e) : 1;
     if (NTJ == 16 && tg == 1 && g16_env != 0 && a.m >= 1) {
-      if (a.rhs_valu) {
-        static std::atomic<size_t> granted[64];
-        hipError_t ge = gram_grant_lds(gram16_kernel<true>, lds, granted);
-        if (ge != hipSuccess) return ge;
-        hipLaunchKernelGGL((gram16_kernel<true>), dim3(chunks, B, 1), dim3(GR_NT), lds, s, a);
-      } else {
-        static std::atomic<size_t> granted[64];
-        hipError_t ge = gram_grant_lds(gram16_kernel<false>, lds, granted);
-        if (ge != hipSuccess) return ge;
-        hipLaunchKernelGGL((gram16_kernel<false>), dim3(chunks, B, 1), dim3(GR_NT), lds, s, a);
-      }
+      // two row chunks and enough problems to fill the device with one workgroup each: both chunks by
+      // the same workgroup, summed in the kernel straight into the final slot (bit-identical to the
+      // reduction pass: BLSQ_GRAM_PAIR = 0 keeps that)
+      const char* pe = getenv("BLSQ_GRAM_PAIR");
+      const bool pair = Gfinal && chunks == 2 && B >= 256 && !(pe && pe[0] == '0');
+      if (pair) { a.Gscr = a.G; a.G = Gfinal; if (fused) *fused = true; }
+      const dim3 grid(pair ? 1 : chunks, B, 1);
+#define BLSQ_GRAM16(RHS_, PAIR_)                                                              \
+  do {                                                                                        \
+    static std::atomic<size_t> granted[64];                                                   \
+    hipError_t ge = gram_grant_lds(gram16_kernel<RHS_, PAIR_>, lds, granted);                 \
+    if (ge != hipSuccess) return ge;                                                          \
+    hipLaunchKernelGGL((gram16_kernel<RHS_, PAIR_>), grid, dim3(GR_NT), lds, s, a);           \
+  } while (0)
+      if (a.rhs_valu) { if (pair) BLSQ_GRAM16(true, true); else BLSQ_GRAM16(true, false); }
+      else { if (pair) BLSQ_GRAM16(false, true); else BLSQ_GRAM16(false, false); }
+#undef BLSQ_GRAM16
       return hipGetLastError();
     }
   }
@@ -1669,8 +1916,14 @@ hipError_t launch_gram_chol(const GramCholArgs& a_in, int B, hipStream_t s) {
   a.count = B;
   const size_t per = sizeof(double) * (4 * (size_t)a.NPAD + 512);
   if (a.NPAD <= 80) {                                   // one wave per problem, eight per workgroup
-    hipLaunchKernelGGL(gram_chol_kernel<1>, dim3((B + GR_NW - 1) / GR_NW), dim3(GR_NT), per * GR_NW,
-                       s, a);
+    // (register-resident right-looking kernel; BLSQ_CHOL_REG = 0: the left-looking one-wave kernel)
+    const char* rge = getenv("BLSQ_CHOL_REG");
+    if (rge && rge[0] == '0')
+      hipLaunchKernelGGL(gram_chol_kernel<1>, dim3((B + GR_NW - 1) / GR_NW), dim3(GR_NT), per * GR_NW,
+                         s, a);
+    else
+      hipLaunchKernelGGL(gram_chol_reg_kernel, dim3((B + GR_NW - 1) / GR_NW), dim3(GR_NT), per * GR_NW,
+                         s, a);
   } else {
     // Right-looking register variant: 0.22 ms per problem on a CU of its own against 0.27 ms for
     // the left-looking kernel, but one workgroup per CU instead of two — so it serves the launches

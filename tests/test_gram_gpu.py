@@ -386,6 +386,34 @@ def test_static_tile_row_kernel_matches_the_generic_one_bit_for_bit(bl, monkeypa
             assert np.array_equal(outs[0][0], o[0])
 
 
+def test_chunk_pairs_summed_in_the_kernel_match_the_reduction_pass(bl, monkeypatch):
+    """Two row chunks (2048 < m <= 4096), 16 column tiles and at least 256 problems: one workgroup
+    takes both chunks and adds them in the kernel, (0 + P0) + P1 — what the separate reduction pass
+    computes from the two partial Grams (BLSQ_GRAM_PAIR = 0 keeps that pass).  Bit for bit, so a
+    problem's result still does not depend on the size of its batch."""
+    from bounded_lsq import _synth, _abi
+    for (B, m, n) in [(256, 2100, 256), (257, 2049, 250), (256, 4096, 241)]:
+        base = _synth.trf_batch(91 + n, 8, m, n)
+        P = {k: np.concatenate([v] * ((B + 7) // 8))[:B].copy() for k, v in base.items()}
+        P["f"] = P["f"] * (1.0 + 0.01 * np.arange(B))[:, None]        # (not 32 copies of 8 problems)
+        Delta = np.full(B, 0.7)
+        outs = []
+        for pair in ("1", "0"):
+            monkeypatch.setenv("BLSQ_GRAM_PAIR", pair)
+            ctx = _abi.Context(0)
+            sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
+            ctx.gram_stats(reset=True)
+            sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+            assert ctx.gram_stats() == (B, 0)
+            S = sol.step(Delta, np.zeros(B))
+            outs.append((S.step.copy(), sol.fetch_factor().g.copy()))
+            sol.close(); ctx.close()
+        assert np.array_equal(outs[0][1], outs[1][1])
+        assert np.array_equal(outs[0][0], outs[1][0])
+        for b in (0, B - 1):
+            assert rel(outs[0][1][b], P["J"][b].T @ P["f"][b]) < 1e-13
+
+
 def test_both_cholesky_kernels_agree_bit_for_bit(bl, monkeypatch):
     """N > 80: launches of at most 256 problems use the right-looking register kernel, larger ones the
     left-looking one (BLSQ_CHOL_RL forces either).  Both apply the same operands in the same order —
