@@ -386,6 +386,24 @@ def test_static_tile_row_kernel_matches_the_generic_one_bit_for_bit(bl, monkeypa
             assert np.array_equal(outs[0][0], o[0])
 
 
+@pytest.mark.parametrize("n", [15, 16, 17, 47, 48, 49, 62, 63, 64, 65, 79, 80, 81, 111, 112, 113,
+                               127, 128, 129, 239, 240, 241, 255, 256, 257])
+def test_every_kernel_dispatch_boundary(bl, n):
+    """Widths on both sides of every switch between kernels — narrow (direct from global) / tile
+    table / 8 column tiles / 16 column tiles for the Gram, one wave with the matrix in registers
+    (N <= 80) / a workgroup per problem for the Cholesky and the certificate, rhs column inside or
+    outside the MFMA tiles (n % 16) — both solvers, two row counts (one and several row chunks),
+    against the oracle at the 1e-10 bar with bit-exact masks."""
+    from bounded_lsq import _synth
+    for m in (3 * n + 5, 2048 + 3 * n):
+        P = _synth.trf_batch(500 + n, 2, m, n)
+        stats, _ = _check(bl, P, np.array([0.7, 0.05]))
+        assert stats == (2, 0)
+        Pd = _synth.dogbox_batch(900 + n, 2, m, n)
+        stats, _ = _check(bl, Pd, np.array([0.7, 0.05]), kind="dogbox")
+        assert stats == (2, 0)
+
+
 def test_chunk_pairs_summed_in_the_kernel_match_the_reduction_pass(bl, monkeypatch):
     """Two row chunks (2048 < m <= 4096), 16 column tiles and at least 256 problems: one workgroup
     takes both chunks and adds them in the kernel, (0 + P0) + P1 — what the separate reduction pass
