@@ -1755,10 +1755,7 @@ bool gram_supported(int m, int n) {
 // a problem's Gram (and so every bit of its result) does not depend on how many problems share the
 // launch.  2048 rows; 1024 for very tall problems (one 250 000 x 128 row block of BASELINE config 5:
 // 245 workgroups fill the 256 CUs, 123 leave half of them idle).
-static int gram_chunk_rows(int m) {
-  static const int tall_env = [] { const char* e = getenv("BLSQ_GRAM_TALL_ROWS"); return e ? atoi(e) : 0; }();
-  return m > 131072 ? (tall_env > 0 ? tall_env : 1024) : 2048;
-}
+static int gram_chunk_rows(int m) { return m > 131072 ? 1024 : 2048; }
 int gram_chunks(int B, int m) {
   (void)B;
   const int r = gram_chunk_rows(m);
