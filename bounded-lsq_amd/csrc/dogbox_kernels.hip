@@ -59,6 +59,7 @@ __global__ __launch_bounds__(DG_NT) void dog_prep_kernel(DogState st, int jac_sc
   double* S = st.S + (long)b * ld * ld;
   double* gm = sh;              // g masked to the free set (full length)
   double* u = gm + ld;
+  int* actl = (int*)(u + ld);   // [ld] active flags (the ordered free list is built from LDS)
 
   for (int j = tid; j < n; j += DG_NT) {
     double gj = 0.0, nn = 0.0;
@@ -97,13 +98,14 @@ __global__ __launch_bounds__(DG_NT) void dog_prep_kernel(DogState st, int jac_sc
     st.g[vo + j] = gj;
     const bool act = ((double)st.on_bound[vo + j] * gj) < 0.0;   // dogbox.py:172
     st.active[vo + j] = act ? 1 : 0;
+    actl[j] = act ? 1 : 0;
     gm[j] = act ? 0.0 : gj;
   }
   __syncthreads();
   if (tid == 0) {                                            // ordered free list
     int q = 0;
     for (int j = 0; j < n; ++j)
-      if (!st.active[vo + j]) st.free_idx[vo + q++] = j;
+      if (!actl[j]) st.free_idx[vo + q++] = j;
     nfree_s = q;
     st.ncols[b] = (q > 0) ? q + 1 : 0;
   }
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(DG_NT) void dog_prep_kernel(DogState st, int jac_sc
 
 hipError_t launch_dog_prep(const DogState& st, int jac_scaling, int from_gram, const int* sel,
                            int redo, hipStream_t s) {
-  const size_t lds = sizeof(double) * 2 * (size_t)st.ld;
+  const size_t lds = sizeof(double) * 2 * (size_t)st.ld + sizeof(int) * (size_t)st.ld;
   hipLaunchKernelGGL(dog_prep_kernel, dim3(st.B), dim3(DG_NT), lds, s, st, jac_scaling, from_gram,
                      sel, redo);
   return hipGetLastError();
