@@ -925,6 +925,21 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
     ctx->end();
     return ee;
   };
+  if (!p->use_qr && p->use_chol && p->lm_enable && p->ld <= 80) {
+    // N <= 80, every problem on the normal-equations path: all rounds in ONE launch (one wave per
+    // problem iterates to the end; gram_kernels.hip).  BLSQ_LM_FUSED = 0: the round-by-round loop.
+    const char* fe = getenv("BLSQ_LM_FUSED");
+    if (!(fe && fe[0] == '0')) {
+      GramCholArgs c{};
+      c.Gsrc = p->tree.gram_keep.as<double>(); c.NPAD = p->ld; c.n = p->n;
+      c.colscale = p->st.d; c.diag_vec = p->st.ediag; c.stride_vec = p->ld;
+      ctx->begin(K_LM_CHOL);
+      e = launch_lm_rounds_reg(c, p->lm, ctx->stream);
+      ctx->end();
+      if (e != hipSuccess) return ctx->fail(e, "launch_lm_rounds_reg");
+      return 0;
+    }
+  }
   HIPCHK(ctx, read_back(0));
   if (!p->use_qr && p->use_chol && p->lm_enable) {
     int bound = p->B;                                   // upper bound of the count of the round being enqueued

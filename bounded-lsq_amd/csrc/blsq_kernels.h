@@ -198,6 +198,13 @@ struct LmState {
                           // 0 -> by Cholesky of the modified Gram (nullptr: QR for all)
   int round;              // evaluation number of this launch (host-set)
 };
+// slots of LmState.sc / LmState.st, phases of the iteration (lm_kernels.hip; the fused rounds in gram_kernels.hip)
+enum { LM_IDLE = 0, LM_EVAL = 1, LM_FINAL = 2 };
+enum { SC_ALPHA = 0, SC_LO, SC_HI, SC_PHI, SC_DPHI, SC_DELTA, SC_SMAX, SC_SMIN };
+enum { ST_IT = 0, ST_PHASE, ST_NITER };
+// N <= 80, every problem on the normal-equations path: ALL Newton rounds of the problems lm_start
+// listed in one launch (one wave per problem; factor, solves and the update of alpha in registers / LDS)
+hipError_t launch_lm_rounds_reg(const GramCholArgs& c, const LmState& lm, hipStream_t s);
 hipError_t launch_lm_gate(const LmState& lm, int enable, hipStream_t s);
 hipError_t launch_lm_start(const LmState& lm, const double* Delta, const double* alpha_in,
                            hipStream_t s);

@@ -1297,6 +1297,261 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_reg_kernel(GramCholArgs a)
   }
 }
 
+// ---- N <= 80: ALL Newton rounds of a problem in one launch ----------------------------------------
+// The safeguarded Newton iteration on alpha (trust_region.py:126-150) factors H + alpha I once per
+// round.  For N <= 80 one wave owns a problem for the whole iteration: per round the factor of
+// gram_chol_reg_kernel (tiles in registers, nothing stored), p = -R^-1 c by block back substitution
+// and q = R^-T p by block forward substitution straight from the register tiles (tile x vector: four
+// FMAs per lane and tile + a 16-lane DPP sum, or a four-row sum through LDS for the transposed
+// product; the 16 x 16 diagonal solves are matvecs with the inverse tiles the chain produces anyway),
+// then the scalar update of lm_update_kernel, verbatim.  No launch, no counter read-back and no
+// triangle written between rounds (six stream operations per round otherwise, each with its dispatch
+// gap).  Everything happens in the equilibrated system:  R = R' diag(sq),  c = c' sq_n  =>
+//     p_j = -sq_n dl_j (R'^-1 c')_j ,      q = R'^-T (dl . p) .
+__device__ __forceinline__ double lm_restart_reg(double lo, double hi) {     // trust_region.py:128,134
+  const double gm = sqrt(lo * hi);
+  return (0.001 * hi > gm) ? 0.001 * hi : gm;
+}
+__global__ __launch_bounds__(GR_NT, 2) void lm_rounds_reg_kernel(GramCholArgs a, LmState lm) {
+  constexpr int MT = 5;
+  extern __shared__ double sh_all[];
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int pidx = (int)blockIdx.x * GR_NW + wv;
+  if (pidx >= lm.active_count[0]) return;               // (list 0: the problems lm_start left iterating)
+  const int b = lm.active_list[pidx];
+  if (!lm.fast[b]) return;
+  double* scv = lm.sc + (long)b * 16;
+  int* stv = lm.st + (long)b * 4;
+  int phase = stv[ST_PHASE];
+  if (phase == LM_IDLE) return;
+  const int lane = threadIdx.x & 63, lr = lane >> 4, lc = lane & 15;
+  const int NPAD = a.NPAD, n = a.n, N = n + 1;
+  const int NT = (N + 15) / 16, NTn = (n + 15) / 16;
+  const int jn = n >> 4, cn = n & 15;                   // tile column / column inside it of the rhs
+  double* sh = sh_all + (size_t)wv * (8 * (size_t)NPAD + 256 + MT * 256 + 16 + 64);
+  double* dl = sh;                 // [NPAD] 1 / sqrt(h_jj)
+  double* sq = dl + NPAD;          // [NPAD] sqrt(h_jj)
+  double* sc = sq + NPAD;          // [NPAD] colscale_j dl_j
+  double* td = sc + NPAD;          // [NPAD] (e_j^2 + alpha) dl_j^2
+  double* cv = td + NPAD;          // [NPAD] c' = R'[:, n]
+  double* yv = cv + NPAD;          // [NPAD] R'^-1 c', then dl . p
+  double* pv = yv + NPAD;          // [NPAD] p
+  double* zv = pv + NPAD;          // [NPAD] R'^-T (dl . p)
+  double* Dt = zv + NPAD;          // [256]
+  double* Ria = Dt + 256;          // [MT][256] inverse diagonal tiles
+  double* tv = Ria + MT * 256;     // [16]
+  double* xs = tv + 16;            // [64]
+  auto wsync = []() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); };
+  const double* Gs = a.Gsrc + (long)b * NPAD * NPAD;
+  const double* csv = a.colscale ? a.colscale + (long)b * a.stride_vec : nullptr;
+  const double* edv = a.diag_vec ? a.diag_vec + (long)b * a.stride_vec : nullptr;
+  auto tix = [](int i, int j) { return i * MT - i * (i - 1) / 2 + (j - i); };
+  double alpha = scv[SC_ALPHA], lo = scv[SC_LO], hi = scv[SC_HI], phi = scv[SC_PHI], dphi = scv[SC_DPHI];
+  const double Delta = scv[SC_DELTA];
+  int it = stv[ST_IT], n_iter = stv[ST_NITER];
+  for (int guard = 0; guard < 12; ++guard) {
+    const double sa = sqrt(alpha);
+    // ---- factor of H + alpha I (as gram_chol_reg_kernel; no gather, nothing stored) ----
+    for (int j = lane; j < NPAD; j += WAVE) {
+      const double cs = (csv && j < n) ? csv[j] : 1.0;
+      const double ej = (edv && j < n) ? edv[j] : 0.0;
+      const double add = (j < n) ? fma(ej, ej, sa * sa) : 0.0;
+      const double g = (j < N) ? fma(Gs[(long)j * NPAD + j] * cs, cs, add) : 0.0;
+      const bool okc = (g > 0.0) && is_finite(g);
+      double d = 1.0, s_ = 1.0;
+      if (j < N && okc) {
+        d = __builtin_amdgcn_rsq(g);
+        d = d * fma(-0.5 * g * d, d, 1.5);
+        d = d * fma(-0.5 * g * d, d, 1.5);
+        s_ = g * d;
+      }
+      dl[j] = d; sq[j] = s_; sc[j] = cs * d; td[j] = add * d * d;
+      yv[j] = 0.0; pv[j] = 0.0; zv[j] = 0.0;
+    }
+    wsync();
+    v4d acc[MT * (MT + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      double scr_[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) scr_[g] = sc[(16 * i + lr + 4 * g) < NPAD ? 16 * i + lr + 4 * g : NPAD - 1];
+#pragma unroll
+      for (int j = i; j < MT; ++j) {
+        v4d v4 = {0.0, 0.0, 0.0, 0.0};
+        if (j < NT) {
+          const int col = 16 * j + lc;
+          const int ccl = col < N ? col : N - 1;
+          const double scj = sc[col];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row = 16 * i + lr + 4 * g;
+            const int rcl = row < N ? row : N - 1;
+            const int lo_ = rcl < ccl ? rcl : ccl, hi_ = rcl < ccl ? ccl : rcl;
+            double v = Gs[(long)lo_ * NPAD + hi_];
+            v = (row < N && col < N) ? v * scr_[g] * scj : 0.0;
+            if (j == i && lr + 4 * g == lc) v += td[row];
+            v4[g] = v;
+          }
+        }
+        acc[tix(i, j)] = v4;
+      }
+    }
+    wsync();
+    double pmin = 1.0;
+#pragma unroll
+    for (int kb = 0; kb < MT; ++kb) {
+      if (kb < NT) {
+        double* Ri = Ria + kb * 256;
+        pmin = chol16_blocked3(acc[tix(kb, kb)], Dt, Ri, n - 16 * kb, pmin);
+        if (kb == jn) {                                 // the rhs column runs through this diagonal tile
+          if (lane < 16) cv[16 * kb + lane] = Dt[lane * 16 + cn];
+        }
+#pragma unroll
+        for (int j = kb + 1; j < MT; ++j) {
+          if (j < NT) {
+            v4d X = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) X = gmfma(Ri[(4 * s_ + lr) * 16 + lc], acc[tix(kb, j)][s_], X);
+            acc[tix(kb, j)] = X;
+            if (j == jn && lc == cn) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) cv[16 * kb + lr + 4 * g] = X[g];
+            }
+          }
+        }
+#pragma unroll
+        for (int i = kb + 1; i < MT; ++i) {
+#pragma unroll
+          for (int j = i; j < MT; ++j) {
+            if (j < NT) {
+#pragma unroll
+              for (int s_ = 0; s_ < 4; ++s_)
+                acc[tix(i, j)] = gmfma(-acc[tix(kb, i)][s_], acc[tix(kb, j)][s_], acc[tix(i, j)]);
+            }
+          }
+        }
+        wsync();
+      }
+    }
+    // ---- y = R'^-1 c' (rows and columns below n only), block rows from the bottom ----
+#pragma unroll
+    for (int kk = MT - 1; kk >= 0; --kk) {
+      if (kk < NTn) {
+        double part[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = kk + 1; j < MT; ++j) {
+          if (j < NTn) {
+            const double yj = yv[16 * j + lc];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) part[g] = fma(acc[tix(kk, j)][g], yj, part[g]);
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) part[g] = row16_sum(part[g]);
+        if (lc == 0) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) tv[lr + 4 * g] = cv[16 * kk + lr + 4 * g] - part[g];
+        }
+        wsync();
+        const int nb = (n - 16 * kk < 16) ? n - 16 * kk : 16;
+        const double* Rk = Ria + kk * 256;
+        double yi = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) yi = fma(Rk[lc * 16 + c], (c < nb) ? tv[c] : 0.0, yi);
+        if (lc >= nb) yi = 0.0;
+        if (lr == 0) yv[16 * kk + lc] = yi;
+        wsync();
+      }
+    }
+    // p = -sq_n dl . y,  |p|,  w = dl . p (kept in yv)
+    const double sqn = sq[n];
+    double pp = 0.0;
+    for (int j = lane; j < NPAD; j += WAVE) {
+      const double pj = (j < n) ? -(sqn * dl[j] * yv[j]) : 0.0;
+      pv[j] = pj;
+      pp = fma(pj, pj, pp);
+    }
+    wsync();
+    for (int j = lane; j < NPAD; j += WAVE) yv[j] = (j < n) ? dl[j] * pv[j] : 0.0;
+    const double pn = sqrt(wave_sum(pp));
+    wsync();
+    bool finished = false;
+    if (phase == LM_FINAL) {
+      finished = true;                                  // p at the updated alpha, rescale test on the STALE phi (:149)
+    } else {
+      // ---- z = R'^-T w, block rows from the top ----
+#pragma unroll
+      for (int kk = 0; kk < MT; ++kk) {
+        if (kk < NTn) {
+          double part = 0.0;
+#pragma unroll
+          for (int j = 0; j < kk; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) part = fma(acc[tix(j, kk)][g], zv[16 * j + lr + 4 * g], part);
+          }
+          xs[lane] = part;
+          wsync();
+          const double tot = (xs[lc] + xs[16 + lc]) + (xs[32 + lc] + xs[48 + lc]);
+          if (lr == 0) tv[lc] = yv[16 * kk + lc] - tot;
+          wsync();
+          const int nb = (n - 16 * kk < 16) ? n - 16 * kk : 16;
+          const double* Rk = Ria + kk * 256;
+          double zi = 0.0;
+#pragma unroll
+          for (int c = 0; c < 16; ++c) zi = fma(Rk[c * 16 + lc], (c <= lc) ? tv[c] : 0.0, zi);
+          if (lc >= nb) zi = 0.0;
+          if (lr == 0) zv[16 * kk + lc] = zi;
+          wsync();
+        }
+      }
+      double qq = 0.0;
+      for (int j = lane; j < NPAD; j += WAVE) { const double zj = (j < n) ? zv[j] : 0.0; qq = fma(zj, zj, qq); }
+      qq = wave_sum(qq);
+      // ---- the update of lm_update_kernel (trust_region.py:136-146) ----
+      phi = pn - Delta;
+      dphi = -qq / pn;
+      if (fabs(phi) < 0.01 * Delta) {                   // :138-139
+        finished = true;
+        n_iter = it + 1;
+      } else {
+        if (phi < 0.0) hi = alpha;                      // :141-142
+        const double ratio = phi / dphi;
+        const double cand = alpha - ratio;
+        lo = (cand > lo) ? cand : lo;                   // :145
+        alpha -= (phi + Delta) * ratio / Delta;         // :146
+        ++it;
+        if (it >= 10) {                                 // max_iter reached: final p at the new alpha
+          n_iter = 10;
+          phase = LM_FINAL;
+        } else {
+          if (alpha < lo || alpha > hi) alpha = lm_restart_reg(lo, hi);   // :133-134 of the next pass
+          phase = LM_EVAL;
+        }
+      }
+    }
+    if (finished) {
+      const double f = (phi > 0.0) ? Delta / pn : 1.0;  // :149-150
+      for (int j = lane; j < n; j += WAVE) lm.ph[(long)b * lm.ld + j] = pv[j] * f;
+      break;
+    }
+  }
+  if (lane == 0) {
+    scv[SC_ALPHA] = alpha; scv[SC_LO] = lo; scv[SC_HI] = hi; scv[SC_PHI] = phi; scv[SC_DPHI] = dphi;
+    stv[ST_IT] = it; stv[ST_PHASE] = LM_IDLE; stv[ST_NITER] = n_iter;
+    lm.sa[b] = sqrt(alpha);
+    lm.ncols_lm[b] = 0;
+  }
+}
+
+hipError_t launch_lm_rounds_reg(const GramCholArgs& c, const LmState& lm, hipStream_t s) {
+  const size_t per = sizeof(double) * (8 * (size_t)c.NPAD + 256 + 5 * 256 + 16 + 64);
+  static std::atomic<size_t> granted[64];
+  hipError_t ge = gram_grant_lds(lm_rounds_reg_kernel, per * GR_NW, granted);
+  if (ge != hipSuccess) return ge;
+  hipLaunchKernelGGL(lm_rounds_reg_kernel, dim3((lm.B + GR_NW - 1) / GR_NW), dim3(GR_NT), per * GR_NW, s, c, lm);
+  return hipGetLastError();
+}
+
 // ---- right-looking variant: the whole (scaled) matrix lives in accumulators ----------------------
 // The NT (NT + 1) / 2 <= 153 upper tiles are dealt CYCLICALLY (row-major tile q -> wave q % 8, slot
 // q / 8) so that the shrinking trailing matrix stays balanced, and never leave the registers until

@@ -43,11 +43,7 @@ static hipError_t grant_lds(K kernel, size_t bytes, std::atomic<size_t>* granted
 static constexpr double LM_EPS = 2.220446049250313e-16;
 static constexpr double LM_GATE_MARGIN = 1.0e3;
 
-enum { LM_IDLE = 0, LM_EVAL = 1, LM_FINAL = 2 };
-// sc[] slots
-enum { SC_ALPHA = 0, SC_LO, SC_HI, SC_PHI, SC_DPHI, SC_DELTA, SC_SMAX, SC_SMIN };
-// st[] slots
-enum { ST_IT = 0, ST_PHASE, ST_NITER };
+// (phases and the sc[] / st[] slots: blsq_kernels.h)
 
 // ------------------------------------------------------------------- gate --
 __global__ __launch_bounds__(TRI_NT) void lm_gate_kernel(LmState lm, int enable) {
