@@ -188,6 +188,7 @@ struct QrTree {
   DevBuf gram_keep;                 // [B][NPAD*NPAD] the Grams themselves (kept: the trust-region
                                     // systems are diagonal modifications of them)
   DevBuf gram_rinv, gram_ywork, gram_k2;   // conditioning certificate: inverse diagonal tiles, Y = R'^-T, bound [B]
+  DevBuf gram_cert;                        // [B] ints: 1 = proven inside the factor kernel (N <= 80)
   // per-problem path of the CURRENT triangles: gram_path()[b] = n + 1 (Householder tree) or 0 (Gram).
   // any_gram / any_qr: whether a problem of either kind can exist (host-side upper bounds)
   bool any_gram = false, any_qr = true;
@@ -255,6 +256,10 @@ struct QrTree {
       if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Gram gate work)");
       e = gram_k2.alloc(sizeof(double) * (size_t)B);
       if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Gram gate bound)");
+      e = gram_cert.alloc(sizeof(int) * (size_t)B);
+      if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Gram certificate flags)");
+      e = hipMemsetAsync(gram_cert.p, 0, gram_cert.bytes, ctx->stream);
+      if (e != hipSuccess) return ctx->fail(e, "hipMemsetAsync(Gram certificate flags)");
       e = hipMemsetAsync(gram_k2.p, 0, gram_k2.bytes, ctx->stream);
       if (e != hipSuccess) return ctx->fail(e, "hipMemsetAsync(Gram gate bound)");
       e = gram_ints.alloc(sizeof(int) * (3 * (size_t)B + 4));     // launch mask, count, path, fallback list
@@ -270,7 +275,7 @@ struct QrTree {
     for (auto& L : levels) L.R.release();
     V.release(); T.release();
     gram_part.release(); gram_dsc.release(); gram_ints.release(); gram_keep.release();
-    gram_rinv.release(); gram_ywork.release(); gram_k2.release();
+    gram_rinv.release(); gram_ywork.release(); gram_k2.release(); gram_cert.release();
   }
   // [J f] -> triangle by the normal equations where the conditioning gate allows it.
   // Returns the number of problems left for the Householder tree in *nfallback; their indices
@@ -824,6 +829,7 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb) 
   c.fail_list = t.fb_list();
   c.dsc = t.gram_dsc.as<double>();
   c.rinv = t.gram_rinv.as<double>(); c.ywork = t.gram_ywork.as<double>(); c.k2_out = t.gram_k2.as<double>();
+  c.cert_done = t.gram_cert.as<int>();
   c.colinfo = p->aug_colinfo.as<double>();
   ctx->begin(K_AUG_CHOL);
   e = launch_gram_chol(c, p->B, ctx->stream);
@@ -1551,6 +1557,7 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
   c.fail_list = t.fb_list();
   c.dsc = t.gram_dsc.as<double>();
   c.rinv = t.gram_rinv.as<double>(); c.ywork = t.gram_ywork.as<double>(); c.k2_out = t.gram_k2.as<double>();
+  c.cert_done = t.gram_cert.as<int>();
   c.colinfo = p->colinfo.as<double>();
   ctx->begin(K_AUG_CHOL);
   e = launch_gram_chol(c, p->B, ctx->stream);

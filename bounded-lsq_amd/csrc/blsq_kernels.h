@@ -95,6 +95,8 @@ struct GramCholArgs {
   // conditioning certificate (launch_gram_gate)
   double* ywork;          // [B][NPAD*NPAD] scratch: Y = R'^-T
   double* k2_out;         // optional [B] out: the proven bound on kappa_2 of the equilibrated system
+  int* cert_done;         // optional [B]: 1 = the factor kernel itself proved K2 <= GRAM_K2_MAX (N <= 80: the
+                          // register-resident kernel has R' at hand); launch_gram_gate then skips the problem
 };
 // A problem stays on the normal-equations path only if the PROVEN bound K2 >= kappa_2(R'^T R') of its
 // equilibrated system is at most GRAM_K2_MAX (gram_kernels.hip, gram_cond_kernel).  Consequence used

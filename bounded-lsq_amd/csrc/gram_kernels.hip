@@ -1129,7 +1129,7 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_reg_kernel(GramCholArgs a)
   const int lane = threadIdx.x & 63, tid = lane;
   const int lr = lane >> 4, lc = lane & 15;
   const int NPAD = a.NPAD;
-  double* sh = sh_all + (size_t)wv * (4 * (size_t)NPAD + 512);
+  double* sh = sh_all + (size_t)wv * (4 * (size_t)NPAD + 256 + MT * 256 + 64);
   auto wsync = []() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); };
   if (a.mask && a.mask[b] <= 1) {
     if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
@@ -1151,12 +1151,13 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_reg_kernel(GramCholArgs a)
   double* sq = dl + NPAD;          // [NPAD] sqrt(h_jj)
   double* sc = sq + NPAD;          // [NPAD] colscale_j * dl_j
   double* Dt = sc + NPAD;          // [256]  diagonal tile (row-major)
-  double* Ri = Dt + 256;           // [256]  its inverse
-  double* td = Ri + 256;           // [NPAD] (e_j^2 + alpha) * dl_j^2
+  double* Ria = Dt + 256;          // [MT][256] the inverses of the diagonal tiles (kept: certificate below)
+  double* td = Ria + MT * 256;     // [NPAD] (e_j^2 + alpha) * dl_j^2
+  double* xs = td + NPAD;          // [64]   four-row sums
   const double* csv = a.colscale ? a.colscale + (long)b * a.stride_vec : nullptr;
   const double* edv = a.diag_vec ? a.diag_vec + (long)b * a.stride_vec : nullptr;
   const double sa = a.diag_sqrt ? a.diag_sqrt[b] : 0.0;
-  int* sidx = (int*)Ri;            // [NPAD] source indices — only until the tiles are loaded (Ri is free till then)
+  int* sidx = (int*)Ria;           // [NPAD] source indices — only until the tiles are loaded (Ria is free till then)
   // 0. column scales from the diagonal of H
   int bad = 0;
   for (int j = tid; j < NPAD; j += WAVE) {
@@ -1244,6 +1245,7 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_reg_kernel(GramCholArgs a)
   for (int kb = 0; kb < MT; ++kb) {
     if (kb < NT) {
       // 2. chain of the diagonal tile: R'_kk -> Dt, its inverse -> Ri
+      double* Ri = Ria + kb * 256;
       pmin = chol16_blocked3(acc[tix(kb, kb)], Dt, Ri, n - 16 * kb, pmin);
       if (a.rinv) {                                     // kept for the conditioning certificate
         double* ro = a.rinv + ((long)b * (NPAD / 16) + kb) * 256;
@@ -1258,6 +1260,7 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_reg_kernel(GramCholArgs a)
           if (j == kb) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) X[g] = Dt[(lr + 4 * g) * 16 + lc];
+            acc[tix(kb, kb)] = X;                       // (all 15 tiles of R' stay in registers: certificate)
           } else {
 #pragma unroll
             for (int s_ = 0; s_ < 4; ++s_) X = gmfma(Ri[(4 * s_ + lr) * 16 + lc], acc[tix(kb, j)][s_], X);
@@ -1289,11 +1292,114 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_reg_kernel(GramCholArgs a)
       wsync();                                          // (Dt / Ri are rewritten by the next chain)
     }
   }
+  const bool fail = !(pmin >= GRAM_SMIN * GRAM_SMIN);
   if (tid == 0 && a.fb_mask) {
-    const bool fail = !(pmin >= GRAM_SMIN * GRAM_SMIN);
     a.fb_mask[b] = fail ? a.n + 1 : 0;
     if (a.path_out) a.path_out[b] = fail ? a.n + 1 : 0;
     if (fail) { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
+  }
+  // 5. The first bound of the conditioning certificate (gram_cond_kernel below: same quantities, same
+  //    definition) while R' and the inverse diagonal tiles are still at hand:
+  //        K2 = ||R'||_1 ||R'||_inf ||Y||_1 ||Y||_inf ,   Y = R'^-T  column block by column block.
+  //    K2 <= GRAM_K2_MAX settles the problem here; otherwise the separate kernel decides (it also
+  //    has the tighter Frobenius bound).
+  if (a.cert_done) {
+    bool passed = false;
+    double k2 = 0.0;
+    if (!fail) {
+      const int NTn = (n + 15) / 16;
+      double r1 = 0.0, rinf = 0.0, y1 = 0.0, yinf = 0.0;
+      double colp[MT];
+#pragma unroll
+      for (int jj = 0; jj < MT; ++jj) colp[jj] = 0.0;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if (i < NTn) {
+          double rp[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int jj = i; jj < MT; ++jj) {
+            if (jj < NTn) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int row = 16 * i + lr + 4 * g, col = 16 * jj + lc;
+                const double v = (row < n && col < n) ? fabs(acc[tix(i, jj)][g]) : 0.0;
+                rp[g] += v; colp[jj] += v;
+              }
+            }
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) rinf = fmax(rinf, row16_sum(rp[g]));
+        }
+      }
+      rinf = wave_max(rinf);
+#pragma unroll
+      for (int jj = 0; jj < MT; ++jj) {
+        if (jj < NTn) {
+          xs[lane] = colp[jj];
+          wsync();
+          r1 = fmax(r1, (xs[lc] + xs[16 + lc]) + (xs[32 + lc] + xs[48 + lc]));
+          wsync();
+        }
+      }
+      r1 = wave_max(r1);
+      double rsY[MT][4];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rsY[i][g] = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < MT; ++jj) {
+        if (jj < NTn) {
+          v4d Yc[MT];
+          double cY = 0.0;
+#pragma unroll
+          for (int i = jj; i < MT; ++i) {
+            if (i < NTn) {
+              v4d Yt = {0.0, 0.0, 0.0, 0.0};
+              if (i == jj) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) Yt[g] = Ria[jj * 256 + lc * 16 + lr + 4 * g];   // (R'_jj^-1)^T
+              } else {
+                v4d av = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = jj; kk < i; ++kk) {
+#pragma unroll
+                  for (int s_ = 0; s_ < 4; ++s_) av = gmfma(acc[tix(kk, i)][s_], Yc[kk][s_], av);
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) Yt = gmfma(-Ria[i * 256 + (4 * s_ + lr) * 16 + lc], av[s_], Yt);
+              }
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int row = 16 * i + lr + 4 * g, col = 16 * jj + lc;
+                const double v = (row < n && col < n) ? Yt[g] : 0.0;
+                Yt[g] = v;
+                const double av_ = fabs(v);
+                rsY[i][g] += row16_sum(av_);
+                cY += av_;
+              }
+              Yc[i] = Yt;
+            }
+          }
+          xs[lane] = cY;
+          wsync();
+          y1 = fmax(y1, (xs[lc] + xs[16 + lc]) + (xs[32 + lc] + xs[48 + lc]));
+          wsync();
+        }
+      }
+      y1 = wave_max(y1);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) yinf = fmax(yinf, rsY[i][g]);
+      yinf = wave_max(yinf);
+      k2 = (r1 * rinf) * (y1 * yinf);
+      passed = k2 <= GRAM_K2_MAX;                       // (NaN fails)
+    }
+    if (tid == 0) {
+      a.cert_done[b] = passed ? 1 : 0;
+      if (passed && a.k2_out) a.k2_out[b] = k2;
+    }
   }
 }
 
@@ -1804,6 +1910,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_cond_kernel(GramCholArgs a) {
   const int lr = lane >> 4, lc = lane & 15;
   if (a.mask && a.mask[b] <= 1) return;
   if (a.fb_mask[b] != 0) return;                        // already failed on a pivot
+  if (a.cert_done && a.cert_done[b]) return;            // already proven inside the factor kernel (N <= 80)
   const int NPAD = a.NPAD;
   const int n = a.ncols_dev ? a.ncols_dev[b] - 1 : a.n;
   if (n <= 0) return;
@@ -2186,9 +2293,14 @@ hipError_t launch_gram_chol(const GramCholArgs& a_in, int B, hipStream_t s) {
     if (rge && rge[0] == '0')
       hipLaunchKernelGGL(gram_chol_kernel<1>, dim3((B + GR_NW - 1) / GR_NW), dim3(GR_NT), per * GR_NW,
                          s, a);
-    else
-      hipLaunchKernelGGL(gram_chol_reg_kernel, dim3((B + GR_NW - 1) / GR_NW), dim3(GR_NT), per * GR_NW,
+    else {
+      const size_t per_reg = sizeof(double) * (4 * (size_t)a.NPAD + 256 + 5 * 256 + 64);
+      static std::atomic<size_t> granted[64];
+      hipError_t ge = gram_grant_lds(gram_chol_reg_kernel, per_reg * GR_NW, granted);
+      if (ge != hipSuccess) return ge;
+      hipLaunchKernelGGL(gram_chol_reg_kernel, dim3((B + GR_NW - 1) / GR_NW), dim3(GR_NT), per_reg * GR_NW,
                          s, a);
+    }
   } else {
     // Right-looking register variant: 0.22 ms per problem on a CU of its own against 0.27 ms for
     // the left-looking kernel, but one workgroup per CU instead of two — so it serves the launches
