@@ -907,9 +907,30 @@ int trf_factor_core(blsq_trf_plan* p, const double* dJ, const double* df, int ld
 int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_in) {
   blsq_ctx* ctx = p->ctx;
   int* counts = p->lm.active_count;
+  hipError_t e;
+  p->lm.fused_gram = 0;
+  if (p->use_chol && p->lm_enable && p->ld <= 80) {
+    // N <= 80: the Gauss-Newton step, the bracket and ALL rounds of every normal-equations-path problem
+    // in ONE launch (one wave per problem iterates to the end; gram_kernels.hip).  Householder-path
+    // problems of the same batch go through lm_start and the round loop below.
+    // BLSQ_LM_FUSED = 0: lm_start + the round-by-round loop for everybody.
+    const char* fe = getenv("BLSQ_LM_FUSED");
+    if (!(fe && fe[0] == '0')) {
+      GramCholArgs c{};
+      c.Gsrc = p->tree.gram_keep.as<double>(); c.NPAD = p->ld; c.n = p->n;
+      c.colscale = p->st.d; c.diag_vec = p->st.ediag; c.stride_vec = p->ld;
+      c.rinv = p->tree.gram_rinv.as<double>(); c.dsc = p->tree.gram_dsc.as<double>();
+      ctx->begin(K_LM_CHOL);
+      e = launch_lm_rounds_reg(c, p->lm, dDelta, dalpha_in, ctx->stream);
+      ctx->end();
+      if (e != hipSuccess) return ctx->fail(e, "launch_lm_rounds_reg");
+      if (!p->use_qr) return 0;
+      p->lm.fused_gram = 1;
+    }
+  }
   HIPCHK(ctx, hipMemsetAsync(counts, 0, 16 * sizeof(int), ctx->stream));
   ctx->begin(K_LM_SOLVE);
-  hipError_t e = launch_lm_start(p->lm, dDelta, dalpha_in, ctx->stream);
+  e = launch_lm_start(p->lm, dDelta, dalpha_in, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_lm_start");
   int* pin = ctx->pinned + 8;
@@ -931,21 +952,6 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
     ctx->end();
     return ee;
   };
-  if (!p->use_qr && p->use_chol && p->lm_enable && p->ld <= 80) {
-    // N <= 80, every problem on the normal-equations path: all rounds in ONE launch (one wave per
-    // problem iterates to the end; gram_kernels.hip).  BLSQ_LM_FUSED = 0: the round-by-round loop.
-    const char* fe = getenv("BLSQ_LM_FUSED");
-    if (!(fe && fe[0] == '0')) {
-      GramCholArgs c{};
-      c.Gsrc = p->tree.gram_keep.as<double>(); c.NPAD = p->ld; c.n = p->n;
-      c.colscale = p->st.d; c.diag_vec = p->st.ediag; c.stride_vec = p->ld;
-      ctx->begin(K_LM_CHOL);
-      e = launch_lm_rounds_reg(c, p->lm, ctx->stream);
-      ctx->end();
-      if (e != hipSuccess) return ctx->fail(e, "launch_lm_rounds_reg");
-      return 0;
-    }
-  }
   HIPCHK(ctx, read_back(0));
   if (!p->use_qr && p->use_chol && p->lm_enable) {
     int bound = p->B;                                   // upper bound of the count of the round being enqueued
@@ -976,7 +982,7 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
   HIPCHK(ctx, hipEventSynchronize(ctx->lm_ev[0]));
   int active = pin[0];
   for (int round = 0; round < 12 && active > 0; ++round) {
-    if (p->use_chol) {
+    if (p->use_chol && !p->lm.fused_gram) {
       e = chol_round(round, active, active, nullptr);
       if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(lm)");
     }

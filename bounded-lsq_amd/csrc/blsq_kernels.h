@@ -199,6 +199,9 @@ struct LmState {
   const int* path;        // optional [B]: != 0 -> the problem's Newton systems are factored by QR,
                           // 0 -> by Cholesky of the modified Gram (nullptr: QR for all)
   int round;              // evaluation number of this launch (host-set)
+  int fused_gram;         // 1: problems with path[b] == 0 belong to lm_rounds_reg_kernel (N <= 80) — lm_start
+                          // and the round kernels leave them alone (a problem's arithmetic must not depend
+                          // on whether its batch also holds Householder-path problems)
 };
 // slots of LmState.sc / LmState.st, phases of the iteration (lm_kernels.hip; the fused rounds in gram_kernels.hip)
 enum { LM_IDLE = 0, LM_EVAL = 1, LM_FINAL = 2 };
@@ -206,7 +209,10 @@ enum { SC_ALPHA = 0, SC_LO, SC_HI, SC_PHI, SC_DPHI, SC_DELTA, SC_SMAX, SC_SMIN }
 enum { ST_IT = 0, ST_PHASE, ST_NITER };
 // N <= 80, every problem on the normal-equations path: ALL Newton rounds of the problems lm_start
 // listed in one launch (one wave per problem; factor, solves and the update of alpha in registers / LDS)
-hipError_t launch_lm_rounds_reg(const GramCholArgs& c, const LmState& lm, hipStream_t s);
+// the launch takes the place of lm_start and of every round for the normal-equations-path problems
+// of the batch (c.rinv / c.dsc = what the augmented Cholesky left)
+hipError_t launch_lm_rounds_reg(const GramCholArgs& c, const LmState& lm, const double* Delta,
+                                const double* alpha_in, hipStream_t s);
 hipError_t launch_lm_gate(const LmState& lm, int enable, hipStream_t s);
 hipError_t launch_lm_start(const LmState& lm, const double* Delta, const double* alpha_in,
                            hipStream_t s);

@@ -1418,19 +1418,30 @@ __device__ __forceinline__ double lm_restart_reg(double lo, double hi) {     // 
   const double gm = sqrt(lo * hi);
   return (0.001 * hi > gm) ? 0.001 * hi : gm;
 }
-__global__ __launch_bounds__(GR_NT, 2) void lm_rounds_reg_kernel(GramCholArgs a, LmState lm) {
+// The launch first does what lm_start_kernel does — the Gauss-Newton step from the AUGMENTED factor
+// (its stored triangle, column scales and inverse diagonal tiles are re-loaded: R' = R diag(dl)), the
+// acceptance test |p| <= Delta and the bracket (trust_region.py:116-130) — for every
+// normal-equations-path problem of the batch (the others are left to lm_start and the round loop,
+// LmState.fused_gram): no list, no counter, and the same arithmetic for a problem whatever else its
+// batch holds.
+__global__ __launch_bounds__(GR_NT, 2) void lm_rounds_reg_kernel(GramCholArgs a, LmState lm,
+                                                                 const double* Delta_in,
+                                                                 const double* alpha_in) {
   constexpr int MT = 5;
+  constexpr bool start = true;
   extern __shared__ double sh_all[];
   const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int pidx = (int)blockIdx.x * GR_NW + wv;
-  if (pidx >= lm.active_count[0]) return;               // (list 0: the problems lm_start left iterating)
-  const int b = lm.active_list[pidx];
-  if (!lm.fast[b]) return;
+  const int b = (int)blockIdx.x * GR_NW + wv;
+  if (b >= lm.B) return;
+  if (lm.path && lm.path[b] != 0) return;               // (Householder-path problem: lm_start and the round loop)
+  const int lane = threadIdx.x & 63, lr = lane >> 4, lc = lane & 15;
+  if (!lm.fast[b]) {
+    if (lane == 0) lm.ncols_lm[b] = 0;
+    return;
+  }
   double* scv = lm.sc + (long)b * 16;
   int* stv = lm.st + (long)b * 4;
-  int phase = stv[ST_PHASE];
-  if (phase == LM_IDLE) return;
-  const int lane = threadIdx.x & 63, lr = lane >> 4, lc = lane & 15;
+  int phase = LM_EVAL;
   const int NPAD = a.NPAD, n = a.n, N = n + 1;
   const int NT = (N + 15) / 16, NTn = (n + 15) / 16;
   const int jn = n >> 4, cn = n & 15;                   // tile column / column inside it of the rhs
@@ -1452,9 +1463,155 @@ __global__ __launch_bounds__(GR_NT, 2) void lm_rounds_reg_kernel(GramCholArgs a,
   const double* csv = a.colscale ? a.colscale + (long)b * a.stride_vec : nullptr;
   const double* edv = a.diag_vec ? a.diag_vec + (long)b * a.stride_vec : nullptr;
   auto tix = [](int i, int j) { return i * MT - i * (i - 1) / 2 + (j - i); };
-  double alpha = scv[SC_ALPHA], lo = scv[SC_LO], hi = scv[SC_HI], phi = scv[SC_PHI], dphi = scv[SC_DPHI];
-  const double Delta = scv[SC_DELTA];
-  int it = stv[ST_IT], n_iter = stv[ST_NITER];
+  v4d acc[MT * (MT + 1) / 2];
+  double sqn = 1.0;
+
+  // y = R'^-1 c' (rows and columns below n only; c' in cv), block rows from the bottom -> yv
+  auto back_solve = [&]() {
+#pragma unroll
+    for (int kk = MT - 1; kk >= 0; --kk) {
+      if (kk < NTn) {
+        double part[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = kk + 1; j < MT; ++j) {
+          if (j < NTn) {
+            const double yj = yv[16 * j + lc];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) part[g] = fma(acc[tix(kk, j)][g], yj, part[g]);
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) part[g] = row16_sum(part[g]);
+        if (lc == 0) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) tv[lr + 4 * g] = cv[16 * kk + lr + 4 * g] - part[g];
+        }
+        wsync();
+        const int nb = (n - 16 * kk < 16) ? n - 16 * kk : 16;
+        const double* Rk = Ria + kk * 256;
+        double yi = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) yi = fma(Rk[lc * 16 + c], (c < nb) ? tv[c] : 0.0, yi);
+        if (lc >= nb) yi = 0.0;
+        if (lr == 0) yv[16 * kk + lc] = yi;
+        wsync();
+      }
+    }
+  };
+  // p = -sq_n dl . y -> pv,  w = dl . p -> yv;  returns |p|
+  auto form_p = [&]() -> double {
+    double pp = 0.0;
+    for (int j = lane; j < NPAD; j += WAVE) {
+      const double pj = (j < n) ? -(sqn * dl[j] * yv[j]) : 0.0;
+      pv[j] = pj;
+      pp = fma(pj, pj, pp);
+    }
+    wsync();
+    for (int j = lane; j < NPAD; j += WAVE) yv[j] = (j < n) ? dl[j] * pv[j] : 0.0;
+    const double pn_ = sqrt(wave_sum(pp));
+    wsync();
+    return pn_;
+  };
+  // z = R'^-T w (w in yv), block rows from the top -> zv;  returns |z|^2
+  auto fwd_solve = [&]() -> double {
+#pragma unroll
+    for (int kk = 0; kk < MT; ++kk) {
+      if (kk < NTn) {
+        double part = 0.0;
+#pragma unroll
+        for (int j = 0; j < kk; ++j) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) part = fma(acc[tix(j, kk)][g], zv[16 * j + lr + 4 * g], part);
+        }
+        xs[lane] = part;
+        wsync();
+        const double tot = (xs[lc] + xs[16 + lc]) + (xs[32 + lc] + xs[48 + lc]);
+        if (lr == 0) tv[lc] = yv[16 * kk + lc] - tot;
+        wsync();
+        const int nb = (n - 16 * kk < 16) ? n - 16 * kk : 16;
+        const double* Rk = Ria + kk * 256;
+        double zi = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) zi = fma(Rk[c * 16 + lc], (c <= lc) ? tv[c] : 0.0, zi);
+        if (lc >= nb) zi = 0.0;
+        if (lr == 0) zv[16 * kk + lc] = zi;
+        wsync();
+      }
+    }
+    double qq = 0.0;
+    for (int j = lane; j < NPAD; j += WAVE) { const double zj = (j < n) ? zv[j] : 0.0; qq = fma(zj, zj, qq); }
+    return wave_sum(qq);
+  };
+
+  double alpha, lo, hi, phi, dphi, Delta;
+  int it, n_iter;
+  if (start) {
+    // ---- the augmented factor back into registers:  R' = R diag(dl),  Ri from the factor kernel ----
+    Delta = Delta_in[b];
+    const double* Ra = lm.Raug + (long)b * NPAD * NPAD;
+    const double* dsc = a.dsc + (long)b * NPAD;
+    const double* rinv = a.rinv + (long)b * (NPAD / 16) * 256;
+    for (int j = lane; j < NPAD; j += WAVE) { dl[j] = dsc[j]; yv[j] = 0.0; pv[j] = 0.0; zv[j] = 0.0; }
+    for (int e = lane; e < NT * 256; e += WAVE) Ria[e] = rinv[e];
+    wsync();
+    sqn = 1.0 / dl[n];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int j = i; j < MT; ++j) {
+        v4d v4 = {0.0, 0.0, 0.0, 0.0};
+        if (j < NT) {
+          const int col = 16 * j + lc;
+          const double dj = dl[col];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) v4[g] = Ra[(long)(16 * i + lr + 4 * g) * NPAD + col] * dj;
+        }
+        acc[tix(i, j)] = v4;
+      }
+    }
+    for (int r = lane; r < NPAD; r += WAVE) cv[r] = (r < n) ? Ra[(long)r * NPAD + n] * dl[n] : 0.0;
+    wsync();
+    // |R^T c| = sq_n |sq . (R'^T c')|  (alpha_upper = |A^T b| / Delta, trust_region.py:111-113)
+    double gg = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < MT; ++kk) {
+      if (kk < NTn) {
+        double part = 0.0;
+#pragma unroll
+        for (int j = 0; j <= kk; ++j) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) part = fma(acc[tix(j, kk)][g], cv[16 * j + lr + 4 * g], part);
+        }
+        xs[lane] = part;
+        wsync();
+        const double tot = (xs[lc] + xs[16 + lc]) + (xs[32 + lc] + xs[48 + lc]);
+        const int col = 16 * kk + lc;
+        const double gj = (col < n) ? tot / dl[col] : 0.0;
+        if (lr == 0) gg = fma(gj, gj, gg);
+        wsync();
+      }
+    }
+    const double gnorm = sqn * sqrt(wave_sum(gg));
+    back_solve();
+    const double pn = form_p();
+    for (int j = lane; j < n; j += WAVE) lm.ph[(long)b * lm.ld + j] = pv[j];
+    if (pn <= Delta) {                                  // trust_region.py:116-117
+      if (lane == 0) {
+        scv[SC_ALPHA] = 0.0; stv[ST_NITER] = 0; stv[ST_PHASE] = LM_IDLE; scv[SC_DELTA] = Delta;
+        lm.ncols_lm[b] = 0;
+      }
+      return;
+    }
+    const double qq = fwd_solve();                      // phi(0), phi'(0) -> alpha_lower (:121-123)
+    phi = pn - Delta;
+    dphi = -qq / pn;
+    hi = gnorm / Delta;
+    lo = -phi / dphi;
+    alpha = alpha_in[b];                                // :127-130 (full rank)
+    if (alpha < lo || alpha > hi) alpha = lm_restart_reg(lo, hi);   // :133-134, iteration 0
+    it = 0; n_iter = 0;
+    if (lane == 0) scv[SC_DELTA] = Delta;
+  }
   for (int guard = 0; guard < 12; ++guard) {
     const double sa = sqrt(alpha);
     // ---- factor of H + alpha I (as gram_chol_reg_kernel; no gather, nothing stored) ----
@@ -1475,7 +1632,7 @@ __global__ __launch_bounds__(GR_NT, 2) void lm_rounds_reg_kernel(GramCholArgs a,
       yv[j] = 0.0; pv[j] = 0.0; zv[j] = 0.0;
     }
     wsync();
-    v4d acc[MT * (MT + 1) / 2];
+    sqn = sq[n];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       double scr_[4];
@@ -1539,80 +1696,13 @@ __global__ __launch_bounds__(GR_NT, 2) void lm_rounds_reg_kernel(GramCholArgs a,
         wsync();
       }
     }
-    // ---- y = R'^-1 c' (rows and columns below n only), block rows from the bottom ----
-#pragma unroll
-    for (int kk = MT - 1; kk >= 0; --kk) {
-      if (kk < NTn) {
-        double part[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int j = kk + 1; j < MT; ++j) {
-          if (j < NTn) {
-            const double yj = yv[16 * j + lc];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) part[g] = fma(acc[tix(kk, j)][g], yj, part[g]);
-          }
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) part[g] = row16_sum(part[g]);
-        if (lc == 0) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g) tv[lr + 4 * g] = cv[16 * kk + lr + 4 * g] - part[g];
-        }
-        wsync();
-        const int nb = (n - 16 * kk < 16) ? n - 16 * kk : 16;
-        const double* Rk = Ria + kk * 256;
-        double yi = 0.0;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) yi = fma(Rk[lc * 16 + c], (c < nb) ? tv[c] : 0.0, yi);
-        if (lc >= nb) yi = 0.0;
-        if (lr == 0) yv[16 * kk + lc] = yi;
-        wsync();
-      }
-    }
-    // p = -sq_n dl . y,  |p|,  w = dl . p (kept in yv)
-    const double sqn = sq[n];
-    double pp = 0.0;
-    for (int j = lane; j < NPAD; j += WAVE) {
-      const double pj = (j < n) ? -(sqn * dl[j] * yv[j]) : 0.0;
-      pv[j] = pj;
-      pp = fma(pj, pj, pp);
-    }
-    wsync();
-    for (int j = lane; j < NPAD; j += WAVE) yv[j] = (j < n) ? dl[j] * pv[j] : 0.0;
-    const double pn = sqrt(wave_sum(pp));
-    wsync();
+    back_solve();
+    const double pn = form_p();
     bool finished = false;
     if (phase == LM_FINAL) {
       finished = true;                                  // p at the updated alpha, rescale test on the STALE phi (:149)
     } else {
-      // ---- z = R'^-T w, block rows from the top ----
-#pragma unroll
-      for (int kk = 0; kk < MT; ++kk) {
-        if (kk < NTn) {
-          double part = 0.0;
-#pragma unroll
-          for (int j = 0; j < kk; ++j) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) part = fma(acc[tix(j, kk)][g], zv[16 * j + lr + 4 * g], part);
-          }
-          xs[lane] = part;
-          wsync();
-          const double tot = (xs[lc] + xs[16 + lc]) + (xs[32 + lc] + xs[48 + lc]);
-          if (lr == 0) tv[lc] = yv[16 * kk + lc] - tot;
-          wsync();
-          const int nb = (n - 16 * kk < 16) ? n - 16 * kk : 16;
-          const double* Rk = Ria + kk * 256;
-          double zi = 0.0;
-#pragma unroll
-          for (int c = 0; c < 16; ++c) zi = fma(Rk[c * 16 + lc], (c <= lc) ? tv[c] : 0.0, zi);
-          if (lc >= nb) zi = 0.0;
-          if (lr == 0) zv[16 * kk + lc] = zi;
-          wsync();
-        }
-      }
-      double qq = 0.0;
-      for (int j = lane; j < NPAD; j += WAVE) { const double zj = (j < n) ? zv[j] : 0.0; qq = fma(zj, zj, qq); }
-      qq = wave_sum(qq);
+      const double qq = fwd_solve();
       // ---- the update of lm_update_kernel (trust_region.py:136-146) ----
       phi = pn - Delta;
       dphi = -qq / pn;
@@ -1649,12 +1739,14 @@ __global__ __launch_bounds__(GR_NT, 2) void lm_rounds_reg_kernel(GramCholArgs a,
   }
 }
 
-hipError_t launch_lm_rounds_reg(const GramCholArgs& c, const LmState& lm, hipStream_t s) {
+hipError_t launch_lm_rounds_reg(const GramCholArgs& c, const LmState& lm, const double* Delta,
+                                const double* alpha_in, hipStream_t s) {
   const size_t per = sizeof(double) * (8 * (size_t)c.NPAD + 256 + 5 * 256 + 16 + 64);
   static std::atomic<size_t> granted[64];
   hipError_t ge = gram_grant_lds(lm_rounds_reg_kernel, per * GR_NW, granted);
   if (ge != hipSuccess) return ge;
-  hipLaunchKernelGGL(lm_rounds_reg_kernel, dim3((lm.B + GR_NW - 1) / GR_NW), dim3(GR_NT), per * GR_NW, s, c, lm);
+  hipLaunchKernelGGL(lm_rounds_reg_kernel, dim3((lm.B + GR_NW - 1) / GR_NW), dim3(GR_NT), per * GR_NW, s, c, lm,
+                     Delta, alpha_in);
   return hipGetLastError();
 }
 

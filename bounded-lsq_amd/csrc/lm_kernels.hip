@@ -154,6 +154,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_start_kernel(LmState lm, const doub
   extern __shared__ double sh[];
   __shared__ double red[32];
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (lm.fused_gram && lm.path && lm.path[b] == 0) return;   // (lm_rounds_reg_kernel owns this problem)
   if (!lm.fast[b]) {
     if (tid == 0) lm.ncols_lm[b] = 0;
     return;

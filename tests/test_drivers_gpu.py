@@ -262,7 +262,9 @@ def test_device_outer_driver_matches_sequential(method, scaling, bounded):
         assert (r.nfev, r.njev, r.status) == (ref.nfev, ref.njev, ref.status), b
         np.testing.assert_allclose(r.x, ref.x, rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(r.obj_value, ref.obj_value, rtol=1e-9)
-        np.testing.assert_allclose(r.optimality, ref.optimality, rtol=1e-6, atol=1e-14)
+        # (the optimality at a converged point is a cancellation residue: |g| ~ 1e-9 with rounding
+        # noise ~ 1e-14 from eps * |J| |f|; the two drivers round a few operations differently)
+        np.testing.assert_allclose(r.optimality, ref.optimality, rtol=1e-6, atol=1e-12)
         np.testing.assert_array_equal(r.active_mask, ref.active_mask)
         assert r.success == ref.success and r.message == ref.message
 

@@ -404,6 +404,48 @@ def test_every_kernel_dispatch_boundary(bl, n):
         assert stats == (2, 0)
 
 
+@pytest.mark.parametrize("n", [6, 16, 48, 64, 79])
+def test_newton_rounds_in_one_launch(bl, monkeypatch, n):
+    """N <= 80: the Gauss-Newton step, the bracket and every Newton round of a normal-equations-path
+    problem run inside ONE launch (lm_rounds_reg_kernel).  Against the round-by-round kernels
+    (BLSQ_LM_FUSED = 0): the same iteration counts, alpha and step to rounding — and bit for bit the
+    same result for a problem whether or not its batch also holds Householder-path problems (which
+    keep the round-by-round loop)."""
+    from bounded_lsq import _synth, _abi
+    B, m = 6, 40 * n + 30
+    P = _synth.trf_batch(300 + n, B, m, n)
+    Delta = np.array([0.5, 0.05, 5.0, 0.2, 0.01, 1.0])
+
+    def run(PP, DD, fused):
+        monkeypatch.setenv("BLSQ_LM_FUSED", fused)
+        ctx = _abi.Context(0)
+        sol = bl.TrfStepSolver(len(DD), m, n, ctx=ctx)
+        ctx.gram_stats(reset=True)
+        sol.factor(PP["J"], PP["f"], PP["x"], PP["lb"], PP["ub"], PP["scale"])
+        stats = ctx.gram_stats()
+        S = sol.step(DD, np.zeros(len(DD)))
+        out = (S.step.copy(), np.asarray(S.alpha).copy(), np.asarray(S.n_iter).copy(), S.hits.copy())
+        sol.close(); ctx.close()
+        return out, stats
+
+    (st1, a1, it1, h1), stats = run(P, Delta, "1")
+    assert stats == (B, 0)
+    (st0, a0, it0, h0), _ = run(P, Delta, "0")
+    assert np.array_equal(it1, it0) and it1.max() >= 1
+    np.testing.assert_allclose(a1, a0, rtol=1e-10, atol=0)
+    for b in range(B):
+        assert rel(st1[b], st0[b]) < 1e-11
+    np.testing.assert_array_equal(h1, h0)
+    # the same problems beside two that fail the gate (no bounds, equicorrelated columns)
+    Q = {k: np.concatenate([v, v[:2]]) for k, v in P.items()}
+    Q["J"][B:] = _equicorrelated(2, m, n, 1 - 1e-9, 7)
+    Q["lb"][B:] = -np.inf; Q["ub"][B:] = np.inf
+    (stm, am, itm, hm), statsm = run(Q, np.concatenate([Delta, Delta[:2]]), "1")
+    if n >= 2:
+        assert statsm == (B, 2)
+    assert np.array_equal(stm[:B], st1) and np.array_equal(am[:B], a1) and np.array_equal(itm[:B], it1)
+
+
 def test_chunk_pairs_summed_in_the_kernel_match_the_reduction_pass(bl, monkeypatch):
     """Two row chunks (2048 < m <= 4096), 16 column tiles and at least 256 problems: one workgroup
     takes both chunks and adds them in the kernel, (0 + P0) + P1 — what the separate reduction pass
