@@ -29,6 +29,8 @@ namespace blsq {
 static constexpr int GR_NT = 512;
 static constexpr int GR_NW = GR_NT / WAVE;
 static constexpr int GR_RC = 32;          // rows per staged chunk (8 MFMA k-steps)
+static constexpr int REG_NW = 4;          // one-wave-per-problem kernels (N <= 80): problems (waves) per workgroup —
+static constexpr int REG_NT = REG_NW * WAVE;   // 1024 problems spread over 256 workgroups instead of 128
 static constexpr double GRAM_SMIN = GRAM_SMIN_PROVEN;   // early reject: a pivot of R' below what the certificate could accept
 
 template <class K>
@@ -1118,11 +1120,11 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
 // the operand fragment of k-step s).  No L2 round trip inside the factorisation (the left-looking
 // kernel above pays one per tile and finished row block: 20 exposed latencies at N = 65), no barrier.
 // Same arguments, outputs and gate bookkeeping as gram_chol_kernel<1>; eight problems per workgroup.
-__global__ __launch_bounds__(GR_NT, 2) void gram_chol_reg_kernel(GramCholArgs a) {
+__global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a) {
   constexpr int MT = 5;                                 // tile rows at most (N <= 80)
   extern __shared__ double sh_all[];
   const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int pidx = (int)blockIdx.x * GR_NW + wv;
+  const int pidx = (int)blockIdx.x * REG_NW + wv;
   if (pidx >= a.count) return;                          // (wave-uniform)
   if (a.count_dev && pidx >= *a.count_dev) return;
   const int b = a.batch_list ? a.batch_list[pidx] : pidx;
@@ -1424,14 +1426,14 @@ __device__ __forceinline__ double lm_restart_reg(double lo, double hi) {     // 
 // normal-equations-path problem of the batch (the others are left to lm_start and the round loop,
 // LmState.fused_gram): no list, no counter, and the same arithmetic for a problem whatever else its
 // batch holds.
-__global__ __launch_bounds__(GR_NT, 2) void lm_rounds_reg_kernel(GramCholArgs a, LmState lm,
+__global__ __launch_bounds__(REG_NT, 1) void lm_rounds_reg_kernel(GramCholArgs a, LmState lm,
                                                                  const double* Delta_in,
                                                                  const double* alpha_in) {
   constexpr int MT = 5;
   constexpr bool start = true;
   extern __shared__ double sh_all[];
   const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int b = (int)blockIdx.x * GR_NW + wv;
+  const int b = (int)blockIdx.x * REG_NW + wv;
   if (b >= lm.B) return;
   if (lm.path && lm.path[b] != 0) return;               // (Householder-path problem: lm_start and the round loop)
   const int lane = threadIdx.x & 63, lr = lane >> 4, lc = lane & 15;
@@ -1743,9 +1745,9 @@ hipError_t launch_lm_rounds_reg(const GramCholArgs& c, const LmState& lm, const 
                                 const double* alpha_in, hipStream_t s) {
   const size_t per = sizeof(double) * (8 * (size_t)c.NPAD + 256 + 5 * 256 + 16 + 64);
   static std::atomic<size_t> granted[64];
-  hipError_t ge = gram_grant_lds(lm_rounds_reg_kernel, per * GR_NW, granted);
+  hipError_t ge = gram_grant_lds(lm_rounds_reg_kernel, per * REG_NW, granted);
   if (ge != hipSuccess) return ge;
-  hipLaunchKernelGGL(lm_rounds_reg_kernel, dim3((lm.B + GR_NW - 1) / GR_NW), dim3(GR_NT), per * GR_NW, s, c, lm,
+  hipLaunchKernelGGL(lm_rounds_reg_kernel, dim3((lm.B + REG_NW - 1) / REG_NW), dim3(REG_NT), per * REG_NW, s, c, lm,
                      Delta, alpha_in);
   return hipGetLastError();
 }
@@ -2388,9 +2390,9 @@ hipError_t launch_gram_chol(const GramCholArgs& a_in, int B, hipStream_t s) {
     else {
       const size_t per_reg = sizeof(double) * (4 * (size_t)a.NPAD + 256 + 5 * 256 + 64);
       static std::atomic<size_t> granted[64];
-      hipError_t ge = gram_grant_lds(gram_chol_reg_kernel, per_reg * GR_NW, granted);
+      hipError_t ge = gram_grant_lds(gram_chol_reg_kernel, per_reg * REG_NW, granted);
       if (ge != hipSuccess) return ge;
-      hipLaunchKernelGGL(gram_chol_reg_kernel, dim3((B + GR_NW - 1) / GR_NW), dim3(GR_NT), per_reg * GR_NW,
+      hipLaunchKernelGGL(gram_chol_reg_kernel, dim3((B + REG_NW - 1) / REG_NW), dim3(REG_NT), per_reg * REG_NW,
                          s, a);
     }
   } else {
