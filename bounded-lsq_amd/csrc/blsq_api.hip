@@ -181,7 +181,7 @@ struct QrTree {
   int B = 0, m = 0, n = 0, N = 0, NPAD = 0, NP = 0;
   std::vector<Level> levels;        // levels.back().nleaf == 1
   DevBuf V, T;                      // scratch shared by all QR launches of the plan
-  // normal-equations fast path (gram_kernels.hip); problems that fail its gate use the levels
+  // normal-equations fast path (gram_kernels.hip, chol_kernels.hip); problems that fail its gate use the levels
   bool gram = false;
   int gram_nchunk = 1;
   DevBuf gram_part, gram_dsc, gram_ints;   // partial Grams, column scales, [B] fallback mask + count
@@ -911,7 +911,7 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
   p->lm.fused_gram = 0;
   if (p->use_chol && p->lm_enable && p->ld <= 80) {
     // N <= 80: the Gauss-Newton step, the bracket and ALL rounds of every normal-equations-path problem
-    // in ONE launch (one wave per problem iterates to the end; gram_kernels.hip).  Householder-path
+    // in ONE launch (one wave per problem iterates to the end; chol_kernels.hip).  Householder-path
     // problems of the same batch go through lm_start and the round loop below.
     // BLSQ_LM_FUSED = 0: lm_start + the round-by-round loop for everybody.
     const char* fe = getenv("BLSQ_LM_FUSED");

@@ -51,7 +51,7 @@ void set_qr_debug_buffer(double* p);
 hipError_t qr_cqr_stats(unsigned long long out[2], int reset, hipStream_t st);
 
 // ------------------------------------------------- normal-equations fast path ----
-// gram_kernels.hip: G = [J f]^T [J f] by MFMA, equilibrated blocked Cholesky in place in the
+// gram_kernels.hip / chol_kernels.hip: G = [J f]^T [J f] by MFMA, equilibrated blocked Cholesky in place in the
 // triangle slot, conditioning gate; problems that fail it get fb_mask[b] = n + 1 and are
 // factored by the Householder tree instead.
 struct GramArgs {
@@ -99,7 +99,7 @@ struct GramCholArgs {
                           // register-resident kernel has R' at hand); launch_gram_gate then skips the problem
 };
 // A problem stays on the normal-equations path only if the PROVEN bound K2 >= kappa_2(R'^T R') of its
-// equilibrated system is at most GRAM_K2_MAX (gram_kernels.hip, gram_cond_kernel).  Consequence used
+// equilibrated system is at most GRAM_K2_MAX (chol_kernels.hip, gram_cond_kernel).  Consequence used
 // by the rank gates: lambda_max >= 1 (unit diagonal), so sigma_min(R') >= 1 / sqrt(GRAM_K2_MAX).
 constexpr double GRAM_K2_MAX = 2.5e5;
 constexpr double GRAM_SMIN_PROVEN = 2.0e-3;         // = 1 / sqrt(GRAM_K2_MAX)
@@ -203,7 +203,7 @@ struct LmState {
                           // and the round kernels leave them alone (a problem's arithmetic must not depend
                           // on whether its batch also holds Householder-path problems)
 };
-// slots of LmState.sc / LmState.st, phases of the iteration (lm_kernels.hip; the fused rounds in gram_kernels.hip)
+// slots of LmState.sc / LmState.st, phases of the iteration (lm_kernels.hip; the fused rounds in chol_kernels.hip)
 enum { LM_IDLE = 0, LM_EVAL = 1, LM_FINAL = 2 };
 enum { SC_ALPHA = 0, SC_LO, SC_HI, SC_PHI, SC_DPHI, SC_DELTA, SC_SMAX, SC_SMIN };
 enum { ST_IT = 0, ST_PHASE, ST_NITER };

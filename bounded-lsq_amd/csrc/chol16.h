@@ -1,6 +1,6 @@
 // Cholesky factor AND inverse of one 16 x 16 diagonal tile, by one wave (all 64 lanes active).
 //
-// This is the sequential core of every blocked Cholesky in gram_kernels.hip: row block kb of the
+// This is the sequential core of every blocked Cholesky in chol_kernels.hip: row block kb of the
 // factor cannot start before the chain of its diagonal tile has finished, so the time of one chain
 // times the number of row blocks is a floor under the whole factorisation.
 //

@@ -1,0 +1,1379 @@
+// Factorisation side of the normal-equations path (gram_kernels.hip computes the Grams):
+//
+//   gram_chol_kernel<NWP>, gram_chol_rl_kernel, gram_chol_reg_kernel
+//                           equilibrated blocked Cholesky of D G D + E^2 (+ alpha I) or of a gathered
+//                           principal sub-matrix, straight from the kept Gram (chol16.h: the 16 x 16 chain)
+//   lm_rounds_reg_kernel    N <= 80: the whole trust-region sub-problem after the factor in one launch
+//   gram_cond_kernel<NWP>   the conditioning certificate (a PROVEN bound on kappa_2)
+#include "gram_common.h"
+#include "tri_ops.h"
+#include "chol16.h"
+
+namespace blsq {
+
+// ---- equilibrated blocked Cholesky, in place in the triangle slot -------------------------------
+// Row block kb of R' :  S_j = C_{kb,j} - sum_{k<kb} R'_{k,kb}^T R'_{k,j}   (MFMA, operands from the
+// rows already written),  R'_{kb,kb} = chol(S_kb) and its inverse on wave 0 (lane j owns column
+// j, broadcasts by v_readlane),  R'_{kb,j} = R'_{kb,kb}^-T S_j  (MFMA; the accumulator layout of S is
+// the B-operand layout).  What is stored is R = R' D^-1; operands are re-scaled on the fly.
+//
+// The same kernel factors the diagonally modified Grams of the trust-region systems (TRF):
+//     H = D G D + diag(e^2) (+ alpha I on the first n columns),    D = diag(colscale, 1)
+// whose Cholesky factor is the triangle of [R D | c; E | 0] (and of [R_aug; sqrt(alpha) I]).  With
+// C = equil(G):  equil(H) = Theta^1/2 C Theta^1/2 + (I - Theta),  0 < Theta <= I diagonal, so its
+// extreme eigenvalues lie inside those of C: a problem that passed the gate on C needs no new one.
+// NWP waves work on one problem: 8 (a whole workgroup; any size) or 1 (N <= 80: eight problems per
+// workgroup, no workgroup barrier at all — the 16x16 chain of one problem overlaps the MFMAs of
+// the others on the same SIMD, and sixteen instead of two problems are resident per CU).
+template <int NWP>
+__global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
+  constexpr int PT = WAVE * NWP;                        // threads per problem
+  constexpr int UMAX = (NWP == 8) ? 3 : 5;              // tiles of a row block per wave
+  constexpr int PPW = GR_NW / NWP;                      // problems per workgroup
+  extern __shared__ double sh_all[];
+  __shared__ double red[32];
+  __shared__ double pmin_all[GR_NW];
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int pslot = wv / NWP;                           // problem slot inside the workgroup
+  const int pidx = (int)blockIdx.x * PPW + pslot;
+  if (pidx >= a.count) return;                          // (NWP == 1 only: wave-uniform)
+  if (a.count_dev && pidx >= *a.count_dev) return;
+  const int b = a.batch_list ? a.batch_list[pidx] : pidx;
+  const int tid = (int)threadIdx.x % PT, lane = tid & 63;
+  const int w = wv % NWP;
+  double* sh = sh_all + (size_t)pslot * (4 * (size_t)a.NPAD + 512);
+  double& pminsh = pmin_all[pslot];
+  // synchronisation among the threads of one problem
+  auto psync = [&]() {
+    if (NWP == 8) __syncthreads();
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // one wave: program order
+  };
+  const int lr = lane >> 4, lc = lane & 15;
+  const int NPAD = a.NPAD;
+  if (a.mask && a.mask[b] <= 1) {
+    if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
+    return;
+  }
+  if (a.skip_path && a.skip_path[b] != 0) return;
+  // columns of this problem: all n (+ rhs), or the gathered free columns (+ rhs)
+  const int N = a.ncols_dev ? a.ncols_dev[b] : a.n + 1;
+  if (N <= 1) {                                         // (dogbox: every variable active — nothing to factor)
+    if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
+    return;
+  }
+  const int n = N - 1;
+  const int NT = (N + 15) / 16;
+  const int* gidx = a.gather ? a.gather + (long)b * a.stride_vec : nullptr;
+  // source row / column of H's index i  (the rhs is the source's column a.n)
+  auto src = [&](int i) -> int { return gidx ? (i < n ? gidx[i] : a.n) : i; };
+  const double* Gs = a.Gsrc + (long)b * NPAD * NPAD;    // source Gram (may alias the output)
+  double* Gb = a.G + (long)b * NPAD * NPAD;             // output triangle
+  double* dl = sh;                 // [NPAD] equilibration 1 / sqrt(h_jj)
+  double* sq = dl + NPAD;          // [NPAD] sqrt(h_jj)
+  double* sc = sq + NPAD;          // [NPAD] colscale_j * dl_j  (scale applied to source entries)
+  double* Dt = sc + NPAD;          // [256]  diagonal tile (row-major)
+  double* Ri = Dt + 256;           // [256]  its inverse
+  double* td = Ri + 256;           // [NPAD] (e_j^2 + alpha) * dl_j^2  (added to the diagonal of C)
+  const double* csv = a.colscale ? a.colscale + (long)b * a.stride_vec : nullptr;
+  const double* edv = a.diag_vec ? a.diag_vec + (long)b * a.stride_vec : nullptr;
+  const double sa = a.diag_sqrt ? a.diag_sqrt[b] : 0.0;
+  // 0. column scales from the diagonal of H
+  int bad = 0;
+  for (int j = tid; j < NPAD; j += PT) {
+    const double cs = (csv && j < n) ? csv[j] : 1.0;
+    const double ej = (edv && j < n) ? edv[j] : 0.0;
+    const double add = (j < n) ? fma(ej, ej, sa * sa) : 0.0;
+    const int sj_ = (j < N) ? src(j) : j;
+    const double g = (j < N) ? fma(Gs[(long)sj_ * NPAD + sj_] * cs, cs, add) : 0.0;
+    const bool okc = (g > 0.0) && is_finite(g);
+    if (j < n && !okc) bad = 1;
+    double d = 1.0, s = 1.0;
+    if (j < N && okc) {
+      d = __builtin_amdgcn_rsq(g);
+      d = d * fma(-0.5 * g * d, d, 1.5);
+      d = d * fma(-0.5 * g * d, d, 1.5);
+      s = g * d;
+    }
+    dl[j] = d; sq[j] = s; sc[j] = cs * d; td[j] = add * d * d;
+    if (a.dsc) a.dsc[(long)b * NPAD + j] = d;
+  }
+  if (a.colinfo) {                                      // (uniform) column-norm summary for the rank gate
+    psync();
+    if (tid == 0) {
+      double mn = __builtin_inf(), sm = 0.0;
+      for (int j = 0; j < n; ++j) { const double v = sq[j]; mn = v < mn ? v : mn; sm = fma(v, v, sm); }
+      a.colinfo[2 * (long)b] = mn; a.colinfo[2 * (long)b + 1] = sm;
+    }
+  }
+  // strictly lower tiles are part of the triangle's image: zero
+  for (int r = 16 + w; r < NPAD; r += NWP) {
+    const int cend = r & ~15;
+    for (int c = lane; c < cend; c += WAVE) Gb[(long)r * NPAD + c] = 0.0;
+  }
+  if (NWP == 8) bad = block_or(bad, red); else bad = __any(bad);
+  if (tid == 0) pminsh = 1.0;
+  psync();
+  if (bad) {                                            // uniform: hand the problem to the QR tree
+    if (tid == 0 && a.fb_mask) {
+      a.fb_mask[b] = a.n + 1; { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }   // (the tree factors ALL n + 1 columns)
+      if (a.path_out) a.path_out[b] = a.n + 1;
+    }
+    return;
+  }
+
+  for (int kb = 0; kb < NT; ++kb) {
+    // ---- A. Schur complements of this row block (tile j = kb + w + 8 u) ----
+    v4d S[UMAX];
+    const double dk = dl[16 * kb + lc];
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) {
+      const int j = kb + w + NWP * u;
+      S[u] = v4d{0.0, 0.0, 0.0, 0.0};
+      if (j < NT) {
+        const double dj = dl[16 * j + lc];
+        const double scj = sc[16 * j + lc];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * kb + lr + 4 * g;
+          const int col = 16 * j + lc;
+          double v = 0.0;
+          if (row < N && col < N) {
+            int sr_ = src(row), sc_ = src(col);
+            if (sr_ > sc_) { const int t_ = sr_; sr_ = sc_; sc_ = t_; }   // symmetric: stay in the upper tiles
+            v = Gs[(long)sr_ * NPAD + sc_] * sc[row] * scj;
+          }
+          if (j == kb && lr + 4 * g == lc) v += td[row];
+          S[u][g] = v;
+        }
+        for (int k = 0; k < kb; ++k) {
+          double av[4], bv[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const long ro = (long)(16 * k + 4 * s + lr) * NPAD;
+            av[s] = Gb[ro + 16 * kb + lc];
+            bv[s] = Gb[ro + 16 * j + lc];
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) S[u] = gmfma(-(av[s] * dk), bv[s] * dj, S[u]);
+        }
+      }
+    }
+    // ---- B. wave 0: Cholesky of the diagonal tile and its inverse (chol16.h), straight from the
+    // accumulators of its Schur complement ----
+    if (w == 0) {
+      const double pm = chol16_blocked3(S[0], Dt, Ri, n - 16 * kb, pminsh);
+      if (lane == 0) pminsh = pm;
+    }
+    psync();
+    if (a.rinv && w == NWP - 1) {                       // kept for the conditioning certificate (off the chain)
+      double* ro = a.rinv + ((long)b * (NPAD / 16) + kb) * 256;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ro[q * 64 + lane] = Ri[q * 64 + lane];
+    }
+    // ---- C. R'_{kb,j} = R'_{kb,kb}^-T S_j, stored as R = R' D^-1 ----
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) {
+      const int j = kb + w + NWP * u;
+      if (j < NT) {
+        v4d X = {0.0, 0.0, 0.0, 0.0};
+        if (j == kb) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) X[g] = Dt[(lr + 4 * g) * 16 + lc];
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) X = gmfma(Ri[(4 * s + lr) * 16 + lc], S[u][s], X);
+        }
+        const double sj = sq[16 * j + lc];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * kb + lr + 4 * g;
+          const int colg = 16 * j + lc;
+          double val = X[g] * sj;
+          if (row >= n || row > colg || colg > n) val = 0.0;
+          Gb[(long)row * NPAD + colg] = val;
+        }
+      }
+    }
+    psync();
+  }
+  if (16 * NT < NPAD) {                                  // sub-matrix: the rest of the slot is zero
+    for (int r = w; r < NPAD; r += NWP) {
+      const int c0 = (r < 16 * NT) ? 16 * NT : (r & ~15);
+      for (int c = c0 + lane; c < NPAD; c += WAVE) Gb[(long)r * NPAD + c] = 0.0;
+    }
+  }
+  if (tid == 0 && a.fb_mask) {
+    const bool fail = !(pminsh >= GRAM_SMIN * GRAM_SMIN);
+    a.fb_mask[b] = fail ? a.n + 1 : 0;
+    if (a.path_out) a.path_out[b] = fail ? a.n + 1 : 0;
+    if (fail) { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
+  }
+}
+
+// ---- N <= 80, one wave per problem, the whole matrix in registers -------------------------------
+// At most 5 x 5 tiles: the 15 upper tiles of the equilibrated matrix are loaded ONCE into
+// accumulators and never leave the wave until their row block is final.  Per row block: the chain of
+// the diagonal tile straight from its accumulator (chol16.h), R'_{kb,j} = R'_kk^-T S_j by MFMA, and
+// the right-looking update of the remaining tiles — whose MFMA operands are the rows just solved,
+// already in the right layout (register s of a tile in the accumulator layout holds rows 4 s + lr:
+// the operand fragment of k-step s).  No L2 round trip inside the factorisation (the left-looking
+// kernel above pays one per tile and finished row block: 20 exposed latencies at N = 65), no barrier.
+// Same arguments, outputs and gate bookkeeping as gram_chol_kernel<1>; eight problems per workgroup.
+__global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a) {
+  constexpr int MT = 5;                                 // tile rows at most (N <= 80)
+  extern __shared__ double sh_all[];
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int pidx = (int)blockIdx.x * REG_NW + wv;
+  if (pidx >= a.count) return;                          // (wave-uniform)
+  if (a.count_dev && pidx >= *a.count_dev) return;
+  const int b = a.batch_list ? a.batch_list[pidx] : pidx;
+  const int lane = threadIdx.x & 63, tid = lane;
+  const int lr = lane >> 4, lc = lane & 15;
+  const int NPAD = a.NPAD;
+  double* sh = sh_all + (size_t)wv * (4 * (size_t)NPAD + 256 + MT * 256 + 64);
+  auto wsync = []() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); };
+  if (a.mask && a.mask[b] <= 1) {
+    if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
+    return;
+  }
+  if (a.skip_path && a.skip_path[b] != 0) return;
+  const int N = a.ncols_dev ? a.ncols_dev[b] : a.n + 1;
+  if (N <= 1) {                                         // (dogbox: every variable active — nothing to factor)
+    if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
+    return;
+  }
+  const int n = N - 1;
+  const int NT = (N + 15) / 16;
+  const int* gidx = a.gather ? a.gather + (long)b * a.stride_vec : nullptr;
+  auto src = [&](int i) -> int { return gidx ? (i < n ? gidx[i] : a.n) : i; };
+  const double* Gs = a.Gsrc + (long)b * NPAD * NPAD;    // source Gram (may alias the output)
+  double* Gb = a.G + (long)b * NPAD * NPAD;             // output triangle
+  double* dl = sh;                 // [NPAD] equilibration 1 / sqrt(h_jj)
+  double* sq = dl + NPAD;          // [NPAD] sqrt(h_jj)
+  double* sc = sq + NPAD;          // [NPAD] colscale_j * dl_j
+  double* Dt = sc + NPAD;          // [256]  diagonal tile (row-major)
+  double* Ria = Dt + 256;          // [MT][256] the inverses of the diagonal tiles (kept: certificate below)
+  double* td = Ria + MT * 256;     // [NPAD] (e_j^2 + alpha) * dl_j^2
+  double* xs = td + NPAD;          // [64]   four-row sums
+  const double* csv = a.colscale ? a.colscale + (long)b * a.stride_vec : nullptr;
+  const double* edv = a.diag_vec ? a.diag_vec + (long)b * a.stride_vec : nullptr;
+  const double sa = a.diag_sqrt ? a.diag_sqrt[b] : 0.0;
+  int* sidx = (int*)Ria;           // [NPAD] source indices — only until the tiles are loaded (Ria is free till then)
+  // 0. column scales from the diagonal of H
+  int bad = 0;
+  for (int j = tid; j < NPAD; j += WAVE) {
+    const double cs = (csv && j < n) ? csv[j] : 1.0;
+    const double ej = (edv && j < n) ? edv[j] : 0.0;
+    const double add = (j < n) ? fma(ej, ej, sa * sa) : 0.0;
+    const int sj_ = (j < N) ? src(j) : j;
+    const double g = (j < N) ? fma(Gs[(long)sj_ * NPAD + sj_] * cs, cs, add) : 0.0;
+    const bool okc = (g > 0.0) && is_finite(g);
+    if (j < n && !okc) bad = 1;
+    double d = 1.0, s_ = 1.0;
+    if (j < N && okc) {
+      d = __builtin_amdgcn_rsq(g);
+      d = d * fma(-0.5 * g * d, d, 1.5);
+      d = d * fma(-0.5 * g * d, d, 1.5);
+      s_ = g * d;
+    }
+    dl[j] = d; sq[j] = s_; sc[j] = cs * d; td[j] = add * d * d;
+    sidx[j] = sj_ < NPAD ? sj_ : 0;                     // source row / column of index j (always a valid one)
+    if (a.dsc) a.dsc[(long)b * NPAD + j] = d;
+  }
+  wsync();
+  if (a.colinfo && tid == 0) {                          // column-norm summary for the rank gate
+    double mn = __builtin_inf(), sm = 0.0;
+    for (int j = 0; j < n; ++j) { const double v = sq[j]; mn = v < mn ? v : mn; sm = fma(v, v, sm); }
+    a.colinfo[2 * (long)b] = mn; a.colinfo[2 * (long)b + 1] = sm;
+  }
+  bad = __any(bad);
+  // 1. the scaled source tiles -> accumulators (the source may alias the output: every read comes
+  //    before any write)
+  v4d acc[MT * (MT + 1) / 2];
+  auto tix = [](int i, int j) { return i * MT - i * (i - 1) / 2 + (j - i); };   // upper tile (i, j) of a 5 x 5 grid
+  if (!bad) {
+    // (unconditional loads from clamped indices, all in flight together; selected afterwards)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      int srow[4];
+      double scr_[4];
+      if (i < NT) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * i + lr + 4 * g;
+          srow[g] = sidx[row < N ? row : N - 1];
+          scr_[g] = sc[row];
+        }
+      }
+#pragma unroll
+      for (int j = i; j < MT; ++j) {
+        v4d v4 = {0.0, 0.0, 0.0, 0.0};
+        if (j < NT) {
+          const int col = 16 * j + lc;
+          const int scol = sidx[col < N ? col : N - 1];
+          const double scj = sc[col];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row = 16 * i + lr + 4 * g;
+            const int lo_ = srow[g] < scol ? srow[g] : scol, hi_ = srow[g] < scol ? scol : srow[g];   // symmetric: upper tiles
+            double v = Gs[(long)lo_ * NPAD + hi_];
+            v = (row < N && col < N) ? v * scr_[g] * scj : 0.0;
+            if (j == i && lr + 4 * g == lc) v += td[row];
+            v4[g] = v;
+          }
+        }
+        acc[tix(i, j)] = v4;
+      }
+    }
+  }
+  wsync();
+  if (bad) {                                            // hand the problem to the QR tree
+    if (tid == 0 && a.fb_mask) {
+      a.fb_mask[b] = a.n + 1; { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }   // (the tree factors ALL n + 1 columns)
+      if (a.path_out) a.path_out[b] = a.n + 1;
+    }
+    return;
+  }
+  // strictly lower tiles and everything beyond 16 NT are part of the triangle's image: zero
+  for (int r = 0; r < NPAD; ++r) {
+    const int cend = (r < 16 * NT) ? (r & ~15) : NPAD;
+    for (int c = lane; c < cend; c += WAVE) Gb[(long)r * NPAD + c] = 0.0;
+    if (r < 16 * NT)
+      for (int c = 16 * NT + lane; c < NPAD; c += WAVE) Gb[(long)r * NPAD + c] = 0.0;
+  }
+  double pmin = 1.0;
+#pragma unroll
+  for (int kb = 0; kb < MT; ++kb) {
+    if (kb < NT) {
+      // 2. chain of the diagonal tile: R'_kk -> Dt, its inverse -> Ri
+      double* Ri = Ria + kb * 256;
+      pmin = chol16_blocked3(acc[tix(kb, kb)], Dt, Ri, n - 16 * kb, pmin);
+      if (a.rinv) {                                     // kept for the conditioning certificate
+        double* ro = a.rinv + ((long)b * (NPAD / 16) + kb) * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ro[q * 64 + lane] = Ri[q * 64 + lane];
+      }
+      // 3. the row block: R'_{kb,j} = R'_kk^-T S_j (kept in the accumulators of row kb), stored as R = R' D^-1
+#pragma unroll
+      for (int j = kb; j < MT; ++j) {
+        if (j < NT) {
+          v4d X = {0.0, 0.0, 0.0, 0.0};
+          if (j == kb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) X[g] = Dt[(lr + 4 * g) * 16 + lc];
+            acc[tix(kb, kb)] = X;                       // (all 15 tiles of R' stay in registers: certificate)
+          } else {
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) X = gmfma(Ri[(4 * s_ + lr) * 16 + lc], acc[tix(kb, j)][s_], X);
+            acc[tix(kb, j)] = X;
+          }
+          const double sj = sq[16 * j + lc];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row = 16 * kb + lr + 4 * g;
+            const int colg = 16 * j + lc;
+            double val = X[g] * sj;
+            if (row >= n || row > colg || colg > n) val = 0.0;
+            Gb[(long)row * NPAD + colg] = val;
+          }
+        }
+      }
+      // 4. right-looking update of the tiles below: (i, j) -= R'_{kb,i}^T R'_{kb,j}
+#pragma unroll
+      for (int i = kb + 1; i < MT; ++i) {
+#pragma unroll
+        for (int j = i; j < MT; ++j) {
+          if (j < NT) {
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+              acc[tix(i, j)] = gmfma(-acc[tix(kb, i)][s_], acc[tix(kb, j)][s_], acc[tix(i, j)]);
+          }
+        }
+      }
+      wsync();                                          // (Dt / Ri are rewritten by the next chain)
+    }
+  }
+  const bool fail = !(pmin >= GRAM_SMIN * GRAM_SMIN);
+  if (tid == 0 && a.fb_mask) {
+    a.fb_mask[b] = fail ? a.n + 1 : 0;
+    if (a.path_out) a.path_out[b] = fail ? a.n + 1 : 0;
+    if (fail) { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
+  }
+  // 5. The first bound of the conditioning certificate (gram_cond_kernel below: same quantities, same
+  //    definition) while R' and the inverse diagonal tiles are still at hand:
+  //        K2 = ||R'||_1 ||R'||_inf ||Y||_1 ||Y||_inf ,   Y = R'^-T  column block by column block.
+  //    K2 <= GRAM_K2_MAX settles the problem here; otherwise the separate kernel decides (it also
+  //    has the tighter Frobenius bound).
+  if (a.cert_done) {
+    bool passed = false;
+    double k2 = 0.0;
+    if (!fail) {
+      const int NTn = (n + 15) / 16;
+      double r1 = 0.0, rinf = 0.0, y1 = 0.0, yinf = 0.0;
+      double colp[MT];
+#pragma unroll
+      for (int jj = 0; jj < MT; ++jj) colp[jj] = 0.0;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if (i < NTn) {
+          double rp[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int jj = i; jj < MT; ++jj) {
+            if (jj < NTn) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int row = 16 * i + lr + 4 * g, col = 16 * jj + lc;
+                const double v = (row < n && col < n) ? fabs(acc[tix(i, jj)][g]) : 0.0;
+                rp[g] += v; colp[jj] += v;
+              }
+            }
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) rinf = fmax(rinf, row16_sum(rp[g]));
+        }
+      }
+      rinf = wave_max(rinf);
+#pragma unroll
+      for (int jj = 0; jj < MT; ++jj) {
+        if (jj < NTn) {
+          xs[lane] = colp[jj];
+          wsync();
+          r1 = fmax(r1, (xs[lc] + xs[16 + lc]) + (xs[32 + lc] + xs[48 + lc]));
+          wsync();
+        }
+      }
+      r1 = wave_max(r1);
+      double rsY[MT][4];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rsY[i][g] = 0.0;
+#pragma unroll
+      for (int jj = 0; jj < MT; ++jj) {
+        if (jj < NTn) {
+          v4d Yc[MT];
+          double cY = 0.0;
+#pragma unroll
+          for (int i = jj; i < MT; ++i) {
+            if (i < NTn) {
+              v4d Yt = {0.0, 0.0, 0.0, 0.0};
+              if (i == jj) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) Yt[g] = Ria[jj * 256 + lc * 16 + lr + 4 * g];   // (R'_jj^-1)^T
+              } else {
+                v4d av = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = jj; kk < i; ++kk) {
+#pragma unroll
+                  for (int s_ = 0; s_ < 4; ++s_) av = gmfma(acc[tix(kk, i)][s_], Yc[kk][s_], av);
+                }
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) Yt = gmfma(-Ria[i * 256 + (4 * s_ + lr) * 16 + lc], av[s_], Yt);
+              }
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int row = 16 * i + lr + 4 * g, col = 16 * jj + lc;
+                const double v = (row < n && col < n) ? Yt[g] : 0.0;
+                Yt[g] = v;
+                const double av_ = fabs(v);
+                rsY[i][g] += row16_sum(av_);
+                cY += av_;
+              }
+              Yc[i] = Yt;
+            }
+          }
+          xs[lane] = cY;
+          wsync();
+          y1 = fmax(y1, (xs[lc] + xs[16 + lc]) + (xs[32 + lc] + xs[48 + lc]));
+          wsync();
+        }
+      }
+      y1 = wave_max(y1);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) yinf = fmax(yinf, rsY[i][g]);
+      yinf = wave_max(yinf);
+      k2 = (r1 * rinf) * (y1 * yinf);
+      passed = k2 <= GRAM_K2_MAX;                       // (NaN fails)
+    }
+    if (tid == 0) {
+      a.cert_done[b] = passed ? 1 : 0;
+      if (passed && a.k2_out) a.k2_out[b] = k2;
+    }
+  }
+}
+
+// ---- N <= 80: ALL Newton rounds of a problem in one launch ----------------------------------------
+// The safeguarded Newton iteration on alpha (trust_region.py:126-150) factors H + alpha I once per
+// round.  For N <= 80 one wave owns a problem for the whole iteration: per round the factor of
+// gram_chol_reg_kernel (tiles in registers, nothing stored), p = -R^-1 c by block back substitution
+// and q = R^-T p by block forward substitution straight from the register tiles (tile x vector: four
+// FMAs per lane and tile + a 16-lane DPP sum, or a four-row sum through LDS for the transposed
+// product; the 16 x 16 diagonal solves are matvecs with the inverse tiles the chain produces anyway),
+// then the scalar update of lm_update_kernel, verbatim.  No launch, no counter read-back and no
+// triangle written between rounds (six stream operations per round otherwise, each with its dispatch
+// gap).  Everything happens in the equilibrated system:  R = R' diag(sq),  c = c' sq_n  =>
+//     p_j = -sq_n dl_j (R'^-1 c')_j ,      q = R'^-T (dl . p) .
+__device__ __forceinline__ double lm_restart_reg(double lo, double hi) {     // trust_region.py:128,134
+  const double gm = sqrt(lo * hi);
+  return (0.001 * hi > gm) ? 0.001 * hi : gm;
+}
+// The launch first does what lm_start_kernel does — the Gauss-Newton step from the AUGMENTED factor
+// (its stored triangle, column scales and inverse diagonal tiles are re-loaded: R' = R diag(dl)), the
+// acceptance test |p| <= Delta and the bracket (trust_region.py:116-130) — for every
+// normal-equations-path problem of the batch (the others are left to lm_start and the round loop,
+// LmState.fused_gram): no list, no counter, and the same arithmetic for a problem whatever else its
+// batch holds.
+__global__ __launch_bounds__(REG_NT, 1) void lm_rounds_reg_kernel(GramCholArgs a, LmState lm,
+                                                                 const double* Delta_in,
+                                                                 const double* alpha_in) {
+  constexpr int MT = 5;
+  constexpr bool start = true;
+  extern __shared__ double sh_all[];
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int b = (int)blockIdx.x * REG_NW + wv;
+  if (b >= lm.B) return;
+  if (lm.path && lm.path[b] != 0) return;               // (Householder-path problem: lm_start and the round loop)
+  const int lane = threadIdx.x & 63, lr = lane >> 4, lc = lane & 15;
+  if (!lm.fast[b]) {
+    if (lane == 0) lm.ncols_lm[b] = 0;
+    return;
+  }
+  double* scv = lm.sc + (long)b * 16;
+  int* stv = lm.st + (long)b * 4;
+  int phase = LM_EVAL;
+  const int NPAD = a.NPAD, n = a.n, N = n + 1;
+  const int NT = (N + 15) / 16, NTn = (n + 15) / 16;
+  const int jn = n >> 4, cn = n & 15;                   // tile column / column inside it of the rhs
+  double* sh = sh_all + (size_t)wv * (8 * (size_t)NPAD + 256 + MT * 256 + 16 + 64);
+  double* dl = sh;                 // [NPAD] 1 / sqrt(h_jj)
+  double* sq = dl + NPAD;          // [NPAD] sqrt(h_jj)
+  double* sc = sq + NPAD;          // [NPAD] colscale_j dl_j
+  double* td = sc + NPAD;          // [NPAD] (e_j^2 + alpha) dl_j^2
+  double* cv = td + NPAD;          // [NPAD] c' = R'[:, n]
+  double* yv = cv + NPAD;          // [NPAD] R'^-1 c', then dl . p
+  double* pv = yv + NPAD;          // [NPAD] p
+  double* zv = pv + NPAD;          // [NPAD] R'^-T (dl . p)
+  double* Dt = zv + NPAD;          // [256]
+  double* Ria = Dt + 256;          // [MT][256] inverse diagonal tiles
+  double* tv = Ria + MT * 256;     // [16]
+  double* xs = tv + 16;            // [64]
+  auto wsync = []() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); };
+  const double* Gs = a.Gsrc + (long)b * NPAD * NPAD;
+  const double* csv = a.colscale ? a.colscale + (long)b * a.stride_vec : nullptr;
+  const double* edv = a.diag_vec ? a.diag_vec + (long)b * a.stride_vec : nullptr;
+  auto tix = [](int i, int j) { return i * MT - i * (i - 1) / 2 + (j - i); };
+  v4d acc[MT * (MT + 1) / 2];
+  double sqn = 1.0;
+
+  // y = R'^-1 c' (rows and columns below n only; c' in cv), block rows from the bottom -> yv
+  auto back_solve = [&]() {
+#pragma unroll
+    for (int kk = MT - 1; kk >= 0; --kk) {
+      if (kk < NTn) {
+        double part[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = kk + 1; j < MT; ++j) {
+          if (j < NTn) {
+            const double yj = yv[16 * j + lc];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) part[g] = fma(acc[tix(kk, j)][g], yj, part[g]);
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) part[g] = row16_sum(part[g]);
+        if (lc == 0) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) tv[lr + 4 * g] = cv[16 * kk + lr + 4 * g] - part[g];
+        }
+        wsync();
+        const int nb = (n - 16 * kk < 16) ? n - 16 * kk : 16;
+        const double* Rk = Ria + kk * 256;
+        double yi = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) yi = fma(Rk[lc * 16 + c], (c < nb) ? tv[c] : 0.0, yi);
+        if (lc >= nb) yi = 0.0;
+        if (lr == 0) yv[16 * kk + lc] = yi;
+        wsync();
+      }
+    }
+  };
+  // p = -sq_n dl . y -> pv,  w = dl . p -> yv;  returns |p|
+  auto form_p = [&]() -> double {
+    double pp = 0.0;
+    for (int j = lane; j < NPAD; j += WAVE) {
+      const double pj = (j < n) ? -(sqn * dl[j] * yv[j]) : 0.0;
+      pv[j] = pj;
+      pp = fma(pj, pj, pp);
+    }
+    wsync();
+    for (int j = lane; j < NPAD; j += WAVE) yv[j] = (j < n) ? dl[j] * pv[j] : 0.0;
+    const double pn_ = sqrt(wave_sum(pp));
+    wsync();
+    return pn_;
+  };
+  // z = R'^-T w (w in yv), block rows from the top -> zv;  returns |z|^2
+  auto fwd_solve = [&]() -> double {
+#pragma unroll
+    for (int kk = 0; kk < MT; ++kk) {
+      if (kk < NTn) {
+        double part = 0.0;
+#pragma unroll
+        for (int j = 0; j < kk; ++j) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) part = fma(acc[tix(j, kk)][g], zv[16 * j + lr + 4 * g], part);
+        }
+        xs[lane] = part;
+        wsync();
+        const double tot = (xs[lc] + xs[16 + lc]) + (xs[32 + lc] + xs[48 + lc]);
+        if (lr == 0) tv[lc] = yv[16 * kk + lc] - tot;
+        wsync();
+        const int nb = (n - 16 * kk < 16) ? n - 16 * kk : 16;
+        const double* Rk = Ria + kk * 256;
+        double zi = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) zi = fma(Rk[c * 16 + lc], (c <= lc) ? tv[c] : 0.0, zi);
+        if (lc >= nb) zi = 0.0;
+        if (lr == 0) zv[16 * kk + lc] = zi;
+        wsync();
+      }
+    }
+    double qq = 0.0;
+    for (int j = lane; j < NPAD; j += WAVE) { const double zj = (j < n) ? zv[j] : 0.0; qq = fma(zj, zj, qq); }
+    return wave_sum(qq);
+  };
+
+  double alpha, lo, hi, phi, dphi, Delta;
+  int it, n_iter;
+  if (start) {
+    // ---- the augmented factor back into registers:  R' = R diag(dl),  Ri from the factor kernel ----
+    Delta = Delta_in[b];
+    const double* Ra = lm.Raug + (long)b * NPAD * NPAD;
+    const double* dsc = a.dsc + (long)b * NPAD;
+    const double* rinv = a.rinv + (long)b * (NPAD / 16) * 256;
+    for (int j = lane; j < NPAD; j += WAVE) { dl[j] = dsc[j]; yv[j] = 0.0; pv[j] = 0.0; zv[j] = 0.0; }
+    for (int e = lane; e < NT * 256; e += WAVE) Ria[e] = rinv[e];
+    wsync();
+    sqn = 1.0 / dl[n];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int j = i; j < MT; ++j) {
+        v4d v4 = {0.0, 0.0, 0.0, 0.0};
+        if (j < NT) {
+          const int col = 16 * j + lc;
+          const double dj = dl[col];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) v4[g] = Ra[(long)(16 * i + lr + 4 * g) * NPAD + col] * dj;
+        }
+        acc[tix(i, j)] = v4;
+      }
+    }
+    for (int r = lane; r < NPAD; r += WAVE) cv[r] = (r < n) ? Ra[(long)r * NPAD + n] * dl[n] : 0.0;
+    wsync();
+    // |R^T c| = sq_n |sq . (R'^T c')|  (alpha_upper = |A^T b| / Delta, trust_region.py:111-113)
+    double gg = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < MT; ++kk) {
+      if (kk < NTn) {
+        double part = 0.0;
+#pragma unroll
+        for (int j = 0; j <= kk; ++j) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) part = fma(acc[tix(j, kk)][g], cv[16 * j + lr + 4 * g], part);
+        }
+        xs[lane] = part;
+        wsync();
+        const double tot = (xs[lc] + xs[16 + lc]) + (xs[32 + lc] + xs[48 + lc]);
+        const int col = 16 * kk + lc;
+        const double gj = (col < n) ? tot / dl[col] : 0.0;
+        if (lr == 0) gg = fma(gj, gj, gg);
+        wsync();
+      }
+    }
+    const double gnorm = sqn * sqrt(wave_sum(gg));
+    back_solve();
+    const double pn = form_p();
+    for (int j = lane; j < n; j += WAVE) lm.ph[(long)b * lm.ld + j] = pv[j];
+    if (pn <= Delta) {                                  // trust_region.py:116-117
+      if (lane == 0) {
+        scv[SC_ALPHA] = 0.0; stv[ST_NITER] = 0; stv[ST_PHASE] = LM_IDLE; scv[SC_DELTA] = Delta;
+        lm.ncols_lm[b] = 0;
+      }
+      return;
+    }
+    const double qq = fwd_solve();                      // phi(0), phi'(0) -> alpha_lower (:121-123)
+    phi = pn - Delta;
+    dphi = -qq / pn;
+    hi = gnorm / Delta;
+    lo = -phi / dphi;
+    alpha = alpha_in[b];                                // :127-130 (full rank)
+    if (alpha < lo || alpha > hi) alpha = lm_restart_reg(lo, hi);   // :133-134, iteration 0
+    it = 0; n_iter = 0;
+    if (lane == 0) scv[SC_DELTA] = Delta;
+  }
+  for (int guard = 0; guard < 12; ++guard) {
+    const double sa = sqrt(alpha);
+    // ---- factor of H + alpha I (as gram_chol_reg_kernel; no gather, nothing stored) ----
+    for (int j = lane; j < NPAD; j += WAVE) {
+      const double cs = (csv && j < n) ? csv[j] : 1.0;
+      const double ej = (edv && j < n) ? edv[j] : 0.0;
+      const double add = (j < n) ? fma(ej, ej, sa * sa) : 0.0;
+      const double g = (j < N) ? fma(Gs[(long)j * NPAD + j] * cs, cs, add) : 0.0;
+      const bool okc = (g > 0.0) && is_finite(g);
+      double d = 1.0, s_ = 1.0;
+      if (j < N && okc) {
+        d = __builtin_amdgcn_rsq(g);
+        d = d * fma(-0.5 * g * d, d, 1.5);
+        d = d * fma(-0.5 * g * d, d, 1.5);
+        s_ = g * d;
+      }
+      dl[j] = d; sq[j] = s_; sc[j] = cs * d; td[j] = add * d * d;
+      yv[j] = 0.0; pv[j] = 0.0; zv[j] = 0.0;
+    }
+    wsync();
+    sqn = sq[n];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      double scr_[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) scr_[g] = sc[(16 * i + lr + 4 * g) < NPAD ? 16 * i + lr + 4 * g : NPAD - 1];
+#pragma unroll
+      for (int j = i; j < MT; ++j) {
+        v4d v4 = {0.0, 0.0, 0.0, 0.0};
+        if (j < NT) {
+          const int col = 16 * j + lc;
+          const int ccl = col < N ? col : N - 1;
+          const double scj = sc[col];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row = 16 * i + lr + 4 * g;
+            const int rcl = row < N ? row : N - 1;
+            const int lo_ = rcl < ccl ? rcl : ccl, hi_ = rcl < ccl ? ccl : rcl;
+            double v = Gs[(long)lo_ * NPAD + hi_];
+            v = (row < N && col < N) ? v * scr_[g] * scj : 0.0;
+            if (j == i && lr + 4 * g == lc) v += td[row];
+            v4[g] = v;
+          }
+        }
+        acc[tix(i, j)] = v4;
+      }
+    }
+    wsync();
+    double pmin = 1.0;
+#pragma unroll
+    for (int kb = 0; kb < MT; ++kb) {
+      if (kb < NT) {
+        double* Ri = Ria + kb * 256;
+        pmin = chol16_blocked3(acc[tix(kb, kb)], Dt, Ri, n - 16 * kb, pmin);
+        if (kb == jn) {                                 // the rhs column runs through this diagonal tile
+          if (lane < 16) cv[16 * kb + lane] = Dt[lane * 16 + cn];
+        }
+#pragma unroll
+        for (int j = kb + 1; j < MT; ++j) {
+          if (j < NT) {
+            v4d X = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) X = gmfma(Ri[(4 * s_ + lr) * 16 + lc], acc[tix(kb, j)][s_], X);
+            acc[tix(kb, j)] = X;
+            if (j == jn && lc == cn) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) cv[16 * kb + lr + 4 * g] = X[g];
+            }
+          }
+        }
+#pragma unroll
+        for (int i = kb + 1; i < MT; ++i) {
+#pragma unroll
+          for (int j = i; j < MT; ++j) {
+            if (j < NT) {
+#pragma unroll
+              for (int s_ = 0; s_ < 4; ++s_)
+                acc[tix(i, j)] = gmfma(-acc[tix(kb, i)][s_], acc[tix(kb, j)][s_], acc[tix(i, j)]);
+            }
+          }
+        }
+        wsync();
+      }
+    }
+    back_solve();
+    const double pn = form_p();
+    bool finished = false;
+    if (phase == LM_FINAL) {
+      finished = true;                                  // p at the updated alpha, rescale test on the STALE phi (:149)
+    } else {
+      const double qq = fwd_solve();
+      // ---- the update of lm_update_kernel (trust_region.py:136-146) ----
+      phi = pn - Delta;
+      dphi = -qq / pn;
+      if (fabs(phi) < 0.01 * Delta) {                   // :138-139
+        finished = true;
+        n_iter = it + 1;
+      } else {
+        if (phi < 0.0) hi = alpha;                      // :141-142
+        const double ratio = phi / dphi;
+        const double cand = alpha - ratio;
+        lo = (cand > lo) ? cand : lo;                   // :145
+        alpha -= (phi + Delta) * ratio / Delta;         // :146
+        ++it;
+        if (it >= 10) {                                 // max_iter reached: final p at the new alpha
+          n_iter = 10;
+          phase = LM_FINAL;
+        } else {
+          if (alpha < lo || alpha > hi) alpha = lm_restart_reg(lo, hi);   // :133-134 of the next pass
+          phase = LM_EVAL;
+        }
+      }
+    }
+    if (finished) {
+      const double f = (phi > 0.0) ? Delta / pn : 1.0;  // :149-150
+      for (int j = lane; j < n; j += WAVE) lm.ph[(long)b * lm.ld + j] = pv[j] * f;
+      break;
+    }
+  }
+  if (lane == 0) {
+    scv[SC_ALPHA] = alpha; scv[SC_LO] = lo; scv[SC_HI] = hi; scv[SC_PHI] = phi; scv[SC_DPHI] = dphi;
+    stv[ST_IT] = it; stv[ST_PHASE] = LM_IDLE; stv[ST_NITER] = n_iter;
+    lm.sa[b] = sqrt(alpha);
+    lm.ncols_lm[b] = 0;
+  }
+}
+
+hipError_t launch_lm_rounds_reg(const GramCholArgs& c, const LmState& lm, const double* Delta,
+                                const double* alpha_in, hipStream_t s) {
+  const size_t per = sizeof(double) * (8 * (size_t)c.NPAD + 256 + 5 * 256 + 16 + 64);
+  static std::atomic<size_t> granted[64];
+  hipError_t ge = gram_grant_lds(lm_rounds_reg_kernel, per * REG_NW, granted);
+  if (ge != hipSuccess) return ge;
+  hipLaunchKernelGGL(lm_rounds_reg_kernel, dim3((lm.B + REG_NW - 1) / REG_NW), dim3(REG_NT), per * REG_NW, s, c, lm,
+                     Delta, alpha_in);
+  return hipGetLastError();
+}
+
+// ---- right-looking variant: the whole (scaled) matrix lives in accumulators ----------------------
+// The NT (NT + 1) / 2 <= 153 upper tiles are dealt CYCLICALLY (row-major tile q -> wave q % 8, slot
+// q / 8) so that the shrinking trailing matrix stays balanced, and never leave the registers until
+// their row block is final.  Per row block kb: the diagonal tile goes through LDS to wave 0 for the
+// 16x16 Cholesky + inverse, the owners of the tiles (kb, j) solve them by MFMA and publish them in an
+// LDS row buffer, and every wave updates its own trailing tiles from that buffer — no global-memory
+// round trip inside the factorisation (the left-looking kernel above re-reads finished rows from L2).
+// Same arguments, same outputs, same gate bookkeeping as gram_chol_kernel.
+template <int SL>
+__global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) {
+  extern __shared__ double sh[];
+  __shared__ double red[32];
+  __shared__ double pminsh;
+  __shared__ int flagsh;                                // last diagonal tile handed to wave 0
+  const int pidx = (int)blockIdx.x;
+  if (a.count_dev && pidx >= *a.count_dev) return;
+  const int b = a.batch_list ? a.batch_list[pidx] : pidx;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane >> 4, lc = lane & 15;
+  const int NPAD = a.NPAD;
+  if (a.mask && a.mask[b] <= 1) {
+    if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
+    return;
+  }
+  if (a.skip_path && a.skip_path[b] != 0) return;
+  const int N = a.ncols_dev ? a.ncols_dev[b] : a.n + 1;
+  if (N <= 1) {                                         // (dogbox: every variable active — nothing to factor)
+    if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
+    return;
+  }
+  const int n = N - 1;
+  const int NT = (N + 15) / 16;
+  const int* gidx = a.gather ? a.gather + (long)b * a.stride_vec : nullptr;
+  auto src = [&](int i) -> int { return gidx ? (i < n ? gidx[i] : a.n) : i; };
+  const double* Gs = a.Gsrc + (long)b * NPAD * NPAD;
+  double* Gb = a.G + (long)b * NPAD * NPAD;
+  double* dl = sh;                 // [NPAD]
+  double* sq = dl + NPAD;          // [NPAD]
+  double* sc = sq + NPAD;          // [NPAD]
+  double* td = sc + NPAD;          // [NPAD]
+  double* Dt = td + NPAD;          // [256]
+  double* Ri = Dt + 256;           // [256]
+  double* Rrow = Ri + 256;         // [NT][256] finished tiles of the current row block
+  const double* csv = a.colscale ? a.colscale + (long)b * a.stride_vec : nullptr;
+  const double* edv = a.diag_vec ? a.diag_vec + (long)b * a.stride_vec : nullptr;
+  const double sa = a.diag_sqrt ? a.diag_sqrt[b] : 0.0;
+  int bad = 0;
+  for (int j = tid; j < NPAD; j += GR_NT) {
+    const double cs = (csv && j < n) ? csv[j] : 1.0;
+    const double ej = (edv && j < n) ? edv[j] : 0.0;
+    const double add = (j < n) ? fma(ej, ej, sa * sa) : 0.0;
+    const int sj_ = (j < N) ? src(j) : j;
+    const double g = (j < N) ? fma(Gs[(long)sj_ * NPAD + sj_] * cs, cs, add) : 0.0;
+    const bool okc = (g > 0.0) && is_finite(g);
+    if (j < n && !okc) bad = 1;
+    double d = 1.0, s = 1.0;
+    if (j < N && okc) {
+      d = __builtin_amdgcn_rsq(g);
+      d = d * fma(-0.5 * g * d, d, 1.5);
+      d = d * fma(-0.5 * g * d, d, 1.5);
+      s = g * d;
+    }
+    dl[j] = d; sq[j] = s; sc[j] = cs * d; td[j] = add * d * d;
+    if (a.dsc) a.dsc[(long)b * NPAD + j] = d;
+  }
+  if (a.colinfo) {
+    __syncthreads();
+    if (tid == 0) {
+      double mn = __builtin_inf(), sm = 0.0;
+      for (int j = 0; j < n; ++j) { const double v = sq[j]; mn = v < mn ? v : mn; sm = fma(v, v, sm); }
+      a.colinfo[2 * (long)b] = mn; a.colinfo[2 * (long)b + 1] = sm;
+    }
+  }
+  bad = block_or(bad, red);
+  if (tid == 0) { pminsh = 1.0; flagsh = 0; }
+  __syncthreads();
+  if (bad) {
+    if (tid == 0 && a.fb_mask) {
+      a.fb_mask[b] = a.n + 1; { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }   // (the tree factors ALL n + 1 columns)
+      if (a.path_out) a.path_out[b] = a.n + 1;
+    }
+    return;
+  }
+  // ROLES: wave 0 only runs the 16x16 chains (its registers hold the column / inverse vectors, no
+  // tiles); waves 1..7 own the tiles.  LOOKAHEAD: in the trailing update of row block kb the owner
+  // of the next diagonal tile updates it first, puts it into LDS and raises a flag; wave 0 starts
+  // the chain of block kb + 1 on that flag while the other tiles are still being updated.  Both
+  // loops pass the same two barriers per row block.
+  constexpr int NWK = GR_NW - 1;                        // worker waves
+  const int ntile = NT * (NT + 1) / 2;
+  // zeros outside the factor: strictly lower tiles, and everything beyond 16 NT (sub-matrix use)
+  auto zero_fill = [&]() {
+    for (int r = w; r < NPAD; r += GR_NW) {
+      const int cend = (r < 16 * NT) ? (r & ~15) : NPAD;
+      for (int c = lane; c < cend; c += WAVE) Gb[(unsigned)(r * NPAD + c)] = 0.0;
+      if (r < 16 * NT)
+        for (int c = 16 * NT + lane; c < NPAD; c += WAVE) Gb[(unsigned)(r * NPAD + c)] = 0.0;
+    }
+  };
+  if (w == 0) {
+    __syncthreads();                                    // X: workers have read the source, Dt holds tile (0, 0)
+    zero_fill();
+    double pmin = 1.0;
+    for (int kb = 0; kb < NT; ++kb) {
+      if (kb > 0) {                                     // wait for the updated diagonal tile kb
+        while (__hip_atomic_load(&flagsh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < kb)
+          __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+      }
+      pmin = chol16_blocked3(Dt, Ri, n - 16 * kb, pmin);   // (chol16.h)
+      if (a.rinv) {                                     // kept for the conditioning certificate
+        double* ro = a.rinv + ((long)b * (NPAD / 16) + kb) * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ro[q * 64 + lane] = Ri[q * 64 + lane];
+      }
+      __syncthreads();                                  // B: R'_kk and its inverse are in LDS
+      __syncthreads();                                  // C: (workers published the row block)
+    }
+    if (lane == 0) pminsh = pmin;
+  } else {
+    // tile table (cyclic over the worker waves: the shrinking trailing matrix stays balanced) and
+    // the scaled source tiles -> accumulators; the source may alias the output, so everything is
+    // read before anything is written
+    const int ww = w - 1;
+    int ti[SL], tj[SL];
+    v4d acc[SL];
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+      int q = ww + NWK * t;
+      const bool valid = q < ntile;
+      int i = 0;
+      while (valid && q >= NT - i) { q -= NT - i; ++i; }
+      ti[t] = valid ? i : -1;
+      tj[t] = valid ? i + q : -1;
+      acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+      if (valid) {
+        const int j = tj[t];
+        const double scj = sc[16 * j + lc];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * i + lr + 4 * g, col = 16 * j + lc;
+          double v = 0.0;
+          if (row < N && col < N) {
+            int sr_ = src(row), sc_ = src(col);
+            if (sr_ > sc_) { const int t_ = sr_; sr_ = sc_; sc_ = t_; }
+            v = Gs[(unsigned)(sr_ * NPAD + sc_)] * sc[row] * scj;
+          }
+          if (j == i && lr + 4 * g == lc) v += td[row];
+          acc[t][g] = v;
+        }
+        if (i == 0 && j == 0) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) Dt[(lr + 4 * g) * 16 + lc] = acc[t][g];
+        }
+      }
+    }
+    __syncthreads();                                    // X: all source reads done before the first store
+    zero_fill();
+    for (int kb = 0; kb < NT; ++kb) {
+      __syncthreads();                                  // B: wave 0 finished the chain of block kb
+      // c. the row block: R'_{kb,j} = R'_{kb,kb}^-T S_j -> LDS row buffer and (unscaled) to memory
+#pragma unroll
+      for (int t = 0; t < SL; ++t) {
+        if (ti[t] == kb) {
+          const int j = tj[t];
+          v4d X = {0.0, 0.0, 0.0, 0.0};
+          if (j == kb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) X[g] = Dt[(lr + 4 * g) * 16 + lc];
+          } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) X = gmfma(Ri[(4 * s + lr) * 16 + lc], acc[t][s], X);
+          }
+          const double sj = sq[16 * j + lc];
+          const double dj = dl[16 * j + lc];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int row = 16 * kb + lr + 4 * g;
+            const int colg = 16 * j + lc;
+            double val = X[g] * sj;
+            if (row >= n || row > colg || colg > n) val = 0.0;
+            Gb[(unsigned)(row * NPAD + colg)] = val;
+            // the operand of the trailing updates is what the left-looking kernel reads back: the
+            // STORED entry times its column's equilibration — the two kernels agree bit for bit
+            if (j != kb) Rrow[j * 256 + (lr + 4 * g) * 16 + lc] = val * dj;
+          }
+        }
+      }
+      __syncthreads();                                  // C: the row block is in the LDS buffer
+      // d. trailing update: the next diagonal tile first (-> LDS, flag for wave 0), then the rest
+#pragma unroll
+      for (int t = 0; t < SL; ++t) {
+        if (ti[t] == kb + 1 && tj[t] == kb + 1) {
+          const double* Ra = Rrow + ti[t] * 256 + lr * 16 + lc;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[t] = gmfma(-Ra[64 * s], Ra[64 * s], acc[t]);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) Dt[(lr + 4 * g) * 16 + lc] = acc[t][g];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_store(&flagsh, kb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < SL; ++t) {
+        if (ti[t] > kb && !(ti[t] == kb + 1 && tj[t] == kb + 1)) {
+          const double* Ra = Rrow + ti[t] * 256 + lr * 16 + lc;
+          const double* Rb = Rrow + tj[t] * 256 + lr * 16 + lc;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc[t] = gmfma(-Ra[64 * s], Rb[64 * s], acc[t]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0 && a.fb_mask) {
+    const bool fail = !(pminsh >= GRAM_SMIN * GRAM_SMIN);
+    a.fb_mask[b] = fail ? a.n + 1 : 0;
+    if (a.path_out) a.path_out[b] = fail ? a.n + 1 : 0;
+    if (fail) { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
+  }
+}
+
+// ---- conditioning gate: a PROVEN bound on kappa_2 of the equilibrated system -----------------------
+// The normal-equations path loses kappa_2(C) eps where C = R'^T R' is the equilibrated system matrix
+// (unit diagonal) the step is solved from.  An estimate of sigma_min(R') by inverse iteration is a
+// LOWER bound on ||R'^-1||, i.e. it can only err on the unsafe side.  This kernel computes an UPPER
+// bound instead, from the explicit inverse:
+//     Y = R'^-T   (lower triangular; 16 x 16 tiles by FP64 MFMA, the inverses of the diagonal tiles
+//                  come from the Cholesky kernel:  Y_ii = R'_ii^-T,
+//                  Y_ij = -R'_ii^-T sum_{k=j}^{i-1} R'_ki^T Y_kj   for j < i)
+//     1 / lambda_min(C) = ||Y||_2^2 <= ||Y||_1 ||Y||_inf ,   lambda_max(C) = ||R'||_2^2 <= ||R'||_1 ||R'||_inf
+//     K2 = ||R'||_1 ||R'||_inf ||Y||_1 ||Y||_inf  >=  kappa_2(C)
+// (all four norms are exact sums of absolute values, accumulated in a fixed order) and keeps the
+// problem on the normal-equations path only if K2 <= GRAM_K2_MAX.  DESIGN.md 3.0 has the error bound
+// this gives for the step.  NWP waves per problem as in gram_chol_kernel.
+template <int NWP>
+__global__ __launch_bounds__(GR_NT, 4) void gram_cond_kernel(GramCholArgs a) {
+  constexpr int PT = WAVE * NWP;
+  constexpr int PPW = GR_NW / NWP;
+  constexpr int UMAX = (NWP == 8) ? 3 : 5;              // column tiles of a row block per wave
+  extern __shared__ double sh_all[];
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int pslot = wv / NWP;
+  const int pidx = (int)blockIdx.x * PPW + pslot;
+  if (pidx >= a.count) return;                          // (NWP == 1 only: wave-uniform)
+  const int b = pidx;
+  const int tid = (int)threadIdx.x % PT, lane = tid & 63;
+  const int w = wv % NWP;
+  const int lr = lane >> 4, lc = lane & 15;
+  if (a.mask && a.mask[b] <= 1) return;
+  if (a.fb_mask[b] != 0) return;                        // already failed on a pivot
+  if (a.cert_done && a.cert_done[b]) return;            // already proven inside the factor kernel (N <= 80)
+  const int NPAD = a.NPAD;
+  const int n = a.ncols_dev ? a.ncols_dev[b] - 1 : a.n;
+  if (n <= 0) return;
+  const int NTn = (n + 15) / 16;
+  auto psync = [&]() {
+    if (NWP == 8) __syncthreads();
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  };
+  double* sh = sh_all + (size_t)pslot * (6 * (size_t)NPAD + 16 * NWP + 64);
+  double* dl = sh;                      // [NPAD] column scales: R'[i][j] = T[i][j] dl[j]
+  double* cs4 = dl + NPAD;              // [NPAD][4] column sums of |Y|, one slot per lane row
+  double* rs = cs4 + 4 * NPAD;          // [NWP][16] row-sum partials of the current block row
+  double* vals = rs + 16 * NWP;         // [64] reduction scratch
+  double* rowsR = vals + 64;            // [NPAD] row sums of |R'|
+  const double* T = a.G + (long)b * NPAD * NPAD;
+  double* Y = a.ywork + (long)b * NPAD * NPAD;
+  const double* Rinv = a.rinv + (long)b * (NPAD / 16) * 256;
+  for (int j = tid; j < NPAD; j += PT) dl[j] = a.dsc[(long)b * NPAD + j];
+  psync();
+  auto reduce_max = [&](double v) -> double {           // max over the threads of this problem
+    v = wave_max(v);
+    if (NWP == 1) return v;
+    psync();
+    if (lane == 0) vals[w] = v;
+    psync();
+    double t = vals[0];
+    for (int q = 1; q < NWP; ++q) t = fmax(t, vals[q]);
+    return t;
+  };
+  // ---- ||R'||_1 (thread per column) and ||R'||_inf (wave per row) ----
+  double r1 = 0.0;
+  for (int j = tid; j < n; j += PT) {
+    double sum = 0.0;
+    for (int i0 = 0; i0 <= j; i0 += 8) {
+      double rv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rv[u] = T[(long)((i0 + u <= j) ? i0 + u : j) * NPAD + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (i0 + u <= j) sum += fabs(rv[u]);
+    }
+    r1 = fmax(r1, sum * dl[j]);
+  }
+  r1 = reduce_max(r1);
+  if constexpr (NWP == 1) {
+    // one wave per problem: four rows at a time, one per 16-lane group (64 sequential wave
+    // reductions at n = 64 were 20 of this kernel's 46 us)
+    for (int i0 = 0; i0 < n; i0 += 4) {
+      const int i = i0 + lr;
+      double sum = 0.0;
+      if (i < n)
+        for (int j = i + lc; j < n; j += 16) sum += fabs(T[(long)i * NPAD + j]) * dl[j];
+      sum = row16_sum(sum);
+      if (lc == 0 && i < n) rowsR[i] = sum;
+    }
+  } else {
+    for (int i = w; i < n; i += NWP) {
+      double sum = 0.0;
+      for (int j = i + lane; j < n; j += WAVE) sum += fabs(T[(long)i * NPAD + j]) * dl[j];
+      sum = wave_sum(sum);
+      if (lane == 0) rowsR[i] = sum;
+    }
+  }
+  psync();
+  double rinf = 0.0;
+  for (int i = tid; i < n; i += PT) rinf = fmax(rinf, rowsR[i]);
+  rinf = reduce_max(rinf);
+  // ---- Y = R'^-T by block rows; row and column sums of |Y| on the way ----
+  double csum[UMAX];
+#pragma unroll
+  for (int u = 0; u < UMAX; ++u) csum[u] = 0.0;
+  double rmax = 0.0;                                    // threads 0..15: max over block rows of "their" row
+  for (int i = 0; i < NTn; ++i) {
+    double rsum[4] = {0.0, 0.0, 0.0, 0.0};
+    const double* Ri = Rinv + (long)i * 256;
+    const double dli = dl[16 * i + lc];
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) {
+      const int j = w + NWP * u;
+      if (j <= i) {
+        v4d Yt = {0.0, 0.0, 0.0, 0.0};
+        if (j == i) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) Yt[g] = Ri[lc * 16 + lr + 4 * g];         // (R'_ii^-1)^T
+        } else {
+          v4d acc = {0.0, 0.0, 0.0, 0.0};
+          for (int k = j; k < i; ++k) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const long ro = (long)(16 * k + 4 * s + lr) * NPAD;
+              av[s] = T[ro + 16 * i + lc];
+              bv[s] = Y[ro + 16 * j + lc];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = gmfma(av[s] * dli, bv[s], acc);
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) Yt = gmfma(-Ri[(4 * s + lr) * 16 + lc], acc[s], Yt);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * i + lr + 4 * g, col = 16 * j + lc;
+          const double v = (row < n && col < n) ? Yt[g] : 0.0;
+          Y[(long)row * NPAD + col] = v;
+          const double av_ = fabs(v);
+          rsum[g] += row16_sum(av_);
+          csum[u] += av_;
+        }
+      }
+    }
+    if (lc == 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) rs[w * 16 + lr + 4 * g] = rsum[g];
+    }
+    psync();                                            // row sums in LDS; Y row block i visible
+    if (tid < 16) {
+      double t = 0.0;
+      for (int q = 0; q < NWP; ++q) t += rs[q * 16 + tid];
+      rmax = fmax(rmax, t);
+    }
+    psync();
+  }
+#pragma unroll
+  for (int u = 0; u < UMAX; ++u) {
+    const int j = w + NWP * u;
+    if (j < NTn) cs4[(16 * j + lc) * 4 + lr] = csum[u];
+  }
+  psync();
+  double y1 = 0.0;
+  for (int c = tid; c < n; c += PT)
+    y1 = fmax(y1, (cs4[4 * c] + cs4[4 * c + 1]) + (cs4[4 * c + 2] + cs4[4 * c + 3]));
+  y1 = reduce_max(y1);
+  const double yinf = reduce_max(tid < 16 ? rmax : 0.0);
+  double k2 = (r1 * rinf) * (y1 * yinf);
+  if (!(k2 <= GRAM_K2_MAX)) {                            // (uniform over the problem's threads)
+    // The 1- / inf-norm products overestimate kappa_2 by 10 ... 1000 (profiles/r02p_gate_calibration.txt).
+    // Second, tighter proven bound for a problem they reject:  lambda_max(C) <= ||C||_F  and
+    // 1 / lambda_min(C) = ||C^-1||_2 <= ||C^-1||_F  with  C^-1 = Y^T Y  formed tile by tile (MFMA; only
+    // its sum of squares is kept) and C rebuilt from the source Gram with the Cholesky's own scalings.
+    // Measured overestimate 4 ... 30 on the ill-conditioned families.  Sums in a fixed order.
+    const int* gidx = a.gather ? a.gather + (long)b * a.stride_vec : nullptr;
+    auto src = [&](int i) -> int { return gidx ? (i < n ? gidx[i] : a.n) : i; };
+    const double* Gs = a.Gsrc + (long)b * NPAD * NPAD;
+    const double* csv = a.colscale ? a.colscale + (long)b * a.stride_vec : nullptr;
+    const double* edv = a.diag_vec ? a.diag_vec + (long)b * a.stride_vec : nullptr;
+    double* scl = cs4;                  // [NPAD] cs_j dl_j   (cs4 is free now)
+    double* tdl = cs4 + NPAD;           // [NPAD] e_j^2 dl_j^2
+    psync();
+    for (int j = tid; j < NPAD; j += PT) {
+      const double cs = (csv && j < n) ? csv[j] : 1.0;
+      const double ej = (edv && j < n) ? edv[j] : 0.0;
+      scl[j] = cs * dl[j];
+      tdl[j] = (ej * ej) * dl[j] * dl[j];
+    }
+    psync();
+    double cf = 0.0, zf = 0.0;          // this wave's share of ||C||_F^2 / ||C^-1||_F^2
+    int q = 0;
+    for (int j = 0; j < NTn; ++j) {
+      for (int i = 0; i <= j; ++i, ++q) {
+        if (q % NWP != w) continue;     // (wave-uniform)
+        const double wgt = (i == j) ? 1.0 : 2.0;
+        double c2 = 0.0;
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * i + lr + 4 * g, col = 16 * j + lc;
+          double v = 0.0;
+          if (row < n && col < n) {
+            int sr_ = src(row), sc_ = src(col);
+            if (sr_ > sc_) { const int t_ = sr_; sr_ = sc_; sc_ = t_; }
+            v = Gs[(long)sr_ * NPAD + sc_] * scl[row] * scl[col];
+            if (row == col) v += tdl[row];
+          }
+          c2 = fma(v, v, c2);
+        }
+        for (int k = j; k < NTn; ++k) {
+          double av[4], bv[4];
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) {
+            const long ro = (long)(16 * k + 4 * s2 + lr) * NPAD;
+            av[s2] = Y[ro + 16 * i + lc];
+            bv[s2] = Y[ro + 16 * j + lc];
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) acc = gmfma(av[s2], bv[s2], acc);
+        }
+        const double z2 = (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]);
+        cf = fma(wgt, wave_sum(c2), cf);
+        zf = fma(wgt, wave_sum(z2), zf);
+      }
+    }
+    if (NWP > 1) {
+      psync();
+      if (lane == 0) { vals[w] = cf; vals[8 + w] = zf; }
+      psync();
+      cf = 0.0; zf = 0.0;
+      for (int qq = 0; qq < NWP; ++qq) { cf += vals[qq]; zf += vals[8 + qq]; }
+    }
+    const double k2f = sqrt(cf) * sqrt(zf);
+    if (k2f < k2) k2 = k2f;
+  }
+  if (tid == 0) {
+    if (a.k2_out) a.k2_out[b] = k2;
+    if (!(k2 <= GRAM_K2_MAX)) {                          // (NaN fails)
+      a.fb_mask[b] = a.n + 1;
+      if (a.path_out) a.path_out[b] = a.n + 1;
+      { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
+    }
+  }
+}
+
+bool gram_supported(int m, int n) {
+  const int NT = (n + 1 + 15) / 16;
+  return NT <= 17 && m >= n && n >= 1;
+}
+// Row chunks whose size is a function of m ALONE (never of the batch size): the summation order of
+// a problem's Gram (and so every bit of its result) does not depend on how many problems share the
+// launch.  2048 rows; 1024 for very tall problems (one 250 000 x 128 row block of BASELINE config 5:
+// 245 workgroups fill the 256 CUs, 123 leave half of them idle).
+hipError_t launch_gram_chol(const GramCholArgs& a_in, int B, hipStream_t s) {
+  GramCholArgs a = a_in;
+  a.count = B;
+  const size_t per = sizeof(double) * (4 * (size_t)a.NPAD + 512);
+  if (a.NPAD <= 80) {                                   // one wave per problem, eight per workgroup
+    // (register-resident right-looking kernel; BLSQ_CHOL_REG = 0: the left-looking one-wave kernel)
+    const char* rge = getenv("BLSQ_CHOL_REG");
+    if (rge && rge[0] == '0')
+      hipLaunchKernelGGL(gram_chol_kernel<1>, dim3((B + GR_NW - 1) / GR_NW), dim3(GR_NT), per * GR_NW,
+                         s, a);
+    else {
+      const size_t per_reg = sizeof(double) * (4 * (size_t)a.NPAD + 256 + 5 * 256 + 64);
+      static std::atomic<size_t> granted[64];
+      hipError_t ge = gram_grant_lds(gram_chol_reg_kernel, per_reg * REG_NW, granted);
+      if (ge != hipSuccess) return ge;
+      hipLaunchKernelGGL(gram_chol_reg_kernel, dim3((B + REG_NW - 1) / REG_NW), dim3(REG_NT), per_reg * REG_NW,
+                         s, a);
+    }
+  } else {
+    // Right-looking register variant: 0.22 ms per problem on a CU of its own against 0.27 ms for
+    // the left-looking kernel, but one workgroup per CU instead of two — so it serves the launches
+    // that cannot fill the CUs twice anyway (the Newton rounds), the left-looking one the rest.
+    // BLSQ_CHOL_RL = 0 / 1 forces either.
+    // The two kernels agree bit for bit (same operands, same order), so the choice is speed only.
+    const char* rle = getenv("BLSQ_CHOL_RL");          // (read per launch: tests compare the two)
+    const int rl_env = rle ? (rle[0] == '0' ? 0 : 1) : -1;
+    constexpr int ncu = 256;                           // MI355X: 8 XCDs x 32 CUs
+    const bool rl = rl_env >= 0 ? rl_env != 0 : (a.expect > 0 ? a.expect : B) <= ncu;
+    if (rl) {
+      const size_t lds = per + sizeof(double) * 256 * (size_t)(a.NPAD / 16);
+      static std::atomic<size_t> granted[64];
+      hipError_t ge = gram_grant_lds(gram_chol_rl_kernel<22>, lds, granted);
+      if (ge != hipSuccess) return ge;
+      hipLaunchKernelGGL(gram_chol_rl_kernel<22>, dim3(B), dim3(GR_NT), lds, s, a);
+    } else {
+      hipLaunchKernelGGL(gram_chol_kernel<8>, dim3(B), dim3(GR_NT), per, s, a);
+    }
+  }
+  return hipGetLastError();
+}
+hipError_t launch_gram_gate(const GramCholArgs& a_in, int B, hipStream_t s) {
+  GramCholArgs a = a_in;
+  a.count = B;
+  const size_t per1 = sizeof(double) * (6 * (size_t)a.NPAD + 16 * 1 + 64);
+  const size_t per8 = sizeof(double) * (6 * (size_t)a.NPAD + 16 * 8 + 64);
+  if (a.NPAD <= 80) {                                   // one wave per problem, eight per workgroup
+    hipLaunchKernelGGL(gram_cond_kernel<1>, dim3((B + GR_NW - 1) / GR_NW), dim3(GR_NT), per1 * GR_NW, s, a);
+  } else {
+    hipLaunchKernelGGL(gram_cond_kernel<8>, dim3(B), dim3(GR_NT), per8, s, a);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace blsq

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_gate_kernel(LmState lm, int enable)
   double* invd = u + ld;
   double* pfbuf = invd + ld;                 // 2 x 16 x ld doubles: DMA staging of the solves
   int ok = (enable != 0) && (lm.m >= n);
-  // Gram-path problems (gram_kernels.hip): R_aug = R'_aug diag(sqrt h_jj) with sigma_min(R'_aug) >=
+  // Gram-path problems (chol_kernels.hip): R_aug = R'_aug diag(sqrt h_jj) with sigma_min(R'_aug) >=
   // sigma_min(R') >= GRAM_SMIN_PROVEN (the conditioning certificate), so  s_min >= that x min_j sqrt(h_jj)  and  s_max <= sqrt(sum_j h_jj)
   // (the exact Frobenius norm).  When that already clears the threshold below, the iteration is
   // not needed; otherwise (extreme column scaling near the bounds) the estimate runs as always.

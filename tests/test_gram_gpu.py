@@ -1,4 +1,4 @@
-"""Normal-equations fast path of the factorisation (gram_kernels.hip) and its conditioning gate.
+"""Normal-equations fast path of the factorisation (gram_kernels.hip, chol_kernels.hip) and its conditioning gate.
 
 The step must match the CPU oracle to 1e-10 / bit-exact masks WHICHEVER path factors a problem;
 the diagnostic counter (blsq_debug_gram_stats) shows which one ran.

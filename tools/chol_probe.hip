@@ -1,7 +1,7 @@
-// Stand-alone timing / check of the blocked Cholesky kernels of csrc/gram_kernels.hip (development aid)
+// Stand-alone timing / check of the blocked Cholesky kernels of csrc/chol_kernels.hip (development aid)
 //   hipcc --offload-arch=gfx950 -O3 -I bounded-lsq_amd/csrc tools/chol_probe.hip -o tools/_build/chol_probe
 //   ./chol_probe n B [reps]
-#include "gram_kernels.hip"
+#include "chol_kernels.hip"
 #include <cmath>
 #include <cstdio>
 #include <vector>
