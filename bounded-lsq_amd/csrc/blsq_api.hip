@@ -464,6 +464,18 @@ struct blsq_trf_plan {
   bool gate_done = false;           // lm_gate already ran in this factor call (no problem left the normal-equations path)
   int lm_expect0 = 0;               // problems the first Newton round of the last step call worked on (kernel choice hint)
   int njac = -1;                    // problems it sent to the Jacobi SVD (-1: unknown)
+  // Optimistic verdict (blsq_trf_factor_dev): the factor call does not wait for the gate's two counters;
+  // it assumes "every problem stays on the normal-equations path, nobody needs the SVD", and the NEXT
+  // call on the plan checks — by then the counters have long arrived.  blsq_trf_step_dev enqueues its
+  // kernels first and checks afterwards (a wrong guess: fallback stage, then the step once more).
+  bool optimistic = true;           // BLSQ_OPTIMISTIC = 0 switches it off
+  bool guess_ok = true;             // the last verdict of this plan was "all fast": only then is the next one guessed
+  bool pending = false;
+  int* pend_pin = nullptr;          // 2 pinned ints of this plan
+  hipEvent_t pend_ev = nullptr;
+  const double* pend_dJ = nullptr; const double* pend_df = nullptr;
+  int pend_ldJ = 0, pend_scale_mode = 0;
+  double* pend_scale_io = nullptr;
 };
 
 struct blsq_dogbox_plan {
@@ -813,7 +825,7 @@ int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode) {
 
 // prep from the Gram, Cholesky of H with the pivot gate, conditioning gate; *nfb = problems of this
 // call that must go to the Householder tree (their indices are flagged in tree.fb_mask()).
-int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb) {
+int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, bool defer = false) {
   blsq_ctx* ctx = p->ctx;
   QrTree& t = p->tree;
   HIPCHK(ctx, hipMemsetAsync(t.fb_count(), 0, 2 * sizeof(int), ctx->stream));
@@ -849,12 +861,22 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb) 
   e = launch_lm_gate(p->lm, p->lm_enable, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_lm_gate");
-  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 1, t.fb_count(), 2 * sizeof(int), hipMemcpyDeviceToHost,
-                             ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  *nfb = ctx->pinned[1];
-  p->gate_done = (*nfb == 0);
-  p->njac = p->gate_done ? ctx->pinned[2] : -1;
+  if (defer) {                              // the counters travel; the verdict is read by trf_resolve
+    HIPCHK(ctx, hipMemcpyAsync(p->pend_pin, t.fb_count(), 2 * sizeof(int), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIPCHK(ctx, hipEventRecord(p->pend_ev, ctx->stream));
+    p->pending = true;
+    *nfb = 0;
+    p->gate_done = true;
+    p->njac = 0;
+  } else {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 1, t.fb_count(), 2 * sizeof(int), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *nfb = ctx->pinned[1];
+    p->gate_done = (*nfb == 0);
+    p->njac = p->gate_done ? ctx->pinned[2] : -1;
+  }
   t.note_paths(ctx, *nfb, mask != nullptr);
   p->path = t.path_rw();
   p->use_chol = t.any_gram;
@@ -879,18 +901,55 @@ int trf_fallback_stage(blsq_trf_plan* p, const double* dJ, const double* df, int
 
 // the whole factor call from device-resident [J f] (mask: outer driver, fresh Jacobians only)
 int trf_factor_core(blsq_trf_plan* p, const double* dJ, const double* df, int ldJ, int scale_mode,
-                    const int* mask) {
+                    const int* mask, bool may_defer = false) {
   blsq_ctx* ctx = p->ctx;
   int rc;
+  p->pending = false;                       // (a verdict nobody asked for belongs to an overwritten factor)
   if (!p->tree.gram) {
     if ((rc = p->tree.run_levels(ctx, dJ, df, ldJ, mask))) return rc;
     return trf_after_triangle(p, p->tree.Rfinal(), scale_mode);
   }
   if ((rc = p->tree.run_gram_only(ctx, dJ, df, ldJ, mask, false))) return rc;
   int nfb = 0;
-  if ((rc = trf_gram_stage(p, scale_mode, mask, &nfb))) return rc;
+  // (never in the n-band that always takes the SVD, nor right after a wrong guess)
+  const bool defer = may_defer && p->optimistic && p->guess_ok && p->lm_enable && !mask && p->pend_pin &&
+                     p->pend_ev;
+  if ((rc = trf_gram_stage(p, scale_mode, mask, &nfb, defer))) return rc;
+  if (defer) { p->pend_dJ = dJ; p->pend_df = df; p->pend_ldJ = ldJ; p->pend_scale_mode = scale_mode; }
+  else if (!mask) p->guess_ok = (nfb == 0 && p->njac == 0);
   if (nfb > 0 && (rc = trf_fallback_stage(p, dJ, df, ldJ, scale_mode, nfb))) return rc;
   return trf_finish(p);
+}
+
+// The verdict of an optimistic factor call.  *redo = false: nothing was pending, or the guess held.
+// *redo = true: it did not — the state is now what the synchronous path would have left (fallback
+// stage, rank gate, SVD), and whatever was computed from the guessed state must be computed again.
+int trf_resolve(blsq_trf_plan* p, bool* redo) {
+  if (redo) *redo = false;
+  if (!p->pending) return 0;
+  blsq_ctx* ctx = p->ctx;
+  p->pending = false;
+  HIPCHK(ctx, hipEventSynchronize(p->pend_ev));
+  const int nfb = p->pend_pin[0], njac = p->pend_pin[1];
+  if (nfb == 0 && njac == 0) return 0;
+  p->guess_ok = false;
+  if (redo) *redo = true;
+  QrTree& t = p->tree;
+  ctx->gram_fast -= nfb; ctx->gram_fallback += nfb;      // (note_paths counted everybody as fast)
+  t.any_qr = nfb > 0; t.any_gram = nfb < p->B; t.path_valid = true;
+  p->gate_done = (nfb == 0);
+  p->njac = p->gate_done ? njac : -1;
+  p->use_chol = t.any_gram;
+  p->use_qr = t.any_qr;
+  p->lm.colinfo = p->use_chol ? p->aug_colinfo.as<double>() : nullptr;
+  int rc;
+  if (nfb > 0 && (rc = trf_fallback_stage(p, p->pend_dJ, p->pend_df, p->pend_ldJ, p->pend_scale_mode, nfb)))
+    return rc;
+  if ((rc = trf_finish(p))) return rc;
+  if (p->pend_scale_mode != BLSQ_SCALE_GIVEN && p->pend_scale_io)
+    HIPCHK(ctx, hipMemcpy2DAsync(p->pend_scale_io, sizeof(double) * p->n, p->st.scale, sizeof(double) * p->ld,
+                                 sizeof(double) * p->n, p->B, hipMemcpyDeviceToDevice, ctx->stream));
+  return 0;
 }
 
 // Safeguarded Newton iteration of the SVD-free problems: lock-step rounds of
@@ -1029,6 +1088,13 @@ extern "C" int blsq_trf_plan_create(blsq_ctx* ctx, int B, int m, int n, blsq_trf
   const int aug_rp = std::max(aug_rows(n), round_up(n + 1, 16));
   int rc = p->tree.build(ctx, B, m, n, (size_t)B * aug_rp);
   if (rc == 0) { p->ld = p->tree.NPAD; rc = trf_alloc_state(p); }
+  if (rc == 0) {
+    const char* oe = getenv("BLSQ_OPTIMISTIC");
+    p->optimistic = !(oe && oe[0] == '0');
+    hipError_t e = hipHostMalloc((void**)&p->pend_pin, 2 * sizeof(int), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->pend_ev, hipEventDisableTiming);
+    if (e != hipSuccess) rc = ctx->fail(e, "optimistic-verdict resources");
+  }
   if (rc != 0) { blsq_trf_plan_destroy(p); return rc; }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   *out = p;
@@ -1038,6 +1104,8 @@ extern "C" int blsq_trf_plan_create(blsq_ctx* ctx, int B, int m, int n, blsq_trf
 extern "C" int blsq_trf_plan_destroy(blsq_trf_plan* p) {
   if (!p) return -1;
   hipStreamSynchronize(p->ctx->stream);
+  if (p->pend_pin) hipHostFree(p->pend_pin);
+  if (p->pend_ev) hipEventDestroy(p->pend_ev);
   p->tree.release(); p->Rcomb.release(); p->Rstack.release();
   p->X.release(); p->vecs.release(); p->scal2.release(); p->sweeps.release();
   p->o_vec.release(); p->o_hits.release(); p->o_act.release(); p->o_scal.release();
@@ -1079,7 +1147,8 @@ extern "C" int blsq_trf_factor_dev(blsq_trf_plan* p, const double* dJ, const dou
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc = trf_put_bounds(p, dx, dlb, dub, dscale_io, hipMemcpyDeviceToDevice);
   if (rc) return rc;
-  if ((rc = trf_factor_core(p, dJ, df, p->n, scale_mode, nullptr))) return rc;
+  p->pend_scale_io = dscale_io;
+  if ((rc = trf_factor_core(p, dJ, df, p->n, scale_mode, nullptr, true))) return rc;
   if (scale_mode != BLSQ_SCALE_GIVEN) {
     HIPCHK(ctx, hipMemcpy2DAsync(dscale_io, sizeof(double) * p->n, p->st.scale,
                                  sizeof(double) * p->ld, sizeof(double) * p->n, p->B,
@@ -1095,13 +1164,19 @@ extern "C" int blsq_trf_step_dev(blsq_trf_plan* p, const double* dDelta, const d
   if (!dDelta) return ctx->bad(2, "Delta is NULL");
   if (!dalpha_in) return ctx->bad(3, "alpha is NULL");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  int rc = trf_lm_rounds(p, dDelta, dalpha_in);
-  if (rc) return rc;
-  ctx->begin(K_STEP);
-  hipError_t e = launch_trf_step(p->st, &p->lm, dDelta, dalpha_in, active_rtol, p->out,
-                                 ctx->stream);
-  ctx->end();
-  if (e != hipSuccess) return ctx->fail(e, "launch_trf_step");
+  // (pass 0 may run on the guessed state of an optimistic factor call; pass 1 only if the guess was wrong)
+  for (int pass = 0; pass < 2; ++pass) {
+    int rc = trf_lm_rounds(p, dDelta, dalpha_in);
+    if (rc) return rc;
+    ctx->begin(K_STEP);
+    hipError_t e = launch_trf_step(p->st, &p->lm, dDelta, dalpha_in, active_rtol, p->out,
+                                   ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_trf_step");
+    bool redo = false;
+    if ((rc = trf_resolve(p, &redo))) return rc;
+    if (!redo) break;
+  }
   return 0;
 }
 
@@ -1110,6 +1185,7 @@ extern "C" int blsq_trf_fetch_factor(blsq_trf_plan* p, double* g, double* g_norm
   if (!p) return -1;
   blsq_ctx* ctx = p->ctx;
   int rc;
+  if ((rc = trf_resolve(p, nullptr))) return rc;
   if ((rc = get_vec(ctx, g, p->n, p->st.g, p->ld, p->B))) return rc;
   if ((rc = get_vec(ctx, scale, p->n, p->st.scale, p->ld, p->B))) return rc;
   if ((rc = get_vec(ctx, sing, p->n, p->st.s, p->ld, p->B))) return rc;
@@ -1129,6 +1205,7 @@ extern "C" int blsq_trf_debug_fast(blsq_trf_plan* p, int32_t* fast) {
   if (!p) return -1;
   blsq_ctx* ctx = p->ctx;
   if (!fast) return ctx->bad(2, "fast is NULL");
+  { int rc_ = trf_resolve(p, nullptr); if (rc_) return rc_; }
   HIPCHK(ctx, hipMemcpyAsync(fast, p->lm.fast, sizeof(int) * p->B, hipMemcpyDeviceToHost,
                              ctx->stream));
   return blsq_sync(ctx);
@@ -1139,6 +1216,7 @@ extern "C" int blsq_trf_debug_cond(blsq_trf_plan* p, double* k2) {
   blsq_ctx* ctx = p->ctx;
   if (!k2) return ctx->bad(2, "k2 is NULL");
   if (!p->tree.gram) { for (int b = 0; b < p->B; ++b) k2[b] = 0.0; return 0; }
+  { int rc_ = trf_resolve(p, nullptr); if (rc_) return rc_; }
   HIPCHK(ctx, hipMemcpyAsync(k2, p->tree.gram_k2.p, sizeof(double) * p->B, hipMemcpyDeviceToHost,
                              ctx->stream));
   return blsq_sync(ctx);
@@ -1148,6 +1226,7 @@ extern "C" int blsq_trf_debug_sweeps(blsq_trf_plan* p, int32_t* sweeps) {
   if (!p) return -1;
   blsq_ctx* ctx = p->ctx;
   if (!sweeps) return ctx->bad(2, "sweeps is NULL");
+  { int rc_ = trf_resolve(p, nullptr); if (rc_) return rc_; }
   HIPCHK(ctx, hipMemcpyAsync(sweeps, p->sweeps.p, sizeof(int) * p->B, hipMemcpyDeviceToHost,
                              ctx->stream));
   return blsq_sync(ctx);

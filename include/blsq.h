@@ -89,7 +89,13 @@ int blsq_trf_step(blsq_trf_plan* plan, const double* Delta /*B*/, double* alpha_
                   int32_t* status /*B*/);
 
 /* device-pointer variants: inputs already resident in HBM, results stay in
- * plan-owned device buffers until fetched. */
+ * plan-owned device buffers until fetched.
+ * blsq_trf_factor_dev is asynchronous all the way: it does not wait for the per-problem verdict of the
+ * conditioning certificate (which problems must take the Householder route) but assumes the common one
+ * — "none" — and the NEXT call on the plan reads the verdict: blsq_trf_step_dev enqueues its kernels
+ * first and, should the guess have been wrong, runs the Householder stage and the step once more
+ * (same results either way).  Consequence for the caller: dJ / df / dscale_io must stay valid until
+ * that next call.  Environment BLSQ_OPTIMISTIC=0: the factor call waits itself. */
 int blsq_trf_factor_dev(blsq_trf_plan* plan, const double* dJ, const double* df,
                         const double* dx, const double* dlb, const double* dub,
                         double* dscale_io, int scale_mode);

@@ -446,6 +446,49 @@ def test_newton_rounds_in_one_launch(bl, monkeypatch, n):
     assert np.array_equal(stm[:B], st1) and np.array_equal(am[:B], a1) and np.array_equal(itm[:B], it1)
 
 
+@pytest.mark.parametrize("shape", [(700, 64), (1500, 200)])
+def test_optimistic_verdict_of_the_device_api(bl, monkeypatch, shape):
+    """blsq_trf_factor_dev does not wait for the gate's counters: it guesses "everybody stays on the
+    normal-equations path, nobody needs the SVD", blsq_trf_step_dev enqueues its kernels on that guess
+    and only then reads the verdict — a wrong guess runs the fallback stage and the step once more.
+    Right guess, wrong guess (problems that fail the certificate; a rank-deficient problem that needs
+    the SVD) and the synchronous mode (BLSQ_OPTIMISTIC = 0) must give the same bits, and the path
+    statistics must come out the same."""
+    from bounded_lsq import _synth, _abi
+    m, n = shape
+    B = 6
+    good = _synth.trf_batch(400 + n, B, m, n)
+    mixed = {k: v.copy() for k, v in good.items()}
+    mixed["J"][1] = _equicorrelated(1, m, n, 1 - 1e-9, 3)[0]          # fails the certificate
+    mixed["lb"][1] = -np.inf; mixed["ub"][1] = np.inf
+    mixed["J"][4][:, n - 1] = mixed["J"][4][:, 0]                        # rank deficient: pivot gate, then the SVD
+    mixed["lb"][4] = -np.inf; mixed["ub"][4] = np.inf
+    Delta = np.array([0.5, 0.05, 5.0, 0.2, 0.3, 1.0])
+    for P, expect_fb in ((good, 0), (mixed, 2)):
+        outs = []
+        for opt in ("1", "0"):
+            monkeypatch.setenv("BLSQ_OPTIMISTIC", opt)
+            ctx = _abi.Context(0)
+            sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
+            d = {k: ctx.to_device(P[k]) for k in ("J", "f", "x", "lb", "ub", "scale")}
+            dD, dA = ctx.to_device(Delta), ctx.to_device(np.zeros(B))
+            ctx.gram_stats(reset=True)
+            for _ in range(2):                                          # (a second round on the settled plan)
+                sol.factor_dev(d["J"], d["f"], d["x"], d["lb"], d["ub"], d["scale"])
+                sol.step_dev(dD, dA)
+            S = sol.fetch_step()
+            stats = ctx.gram_stats()
+            assert stats == (2 * (B - expect_fb), 2 * expect_fb), (opt, stats)
+            outs.append((S.step.copy(), np.asarray(S.alpha).copy(), np.asarray(S.n_iter).copy(), S.hits.copy(),
+                         sol.fetch_factor().g.copy()))
+            sol.close()
+            for v in list(d.values()) + [dD, dA]:
+                ctx.free(v)
+            ctx.close()
+        for x1, x0 in zip(*outs):
+            assert np.array_equal(x1, x0)
+
+
 def test_chunk_pairs_summed_in_the_kernel_match_the_reduction_pass(bl, monkeypatch):
     """Two row chunks (2048 < m <= 4096), 16 column tiles and at least 256 problems: one workgroup
     takes both chunks and adds them in the kernel, (0 + P0) + P1 — what the separate reduction pass
