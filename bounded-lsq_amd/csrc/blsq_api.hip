@@ -460,7 +460,8 @@ struct blsq_trf_plan {
   // SVD-free trust-region path (lm_kernels.hip)
   DevBuf lm_Xa, lm_ints, lm_sc, lm_ph, lm_sa;
   LmState lm{};
-  int lm_enable = 1;
+  int lm_enable = 1;                // SVD-free trust-region path allowed at all (BLSQ_NO_SVDFREE)
+  int lm_gate_mask = 3;             // launch_lm_gate: bit 0 Householder-path problems, bit 1 normal-equations-path problems
   bool gate_done = false;           // lm_gate already ran in this factor call (no problem left the normal-equations path)
   int lm_expect0 = 0;               // problems the first Newton round of the last step call worked on (kernel choice hint)
   int njac = -1;                    // problems it sent to the Jacobi SVD (-1: unknown)
@@ -737,18 +738,20 @@ int trf_alloc_state(blsq_trf_plan* p) {
     lm.active_count = ii + 7 * (size_t)B;
     lm.active_list = ii + 7 * (size_t)B + 16; lm.round = 0;
     lm.sc = p->lm_sc.as<double>(); lm.ph = p->lm_ph.as<double>();
-    // The SVD-free Newton iteration costs one small stacked QR per iteration.  Measured
-    // (8192..16384 problems per launch, Delta mix 10/0.5; SVD-free vs Jacobi-SVD step-solves/s):
-    // 64x8 5.3M vs 3.4M, 128x16 6.2M vs 2.9M (one panel: the QR is trivial), 256x32 1.55M vs
-    // 1.73M, 512x40 0.90M vs 0.90M, 512x48 0.98M vs 0.89M, 512x64 0.76M vs 0.70M.  So the
-    // Jacobi SVD keeps the band 16 < n < 48 where a round of tiny two-panel QRs costs as much as
-    // the whole in-LDS SVD.  BLSQ_SVDFREE_MIN_N overrides the upper edge (0: SVD-free whenever
-    // the gate passes), BLSQ_NO_SVDFREE=1 forces the SVD.
+    // Householder-path problems: the SVD-free Newton iteration costs one small stacked QR per
+    // iteration.  Measured in round 1 (8192..16384 problems per launch, Delta mix 10/0.5; SVD-free vs
+    // Jacobi-SVD step-solves/s): 64x8 5.3M vs 3.4M, 128x16 6.2M vs 2.9M (one panel: the QR is trivial),
+    // 256x32 1.55M vs 1.73M, 512x40 0.90M vs 0.90M, 512x48 0.98M vs 0.89M, 512x64 0.76M vs 0.70M.  So for
+    // THEM the Jacobi SVD keeps the band 16 < n < 48, where a round of tiny two-panel QRs costs as much
+    // as the whole in-LDS SVD.  Normal-equations-path problems have no such band: their rounds are one
+    // launch (lm_rounds_reg_kernel) — 256x32: 6.6M vs 2.4M, 512x40: 5.1M vs 1.3M, 128x24: 9.8M vs 2.9M.
+    // BLSQ_SVDFREE_MIN_N overrides the upper edge of the band (0: none), BLSQ_NO_SVDFREE=1 forces the SVD.
     const char* env = getenv("BLSQ_NO_SVDFREE");
     const char* envn = getenv("BLSQ_SVDFREE_MIN_N");
     const int min_n = envn ? atoi(envn) : 48;
     const bool band = p->n > 16 && p->n < min_n;
-    p->lm_enable = ((env && env[0] == '1') || band) ? 0 : 1;
+    p->lm_enable = (env && env[0] == '1') ? 0 : 1;
+    p->lm_gate_mask = p->lm_enable ? (band ? 2 : 3) : 0;
   }
   p->aug_RP = std::max(aug_rows(p->n), ld);
   if (aug_rows(p->n) > RMAX) return ctx->bad(4, "n too large for the augmented system (n <= 512)");
@@ -791,7 +794,7 @@ int trf_finish(blsq_trf_plan* p) {
   if (!p->gate_done) {
     p->lm.jac_count = nullptr;
     ctx->begin(K_LM_GATE);
-    e = launch_lm_gate(p->lm, p->lm_enable, ctx->stream);
+    e = launch_lm_gate(p->lm, p->lm_gate_mask, ctx->stream);
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_lm_gate");
     p->njac = -1;
@@ -858,7 +861,7 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, 
   p->lm.colinfo = p->aug_colinfo.as<double>();
   p->lm.jac_count = t.fb_count() + 1;
   ctx->begin(K_LM_GATE);
-  e = launch_lm_gate(p->lm, p->lm_enable, ctx->stream);
+  e = launch_lm_gate(p->lm, p->lm_gate_mask, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_lm_gate");
   if (defer) {                              // the counters travel; the verdict is read by trf_resolve

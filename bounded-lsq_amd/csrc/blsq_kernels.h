@@ -213,7 +213,7 @@ enum { ST_IT = 0, ST_PHASE, ST_NITER };
 // of the batch (c.rinv / c.dsc = what the augmented Cholesky left)
 hipError_t launch_lm_rounds_reg(const GramCholArgs& c, const LmState& lm, const double* Delta,
                                 const double* alpha_in, hipStream_t s);
-hipError_t launch_lm_gate(const LmState& lm, int enable, hipStream_t s);
+hipError_t launch_lm_gate(const LmState& lm, int enable, hipStream_t s);   // enable: bit 0 Householder-path, bit 1 normal-equations-path problems
 hipError_t launch_lm_start(const LmState& lm, const double* Delta, const double* alpha_in,
                            hipStream_t s);
 hipError_t launch_lm_update(const LmState& lm, int active, hipStream_t s);   // grid = (upper bound of the) active problems of lm.round

@@ -56,7 +56,10 @@ __global__ __launch_bounds__(TRI_NT) void lm_gate_kernel(LmState lm, int enable)
   double* u = v + ld;
   double* invd = u + ld;
   double* pfbuf = invd + ld;                 // 2 x 16 x ld doubles: DMA staging of the solves
-  int ok = (enable != 0) && (lm.m >= n);
+  // enable: bit 0 for Householder-path problems, bit 1 for normal-equations-path problems (which have no
+  // n-band where the SVD is preferred: their Newton rounds are one launch)
+  const bool on_gram = lm.path && lm.path[b] == 0;
+  int ok = (((enable >> (on_gram ? 1 : 0)) & 1) != 0) && (lm.m >= n);
   // Gram-path problems (chol_kernels.hip): R_aug = R'_aug diag(sqrt h_jj) with sigma_min(R'_aug) >=
   // sigma_min(R') >= GRAM_SMIN_PROVEN (the conditioning certificate), so  s_min >= that x min_j sqrt(h_jj)  and  s_max <= sqrt(sum_j h_jj)
   // (the exact Frobenius norm).  When that already clears the threshold below, the iteration is
