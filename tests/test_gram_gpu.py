@@ -446,8 +446,9 @@ def test_newton_rounds_in_one_launch(bl, monkeypatch, n):
     assert np.array_equal(stm[:B], st1) and np.array_equal(am[:B], a1) and np.array_equal(itm[:B], it1)
 
 
+@pytest.mark.parametrize("scale_mode", [0, 1])
 @pytest.mark.parametrize("shape", [(700, 64), (1500, 200)])
-def test_optimistic_verdict_of_the_device_api(bl, monkeypatch, shape):
+def test_optimistic_verdict_of_the_device_api(bl, monkeypatch, shape, scale_mode):
     """blsq_trf_factor_dev does not wait for the gate's counters: it guesses "everybody stays on the
     normal-equations path, nobody needs the SVD", blsq_trf_step_dev enqueues its kernels on that guess
     and only then reads the verdict — a wrong guess runs the fallback stage and the step once more.
@@ -474,13 +475,13 @@ def test_optimistic_verdict_of_the_device_api(bl, monkeypatch, shape):
             dD, dA = ctx.to_device(Delta), ctx.to_device(np.zeros(B))
             ctx.gram_stats(reset=True)
             for _ in range(2):                                          # (a second round on the settled plan)
-                sol.factor_dev(d["J"], d["f"], d["x"], d["lb"], d["ub"], d["scale"])
+                sol.factor_dev(d["J"], d["f"], d["x"], d["lb"], d["ub"], d["scale"], scale_mode)
                 sol.step_dev(dD, dA)
             S = sol.fetch_step()
             stats = ctx.gram_stats()
             assert stats == (2 * (B - expect_fb), 2 * expect_fb), (opt, stats)
             outs.append((S.step.copy(), np.asarray(S.alpha).copy(), np.asarray(S.n_iter).copy(), S.hits.copy(),
-                         sol.fetch_factor().g.copy()))
+                         sol.fetch_factor().g.copy(), ctx.to_host(d["scale"], (B, n), np.float64)))
             sol.close()
             for v in list(d.values()) + [dD, dA]:
                 ctx.free(v)
