@@ -493,6 +493,13 @@ struct blsq_dogbox_plan {
   int svdfree_enable = 1;
   DogState st{};
   DogStepOut out{};
+  // optimistic verdict of blsq_dogbox_factor_dev (as blsq_trf_plan)
+  bool optimistic = true, guess_ok = true, pending = false;
+  int* pend_pin = nullptr;
+  hipEvent_t pend_ev = nullptr;
+  const double* pend_dJ = nullptr; const double* pend_df = nullptr;
+  int pend_ldJ = 0, pend_scale_mode = 0;
+  double* pend_scale_io = nullptr;
 };
 
 // ============================================================ ctx / misc ===
@@ -1623,10 +1630,11 @@ int dog_after_triangle(blsq_dogbox_plan* p, int scale_mode) {
 // — the system lstsq(J_free, -f) is solved from (dogbox.py:197).  No triangle of J is formed; a problem
 // the gate rejects goes through the Householder tree and is prepared again from its triangle.
 int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int ldJ, int scale_mode,
-                    const int* mask) {
+                    const int* mask, bool may_defer = false) {
   blsq_ctx* ctx = p->ctx;
   QrTree& t = p->tree;
   int rc;
+  p->pending = false;
   if (!t.gram) {
     if ((rc = t.run_levels(ctx, dJ, df, ldJ, mask))) return rc;
     return dog_after_triangle(p, scale_mode);
@@ -1664,12 +1672,25 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_dog_gate_solve");
   }
-  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 1, t.fb_count(), 2 * sizeof(int), hipMemcpyDeviceToHost,
-                             ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  const int nfb = ctx->pinned[1];
-  p->gate_done = (nfb == 0);
-  p->njac = p->gate_done ? ctx->pinned[2] : -1;
+  const bool defer = may_defer && p->optimistic && p->guess_ok && p->svdfree_enable && !mask && p->pend_pin &&
+                     p->pend_ev;
+  int nfb = 0;
+  if (defer) {                              // guess: nobody leaves the path, nobody needs the SVD (dog_resolve checks)
+    HIPCHK(ctx, hipMemcpyAsync(p->pend_pin, t.fb_count(), 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(p->pend_ev, ctx->stream));
+    p->pending = true;
+    p->pend_dJ = dJ; p->pend_df = df; p->pend_ldJ = ldJ; p->pend_scale_mode = scale_mode;
+    p->gate_done = true;
+    p->njac = 0;
+  } else {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 1, t.fb_count(), 2 * sizeof(int), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    nfb = ctx->pinned[1];
+    p->gate_done = (nfb == 0);
+    p->njac = p->gate_done ? ctx->pinned[2] : -1;
+    if (!mask) p->guess_ok = (nfb == 0 && p->njac == 0);
+  }
   t.note_paths(ctx, nfb, mask != nullptr);
   if (nfb > 0) {
     if ((rc = t.run_levels(ctx, dJ, df, ldJ, t.fb_mask(), t.fb_list(), nfb))) return rc;
@@ -1679,6 +1700,37 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
     if (e != hipSuccess) return ctx->fail(e, "launch_dog_prep(redo)");
   }
   return dog_finish(p, t.path_rw(), t.any_qr, t.any_gram);
+}
+
+// the verdict of an optimistic dogbox factor call (as trf_resolve)
+int dog_resolve(blsq_dogbox_plan* p, bool* redo) {
+  if (redo) *redo = false;
+  if (!p->pending) return 0;
+  blsq_ctx* ctx = p->ctx;
+  QrTree& t = p->tree;
+  p->pending = false;
+  HIPCHK(ctx, hipEventSynchronize(p->pend_ev));
+  const int nfb = p->pend_pin[0], njac = p->pend_pin[1];
+  if (nfb == 0 && njac == 0) return 0;
+  p->guess_ok = false;
+  if (redo) *redo = true;
+  ctx->gram_fast -= nfb; ctx->gram_fallback += nfb;
+  t.any_qr = nfb > 0; t.any_gram = nfb < p->B; t.path_valid = true;
+  p->gate_done = (nfb == 0);
+  p->njac = p->gate_done ? njac : -1;
+  int rc;
+  if (nfb > 0) {
+    if ((rc = t.run_levels(ctx, p->pend_dJ, p->pend_df, p->pend_ldJ, t.fb_mask(), t.fb_list(), nfb))) return rc;
+    ctx->begin(K_PREP);
+    hipError_t e = launch_dog_prep(p->st, p->pend_scale_mode, 0, t.fb_mask(), 1, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_dog_prep(redo)");
+  }
+  if ((rc = dog_finish(p, t.path_rw(), t.any_qr, t.any_gram))) return rc;
+  if (p->pend_scale_mode != BLSQ_SCALE_GIVEN && p->pend_scale_io)
+    HIPCHK(ctx, hipMemcpy2DAsync(p->pend_scale_io, sizeof(double) * p->n, p->st.scale, sizeof(double) * p->ld,
+                                 sizeof(double) * p->n, p->B, hipMemcpyDeviceToDevice, ctx->stream));
+  return 0;
 }
 
 }  // namespace
@@ -1696,6 +1748,13 @@ extern "C" int blsq_dogbox_plan_create(blsq_ctx* ctx, int B, int m, int n,
   p->ctx = ctx; p->B = B; p->m = m; p->n = n;
   int rc = p->tree.build(ctx, B, m, n, (size_t)B * round_up(n + 1, 16));
   if (rc == 0) { p->ld = p->tree.NPAD; rc = dog_alloc_state(p); }
+  if (rc == 0) {
+    const char* oe = getenv("BLSQ_OPTIMISTIC");
+    p->optimistic = !(oe && oe[0] == '0');
+    hipError_t e = hipHostMalloc((void**)&p->pend_pin, 2 * sizeof(int), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->pend_ev, hipEventDisableTiming);
+    if (e != hipSuccess) rc = ctx->fail(e, "optimistic-verdict resources");
+  }
   if (rc != 0) { blsq_dogbox_plan_destroy(p); return rc; }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   *out = p;
@@ -1705,6 +1764,8 @@ extern "C" int blsq_dogbox_plan_create(blsq_ctx* ctx, int B, int m, int n,
 extern "C" int blsq_dogbox_plan_destroy(blsq_dogbox_plan* p) {
   if (!p) return -1;
   hipStreamSynchronize(p->ctx->stream);
+  if (p->pend_pin) hipHostFree(p->pend_pin);
+  if (p->pend_ev) hipEventDestroy(p->pend_ev);
   p->tree.release();
   p->S.release(); p->X.release(); p->vecs.release(); p->ivecs.release(); p->scal2.release();
   p->sweeps.release(); p->active.release(); p->onb.release(); p->o_vec.release();
@@ -1729,7 +1790,8 @@ extern "C" int blsq_dogbox_factor_dev(blsq_dogbox_plan* p, const double* dJ, con
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc = dog_put(p, dx, dlb, dub, dscale_io, don_bound, hipMemcpyDeviceToDevice);
   if (rc) return rc;
-  if ((rc = dog_factor_core(p, dJ, df, p->n, scale_mode, nullptr))) return rc;
+  p->pend_scale_io = dscale_io;
+  if ((rc = dog_factor_core(p, dJ, df, p->n, scale_mode, nullptr, true))) return rc;
   if (scale_mode != BLSQ_SCALE_GIVEN) {
     HIPCHK(ctx, hipMemcpy2DAsync(dscale_io, sizeof(double) * p->n, p->st.scale,
                                  sizeof(double) * p->ld, sizeof(double) * p->n, p->B,
@@ -1743,10 +1805,16 @@ extern "C" int blsq_dogbox_step_dev(blsq_dogbox_plan* p, const double* dDelta) {
   blsq_ctx* ctx = p->ctx;
   if (!dDelta) return ctx->bad(2, "Delta is NULL");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  ctx->begin(K_STEP);
-  hipError_t e = launch_dog_step(p->st, dDelta, p->out, ctx->stream);
-  ctx->end();
-  if (e != hipSuccess) return ctx->fail(e, "launch_dog_step");
+  for (int pass = 0; pass < 2; ++pass) {    // (pass 1 only after a wrong optimistic guess)
+    ctx->begin(K_STEP);
+    hipError_t e = launch_dog_step(p->st, dDelta, p->out, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_dog_step");
+    bool redo = false;
+    int rc = dog_resolve(p, &redo);
+    if (rc) return rc;
+    if (!redo) break;
+  }
   return 0;
 }
 
@@ -1757,6 +1825,7 @@ extern "C" int blsq_dogbox_fetch_factor(blsq_dogbox_plan* p, double* g, uint8_t*
   blsq_ctx* ctx = p->ctx;
   const int B = p->B, n = p->n, ld = p->ld;
   int rc;
+  if ((rc = dog_resolve(p, nullptr))) return rc;
   if ((rc = get_vec(ctx, g, n, p->st.g, ld, B))) return rc;
   if ((rc = get_vec(ctx, scale, n, p->st.scale, ld, B))) return rc;
   if ((rc = get_vec(ctx, (unsigned char*)active_set, n, p->st.active, ld, B))) return rc;
@@ -1798,6 +1867,7 @@ extern "C" int blsq_dogbox_debug_cond(blsq_dogbox_plan* p, double* k2) {
   blsq_ctx* ctx = p->ctx;
   if (!k2) return ctx->bad(2, "k2 is NULL");
   if (!p->tree.gram) { for (int b = 0; b < p->B; ++b) k2[b] = 0.0; return 0; }
+  { int rc_ = dog_resolve(p, nullptr); if (rc_) return rc_; }
   HIPCHK(ctx, hipMemcpyAsync(k2, p->tree.gram_k2.p, sizeof(double) * p->B, hipMemcpyDeviceToHost,
                              ctx->stream));
   return blsq_sync(ctx);

@@ -90,7 +90,7 @@ int blsq_trf_step(blsq_trf_plan* plan, const double* Delta /*B*/, double* alpha_
 
 /* device-pointer variants: inputs already resident in HBM, results stay in
  * plan-owned device buffers until fetched.
- * blsq_trf_factor_dev is asynchronous all the way: it does not wait for the per-problem verdict of the
+ * blsq_trf_factor_dev (and blsq_dogbox_factor_dev, with blsq_dogbox_step_dev) is asynchronous all the way: it does not wait for the per-problem verdict of the
  * conditioning certificate (which problems must take the Householder route) but assumes the common one
  * — "none" — and the NEXT call on the plan reads the verdict: blsq_trf_step_dev enqueues its kernels
  * first and, should the guess have been wrong, runs the Householder stage and the step once more

@@ -490,6 +490,39 @@ def test_optimistic_verdict_of_the_device_api(bl, monkeypatch, shape, scale_mode
             assert np.array_equal(x1, x0)
 
 
+def test_optimistic_verdict_of_the_dogbox_device_api(bl, monkeypatch):
+    """blsq_dogbox_factor_dev / blsq_dogbox_step_dev: the same optimistic scheme as TRF — right guess,
+    wrong guess (a problem that fails the certificate) and the synchronous mode give the same bits."""
+    from bounded_lsq import _synth, _abi
+    B, m, n = 6, 700, 64
+    good = _synth.dogbox_batch(500, B, m, n)
+    mixed = {k: v.copy() for k, v in good.items()}
+    mixed["J"][2] = _equicorrelated(1, m, n, 1 - 1e-9, 3)[0]
+    mixed["lb"][2] = -np.inf; mixed["ub"][2] = np.inf; mixed["on_bound"][2] = 0
+    Delta = np.full(B, 0.05)
+    for P, expect_fb in ((good, 0), (mixed, 1)):
+        outs = []
+        for opt in ("1", "0"):
+            monkeypatch.setenv("BLSQ_OPTIMISTIC", opt)
+            ctx = _abi.Context(0)
+            sol = bl.DogboxStepSolver(B, m, n, ctx=ctx)
+            d = {k: ctx.to_device(P[k]) for k in ("J", "f", "x", "lb", "ub", "scale", "on_bound")}
+            dD = ctx.to_device(Delta)
+            ctx.gram_stats(reset=True)
+            for _ in range(2):
+                sol.factor_dev(d["J"], d["f"], d["x"], d["lb"], d["ub"], d["scale"], d["on_bound"])
+                sol.step_dev(dD)
+            S = sol.fetch_step()
+            assert ctx.gram_stats() == (2 * (B - expect_fb), 2 * expect_fb), opt
+            outs.append((S.step.copy(), S.on_bound_new.copy(), S.predicted_reduction.copy()))
+            sol.close()
+            for v in list(d.values()) + [dD]:
+                ctx.free(v)
+            ctx.close()
+        for x1, x0 in zip(*outs):
+            assert np.array_equal(x1, x0)
+
+
 def test_chunk_pairs_summed_in_the_kernel_match_the_reduction_pass(bl, monkeypatch):
     """Two row chunks (2048 < m <= 4096), 16 column tiles and at least 256 problems: one workgroup
     takes both chunks and adds them in the kernel, (0 + P0) + P1 — what the separate reduction pass
