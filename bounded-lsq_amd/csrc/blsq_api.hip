@@ -189,6 +189,7 @@ struct QrTree {
                                     // systems are diagonal modifications of them)
   DevBuf gram_rinv, gram_ywork, gram_k2;   // conditioning certificate: inverse diagonal tiles, Y = R'^-T, bound [B]
   DevBuf gram_cert;                        // [B] ints: 1 = proven inside the factor kernel (N <= 80)
+  bool fb_zeroed = false;                  // the gate counters were cleared by pack_vecs_kernel of this factor call
   // per-problem path of the CURRENT triangles: gram_path()[b] = n + 1 (Householder tree) or 0 (Gram).
   // any_gram / any_qr: whether a problem of either kind can exist (host-side upper bounds)
   bool any_gram = false, any_qr = true;
@@ -838,7 +839,8 @@ int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode) {
 int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, bool defer = false) {
   blsq_ctx* ctx = p->ctx;
   QrTree& t = p->tree;
-  HIPCHK(ctx, hipMemsetAsync(t.fb_count(), 0, 2 * sizeof(int), ctx->stream));
+  if (!t.fb_zeroed) HIPCHK(ctx, hipMemsetAsync(t.fb_count(), 0, 2 * sizeof(int), ctx->stream));
+  t.fb_zeroed = false;
   p->st.Rt = t.Rfinal(); p->st.Gk = t.gram_keep.as<double>(); p->st.path = t.path_rw();
   ctx->begin(K_PREP);
   hipError_t e = launch_trf_prep(p->st, scale_mode, 1, mask, 0, ctx->stream);
@@ -1128,13 +1130,16 @@ extern "C" int blsq_trf_plan_destroy(blsq_trf_plan* p) {
 }
 
 static int trf_put_bounds(blsq_trf_plan* p, const double* x, const double* lb, const double* ub,
-                          const double* scale, hipMemcpyKind kind) {
+                          const double* scale, hipMemcpyKind kind, bool zero_counts = false) {
   blsq_ctx* ctx = p->ctx;
   int rc;
   if (kind == hipMemcpyDeviceToDevice) {                // one launch instead of four strided copies
-    PackVecs pv{{x, lb, ub, scale, nullptr}, {p->st.x, p->st.lb, p->st.ub, p->st.scale, nullptr}};
+    // (the two gate counters of the factor call that follows are cleared by the same launch)
+    PackVecs pv{{x, lb, ub, scale, nullptr}, {p->st.x, p->st.lb, p->st.ub, p->st.scale, nullptr},
+                (zero_counts && p->tree.gram) ? p->tree.fb_count() : nullptr, 2};
     hipError_t e = launch_pack_vecs(pv, p->n, p->ld, p->B, ctx->stream);
     if (e != hipSuccess) return ctx->fail(e, "launch_pack_vecs");
+    p->tree.fb_zeroed = zero_counts && p->tree.gram;
     return 0;
   }
   if ((rc = put_vec(ctx, p->st.x, p->ld, x, p->n, p->B, kind))) return rc;
@@ -1155,7 +1160,7 @@ extern "C" int blsq_trf_factor_dev(blsq_trf_plan* p, const double* dJ, const dou
   if (!dscale_io) return ctx->bad(7, "scale is NULL");
   if (scale_mode < 0 || scale_mode > 2) return ctx->bad(8, "scale_mode");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  int rc = trf_put_bounds(p, dx, dlb, dub, dscale_io, hipMemcpyDeviceToDevice);
+  int rc = trf_put_bounds(p, dx, dlb, dub, dscale_io, hipMemcpyDeviceToDevice, true);
   if (rc) return rc;
   p->pend_scale_io = dscale_io;
   if ((rc = trf_factor_core(p, dJ, df, p->n, scale_mode, nullptr, true))) return rc;
@@ -1547,13 +1552,15 @@ int dog_alloc_state(blsq_dogbox_plan* p) {
 }
 
 int dog_put(blsq_dogbox_plan* p, const double* x, const double* lb, const double* ub,
-            const double* scale, const int64_t* on_bound, hipMemcpyKind kind) {
+            const double* scale, const int64_t* on_bound, hipMemcpyKind kind, bool zero_counts = false) {
   blsq_ctx* ctx = p->ctx;
   int rc;
   if (kind == hipMemcpyDeviceToDevice) {
-    PackVecs pv{{x, lb, ub, scale, on_bound}, {p->st.x, p->st.lb, p->st.ub, p->st.scale, p->st.on_bound}};
+    PackVecs pv{{x, lb, ub, scale, on_bound}, {p->st.x, p->st.lb, p->st.ub, p->st.scale, p->st.on_bound},
+                (zero_counts && p->tree.gram) ? p->tree.fb_count() : nullptr, 2};
     hipError_t e = launch_pack_vecs(pv, p->n, p->ld, p->B, ctx->stream);
     if (e != hipSuccess) return ctx->fail(e, "launch_pack_vecs");
+    p->tree.fb_zeroed = zero_counts && p->tree.gram;
     return 0;
   }
   if ((rc = put_vec(ctx, p->st.x, p->ld, x, p->n, p->B, kind))) return rc;
@@ -1640,7 +1647,8 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
     return dog_after_triangle(p, scale_mode);
   }
   if ((rc = t.run_gram_only(ctx, dJ, df, ldJ, mask, false))) return rc;
-  HIPCHK(ctx, hipMemsetAsync(t.fb_count(), 0, 2 * sizeof(int), ctx->stream));
+  if (!t.fb_zeroed) HIPCHK(ctx, hipMemsetAsync(t.fb_count(), 0, 2 * sizeof(int), ctx->stream));
+  t.fb_zeroed = false;
   p->st.Rt = t.Rfinal(); p->st.Gk = t.gram_keep.as<double>(); p->st.path = t.path_rw();
   ctx->begin(K_PREP);
   hipError_t e = launch_dog_prep(p->st, scale_mode, 1, mask, 0, ctx->stream);
@@ -1788,7 +1796,7 @@ extern "C" int blsq_dogbox_factor_dev(blsq_dogbox_plan* p, const double* dJ, con
   if (scale_mode < 0 || scale_mode > 2) return ctx->bad(8, "scale_mode");
   if (!don_bound) return ctx->bad(9, "on_bound is NULL");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  int rc = dog_put(p, dx, dlb, dub, dscale_io, don_bound, hipMemcpyDeviceToDevice);
+  int rc = dog_put(p, dx, dlb, dub, dscale_io, don_bound, hipMemcpyDeviceToDevice, true);
   if (rc) return rc;
   p->pend_scale_io = dscale_io;
   if ((rc = dog_factor_core(p, dJ, df, p->n, scale_mode, nullptr, true))) return rc;

@@ -156,7 +156,7 @@ struct TrfState {         // all device pointers, batch-major, vector stride ld
 // problems with sel[b] > 1 are processed.  redo: the problem was prepared from its Gram already in
 // this factor call (its gate failed since): start again from scale_in.
 // up to five caller vectors [B][n] (8-byte elements; nullptr: skipped) -> the [B][ld] state layout, one launch
-struct PackVecs { const void* src[5]; void* dst[5]; };
+struct PackVecs { const void* src[5]; void* dst[5]; int* zero; int nzero; };   // zero[0 .. nzero): counters cleared on the way
 hipError_t launch_pack_vecs(const PackVecs& pv, int n, int ld, int B, hipStream_t s);
 hipError_t launch_trf_prep(const TrfState& st, int jac_scaling, int from_gram, const int* sel,
                            int redo, hipStream_t s);

@@ -557,6 +557,7 @@ hipError_t launch_trf_step(const TrfState& st, const LmState* lm, const double* 
 __global__ void pack_vecs_kernel(PackVecs pv, int n, int ld, int B) {
   const long total = (long)B * n;
   const int v = blockIdx.y;
+  if (blockIdx.x == 0 && v == 0 && pv.zero && (int)threadIdx.x < pv.nzero) pv.zero[threadIdx.x] = 0;
   const unsigned long long* src = (const unsigned long long*)pv.src[v];
   unsigned long long* dst = (unsigned long long*)pv.dst[v];
   if (!src || !dst) return;
