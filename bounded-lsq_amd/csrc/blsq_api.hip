@@ -489,7 +489,7 @@ struct blsq_dogbox_plan {
   DevBuf in_J, in_f, in_vec, in_scal;
   bool gate_done = false;           // as blsq_trf_plan
   int njac = -1;
-  DevBuf gate_ints;                 // [2B] fast flags, Jacobi launch mask
+  DevBuf gate_ints;                 // [3B] fast flags, Jacobi launch mask, finished-in-the-Cholesky-kernel flags
   DevBuf colinfo;                   // [B][2] column-norm summary of the free block (Gram-path problems)
   int svdfree_enable = 1;
   DogState st{};
@@ -1523,7 +1523,7 @@ int dog_alloc_state(blsq_dogbox_plan* p) {
   ALLOC(p->o_scal, sizeof(double) * (size_t)B * 4);
   ALLOC(p->o_info, sizeof(int) * (size_t)B * 4);
   ALLOC(p->in_scal, sizeof(double) * (size_t)B);
-  ALLOC(p->gate_ints, sizeof(int) * 2 * (size_t)B);
+  ALLOC(p->gate_ints, sizeof(int) * 3 * (size_t)B);
   ALLOC(p->colinfo, sizeof(double) * 2 * (size_t)B);
   {
     const char* env = getenv("BLSQ_NO_SVDFREE");
@@ -1595,7 +1595,7 @@ int dog_finish(blsq_dogbox_plan* p, const int* path, bool any_qr, bool any_gram)
   if (!p->gate_done) {
     ctx->begin(K_LM_GATE);
     e = launch_dog_gate_solve(p->st, gfast, gmask, p->svdfree_enable, path,
-                              (path && any_gram) ? p->colinfo.as<double>() : nullptr, nullptr, ctx->stream);
+                              (path && any_gram) ? p->colinfo.as<double>() : nullptr, nullptr, nullptr, ctx->stream);
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_dog_gate_solve");
     p->njac = -1;
@@ -1663,6 +1663,14 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
   c.rinv = t.gram_rinv.as<double>(); c.ywork = t.gram_ywork.as<double>(); c.k2_out = t.gram_k2.as<double>();
   c.cert_done = t.gram_cert.as<int>();
   c.colinfo = p->colinfo.as<double>();
+  int* gdone = p->gate_ints.as<int>() + 2 * (size_t)p->B;
+  const bool fin = p->ld <= 80;             // (the register-resident kernel also finishes the gate / Newton / Cauchy work)
+  if (fin) {
+    int* gf_ = p->gate_ints.as<int>();
+    c.dog.g = p->st.g; c.dog.newton = p->st.newton; c.dog.cauchy = p->st.cauchy;
+    c.dog.fast = gf_; c.dog.ncols_jac = gf_ + p->B; c.dog.done = gdone;
+    c.dog.m = p->m; c.dog.enable = p->svdfree_enable;
+  }
   ctx->begin(K_AUG_CHOL);
   e = launch_gram_chol(c, p->B, ctx->stream);
   ctx->end();
@@ -1676,7 +1684,7 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
     p->st.fast = gfast;
     ctx->begin(K_LM_GATE);
     e = launch_dog_gate_solve(p->st, gfast, gfast + p->B, p->svdfree_enable, t.path_rw(),
-                              p->colinfo.as<double>(), t.fb_count() + 1, ctx->stream);
+                              p->colinfo.as<double>(), t.fb_count() + 1, fin ? gdone : nullptr, ctx->stream);
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_dog_gate_solve");
   }

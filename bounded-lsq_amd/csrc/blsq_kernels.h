@@ -97,6 +97,18 @@ struct GramCholArgs {
   double* k2_out;         // optional [B] out: the proven bound on kappa_2 of the equilibrated system
   int* cert_done;         // optional [B]: 1 = the factor kernel itself proved K2 <= GRAM_K2_MAX (N <= 80: the
                           // register-resident kernel has R' at hand); launch_gram_gate then skips the problem
+  // dogbox, N <= 80 (optional; g == nullptr: off): the register-resident kernel also does what
+  // dog_gate_solve_kernel does for a problem whose rank the column-norm bound already settles — Cauchy
+  // step, Newton step -R_f^-1 c_f, fast flag — and sets done[b]; dog_gate_solve skips those
+  struct DogFinish {
+    const double* g;      // [B][stride_vec] gradient (full length; gathered through `gather`)
+    double* newton;       // [B][stride_vec] out (free order)
+    double* cauchy;       // [B][stride_vec] out (free order)
+    int* fast;            // [B] out
+    int* ncols_jac;       // [B] out
+    int* done;            // [B] out: 1 = finished here
+    int m, enable;
+  } dog;
 };
 // A problem stays on the normal-equations path only if the PROVEN bound K2 >= kappa_2(R'^T R') of its
 // equilibrated system is at most GRAM_K2_MAX (chol_kernels.hip, gram_cond_kernel).  Consequence used
@@ -203,6 +215,9 @@ struct LmState {
                           // and the round kernels leave them alone (a problem's arithmetic must not depend
                           // on whether its batch also holds Householder-path problems)
 };
+// rank gate of the SVD-free paths (lm_kernels.hip; the dogbox finish in chol_kernels.hip)
+static constexpr double LM_EPS = 2.220446049250313e-16;
+static constexpr double LM_GATE_MARGIN = 1.0e3;
 // slots of LmState.sc / LmState.st, phases of the iteration (lm_kernels.hip; the fused rounds in chol_kernels.hip)
 enum { LM_IDLE = 0, LM_EVAL = 1, LM_FINAL = 2 };
 enum { SC_ALPHA = 0, SC_LO, SC_HI, SC_PHI, SC_DPHI, SC_DELTA, SC_SMAX, SC_SMIN };
@@ -246,8 +261,10 @@ hipError_t launch_dog_prep(const DogState& st, int jac_scaling, int from_gram, c
                            int redo, hipStream_t s);
 hipError_t launch_dog_solve(const DogState& st, const int* skip, hipStream_t s);
 // path / colinfo (optional): Gram-path flags and the column-norm summary of the free block
+// done (optional [B]): problems the Cholesky kernel already finished (GramCholArgs::dog) are skipped
 hipError_t launch_dog_gate_solve(const DogState& st, int* fast, int* ncols_jac, int enable,
-                                 const int* path, const double* colinfo, int* jac_count, hipStream_t s);
+                                 const int* path, const double* colinfo, int* jac_count,
+                                 const int* done, hipStream_t s);
 
 struct DogStepOut {
   double* step;           // [B][ld]  full length

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
   const int lane = threadIdx.x & 63, tid = lane;
   const int lr = lane >> 4, lc = lane & 15;
   const int NPAD = a.NPAD;
-  double* sh = sh_all + (size_t)wv * (4 * (size_t)NPAD + 256 + MT * 256 + 64);
+  double* sh = sh_all + (size_t)wv * (8 * (size_t)NPAD + 256 + MT * 256 + 64 + 16);
   auto wsync = []() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); };
   if (a.mask && a.mask[b] <= 1) {
     if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
@@ -255,6 +255,11 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
   double* Ria = Dt + 256;          // [MT][256] the inverses of the diagonal tiles (kept: certificate below)
   double* td = Ria + MT * 256;     // [NPAD] (e_j^2 + alpha) * dl_j^2
   double* xs = td + NPAD;          // [64]   four-row sums
+  double* cv = xs + 64;            // [NPAD] c' = R'[:, n]            (dogbox finish below)
+  double* yv = cv + NPAD;          // [NPAD] R'^-1 c'
+  double* vv = yv + NPAD;          // [NPAD] g of the free variables
+  double* wq = vv + NPAD;          // [NPAD] sq . g
+  double* tv = wq + NPAD;          // [16]
   const double* csv = a.colscale ? a.colscale + (long)b * a.stride_vec : nullptr;
   const double* edv = a.diag_vec ? a.diag_vec + (long)b * a.stride_vec : nullptr;
   const double sa = a.diag_sqrt ? a.diag_sqrt[b] : 0.0;
@@ -285,6 +290,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
     double mn = __builtin_inf(), sm = 0.0;
     for (int j = 0; j < n; ++j) { const double v = sq[j]; mn = v < mn ? v : mn; sm = fma(v, v, sm); }
     a.colinfo[2 * (long)b] = mn; a.colinfo[2 * (long)b + 1] = sm;
+    tv[0] = mn; tv[1] = sm;                             // (kept for the dogbox finish)
   }
   bad = __any(bad);
   // 1. the scaled source tiles -> accumulators (the source may alias the output: every read comes
@@ -348,6 +354,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
       // 2. chain of the diagonal tile: R'_kk -> Dt, its inverse -> Ri
       double* Ri = Ria + kb * 256;
       pmin = chol16_blocked3(acc[tix(kb, kb)], Dt, Ri, n - 16 * kb, pmin);
+      if (kb == (n >> 4) && lane < 16) cv[16 * kb + lane] = Dt[lane * 16 + (n & 15)];   // rhs column through the diagonal tile
       if (a.rinv) {                                     // kept for the conditioning certificate
         double* ro = a.rinv + ((long)b * (NPAD / 16) + kb) * 256;
 #pragma unroll
@@ -366,6 +373,10 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
 #pragma unroll
             for (int s_ = 0; s_ < 4; ++s_) X = gmfma(Ri[(4 * s_ + lr) * 16 + lc], acc[tix(kb, j)][s_], X);
             acc[tix(kb, j)] = X;
+            if (j == (n >> 4) && lc == (n & 15)) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) cv[16 * kb + lr + 4 * g] = X[g];
+            }
           }
           const double sj = sq[16 * j + lc];
 #pragma unroll
@@ -500,6 +511,91 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
     if (tid == 0) {
       a.cert_done[b] = passed ? 1 : 0;
       if (passed && a.k2_out) a.k2_out[b] = k2;
+    }
+  }
+  // 6. dogbox finish (GramCholArgs::dog): what dog_gate_solve_kernel computes for a problem on this path —
+  //    Cauchy step -(g.g)/(J_f g . J_f g) g_f with |J_f g_f| = |R g_f|, and, when the column-norm bound
+  //    already proves the free block full rank (the `sure` case there), the Newton step -R_f^-1 c_f —
+  //    from the register tiles:  R = R' diag(sq),  c = c' sq_n.
+  if (a.dog.g) {
+    bool finished = false;
+    if (!fail && a.colinfo) {
+      const int NTn = (n + 15) / 16;
+      const double mn = tv[0], sm = tv[1];
+      wsync();
+      const double* gb = a.dog.g + (long)b * a.stride_vec;
+      double gg = 0.0;
+      for (int q = lane; q < NPAD; q += WAVE) {
+        const double gq = (q < n) ? gb[gidx ? gidx[q] : q] : 0.0;
+        vv[q] = gq; wq[q] = gq * sq[q]; yv[q] = 0.0;
+        gg = fma(gq, gq, gg);
+      }
+      gg = wave_sum(gg);
+      wsync();
+      double uu = 0.0;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if (i < NTn) {
+          double part[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int jj = i; jj < MT; ++jj) {
+            if (jj < NTn) {
+              const double wj = wq[16 * jj + lc];
+#pragma unroll
+              for (int g = 0; g < 4; ++g) part[g] = fma(acc[tix(i, jj)][g], wj, part[g]);
+            }
+          }
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const double u = row16_sum(part[g]);
+            if (lc == 0 && 16 * i + lr + 4 * g < n) uu = fma(u, u, uu);
+          }
+        }
+      }
+      uu = wave_sum(uu);
+      const double fac = -gg / uu;
+      for (int q = lane; q < n; q += WAVE) a.dog.cauchy[(long)b * a.stride_vec + q] = fac * vv[q];
+      const int mx = a.dog.m > n ? a.dog.m : n;
+      const bool sure = is_finite(sm) && sm > 0.0 && (GRAM_SMIN_PROVEN * mn > LM_GATE_MARGIN * LM_EPS * mx * sqrt(sm));
+      if (a.dog.enable != 0 && a.dog.m >= n && sure) {
+        // y = R'^-1 c' (block rows from the bottom), newton = -sq_n dl . y
+#pragma unroll
+        for (int kk = MT - 1; kk >= 0; --kk) {
+          if (kk < NTn) {
+            double part[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int jj = kk + 1; jj < MT; ++jj) {
+              if (jj < NTn) {
+                const double yj = yv[16 * jj + lc];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) part[g] = fma(acc[tix(kk, jj)][g], yj, part[g]);
+              }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) part[g] = row16_sum(part[g]);
+            if (lc == 0) {
+#pragma unroll
+              for (int g = 0; g < 4; ++g) tv[lr + 4 * g] = cv[16 * kk + lr + 4 * g] - part[g];
+            }
+            wsync();
+            const int nb = (n - 16 * kk < 16) ? n - 16 * kk : 16;
+            const double* Rk = Ria + kk * 256;
+            double yi = 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) yi = fma(Rk[lc * 16 + c], (c < nb) ? tv[c] : 0.0, yi);
+            if (lc >= nb) yi = 0.0;
+            if (lr == 0) yv[16 * kk + lc] = yi;
+            wsync();
+          }
+        }
+        const double sqn = sq[n];
+        for (int q = lane; q < n; q += WAVE) a.dog.newton[(long)b * a.stride_vec + q] = -(sqn * dl[q] * yv[q]);
+        finished = true;
+      }
+    }
+    if (tid == 0) {
+      a.dog.done[b] = finished ? 1 : 0;
+      if (finished) { a.dog.fast[b] = 1; a.dog.ncols_jac[b] = 0; }
     }
   }
 }
@@ -1334,7 +1430,7 @@ hipError_t launch_gram_chol(const GramCholArgs& a_in, int B, hipStream_t s) {
       hipLaunchKernelGGL(gram_chol_kernel<1>, dim3((B + GR_NW - 1) / GR_NW), dim3(GR_NT), per * GR_NW,
                          s, a);
     else {
-      const size_t per_reg = sizeof(double) * (4 * (size_t)a.NPAD + 256 + 5 * 256 + 64);
+      const size_t per_reg = sizeof(double) * (8 * (size_t)a.NPAD + 256 + 5 * 256 + 64 + 16);
       static std::atomic<size_t> granted[64];
       hipError_t ge = gram_grant_lds(gram_chol_reg_kernel, per_reg * REG_NW, granted);
       if (ge != hipSuccess) return ge;

@@ -40,8 +40,7 @@ static hipError_t grant_lds(K kernel, size_t bytes, std::atomic<size_t>* granted
   return e;
 }
 
-static constexpr double LM_EPS = 2.220446049250313e-16;
-static constexpr double LM_GATE_MARGIN = 1.0e3;
+// (LM_EPS, LM_GATE_MARGIN: blsq_kernels.h)
 
 // (phases and the sc[] / st[] slots: blsq_kernels.h)
 
@@ -315,10 +314,12 @@ hipError_t launch_lm_update(const LmState& lm, int active, hipStream_t s) {
 __global__ __launch_bounds__(TRI_NT) void dog_gate_solve_kernel(DogState st, int* fast,
                                                                 int* ncols_jac, int enable,
                                                                 const int* path,
-                                                                const double* colinfo, int* jac_count) {
+                                                                const double* colinfo, int* jac_count,
+                                                                const int* done) {
   extern __shared__ double sh[];
   __shared__ double red[32];
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (done && done[b]) return;                            // (finished inside the Cholesky kernel)
   const int ld = st.ld;
   const int N = st.ncols[b];
   const int nf = N - 1;
@@ -403,11 +404,12 @@ __global__ __launch_bounds__(TRI_NT) void dog_gate_solve_kernel(DogState st, int
 }
 
 hipError_t launch_dog_gate_solve(const DogState& st, int* fast, int* ncols_jac, int enable,
-                                 const int* path, const double* colinfo, int* jac_count, hipStream_t s) {
+                                 const int* path, const double* colinfo, int* jac_count,
+                                 const int* done, hipStream_t s) {
   const size_t lds = sizeof(double) * (3 + 32) * (size_t)st.ld;
   { static std::atomic<size_t> granted[64]; hipError_t ge = grant_lds(dog_gate_solve_kernel, lds, granted); if (ge != hipSuccess) return ge; }
   hipLaunchKernelGGL(dog_gate_solve_kernel, dim3(st.B), dim3(TRI_NT), lds, s, st, fast,
-                     ncols_jac, enable, path, colinfo, jac_count);
+                     ncols_jac, enable, path, colinfo, jac_count, done);
   return hipGetLastError();
 }
 
