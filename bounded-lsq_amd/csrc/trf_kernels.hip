@@ -191,6 +191,84 @@ __device__ void full_matvec(const double* M, int n, int ld, const double* svec, 
   __syncthreads();
 }
 
+// Three products with ONE pass over the matrix (the reflective branch needs J_h p_h, J_h r_h and
+// J_h (-g_h); the matrix — half a megabyte per problem at n = 256 — does not stay in any cache
+// between separate passes):  u1 = M s1,  u2 = M s2 (s2 == nullptr: skipped),  u3 = M (-g3).
+// Per row and product exactly the operations of tri_matvec / full_matvec, in the same order.
+__device__ void tri_matvec3(const double* R, const double* dvec, int n, int ld, const double* s1,
+                            double* u1, const double* s2, double* u2, const double* g3, double* u3) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int RB = 8;
+  for (int i0 = w; i0 < n; i0 += NS_NW * RB) {
+    double a1[RB], a2[RB], a3[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) { a1[r] = 0.0; a2[r] = 0.0; a3[r] = 0.0; }
+    for (int jj = 0; i0 + lane + jj < n; jj += WAVE) {
+      double rv[RB];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int i = i0 + r * NS_NW;
+        const int ic = (i < n) ? i : n - 1;
+        const int j = ic + lane + jj;
+        rv[r] = R[(long)ic * ld + ((j < n) ? j : n - 1)];
+      }
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int i = i0 + r * NS_NW;
+        const int j = i + lane + jj;
+        if (i < n && j < n) {
+          const double rd = dvec ? rv[r] * dvec[j] : rv[r];
+          a1[r] = fma(rd, s1[j], a1[r]);
+          if (s2) a2[r] = fma(rd, s2[j], a2[r]);
+          a3[r] = fma(rd, -g3[j], a3[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int i = i0 + r * NS_NW;
+      const double t1 = wave_sum(a1[r]);
+      const double t2 = s2 ? wave_sum(a2[r]) : 0.0;
+      const double t3 = wave_sum(a3[r]);
+      if (lane == 0 && i < n) { u1[i] = t1; if (s2) u2[i] = t2; u3[i] = t3; }
+    }
+  }
+  __syncthreads();
+}
+__device__ void full_matvec3(const double* M, int n, int ld, const double* s1, double* u1,
+                             const double* s2, double* u2, const double* g3, double* u3) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int RB = 4;
+  for (int i0 = w; i0 < n; i0 += NS_NW * RB) {
+    double a1[RB], a2[RB], a3[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) { a1[r] = 0.0; a2[r] = 0.0; a3[r] = 0.0; }
+    for (int jj = lane; jj < n; jj += WAVE) {
+      double rv[RB];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int i = i0 + r * NS_NW;
+        rv[r] = M[(long)((i < n) ? i : n - 1) * ld + jj];
+      }
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        a1[r] = fma(rv[r], s1[jj], a1[r]);
+        if (s2) a2[r] = fma(rv[r], s2[jj], a2[r]);
+        a3[r] = fma(rv[r], -g3[jj], a3[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const int i = i0 + r * NS_NW;
+      const double t1 = wave_sum(a1[r]);
+      const double t2 = s2 ? wave_sum(a2[r]) : 0.0;
+      const double t3 = wave_sum(a3[r]);
+      if (lane == 0 && i < n) { u1[i] = t1; if (s2) u2[i] = t2; u3[i] = t3; }
+    }
+  }
+  __syncthreads();
+}
+
 __device__ double dot_dev(const double* a, const double* b, int n, double* red) {
   double acc = 0.0;
   for (int j = threadIdx.x; j < n; j += NS_NT) acc += a[j] * b[j];
@@ -218,6 +296,11 @@ __device__ double quad_min_dev(double a, double b, double lo, double hi) {
   return tbest;
 }
 
+// MV3: the three model products of the reflective branch in one pass over the matrix (n >= 128, where
+// the matrix streams from HBM: 0.118 -> 0.106 ms at 4096 x 256 x 512; for small n the extra
+// accumulators cost occupancy — 0.042 -> 0.060 ms at 512 x 64 x 1024 — so those keep three passes).
+// Same results bit for bit.
+template <bool MV3>
 __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int* lm_fast,
                                                          const double* lm_ph, const double* lm_sc,
                                                          const int* lm_st, const double* Delta_in,
@@ -267,6 +350,13 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     if (!gp) tri_matvec(Rh, dg, n, ld, svec, u);
     else if (fast) tri_matvec(X, nullptr, n, ld, svec, u);
     else full_matvec(X, n, ld, svec, u);
+  };
+  // u1 = J_h s1, u2 = J_h s2 (s2 may be null), u3 = J_h (-g3) in one pass over the matrix
+  auto model_mv3 = [&](const double* s1, double* u1, const double* s2, double* u2, const double* g3,
+                       double* u3) {
+    if (!gp) tri_matvec3(Rh, dg, n, ld, s1, u1, s2, u2, g3, u3);
+    else if (fast) tri_matvec3(X, nullptr, n, ld, s1, u1, s2, u2, g3, u3);
+    else full_matvec3(X, n, ld, s1, u1, s2, u2, g3, u3);
   };
   if (fast) {
     for (int j = tid; j < n; j += NS_NT) ph[j] = lm_ph[vo + j];
@@ -435,11 +525,17 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     double r_lo;
     if (r_hi > 0.0) r_lo = (1.0 - theta) * p_stride / r_hi;
     else r_lo = -1.0;
-    model_mv(ph, up);                                            // J_h p_h (stride-scaled)
+    // J_h p_h (stride-scaled), J_h r_h (if the reflected step exists) and J_h (-g_h) in one pass
+    const bool need_r = (status == 0 && r_lo <= r_hi);
+    if constexpr (MV3) {
+      model_mv3(ph, up, need_r ? rh : nullptr, ur, gh, ug);
+    } else {
+      model_mv(ph, up);
+      if (need_r) model_mv(rh, ur);
+    }
     bool have_r = false;
     double r_t = 0.0;
-    if (status == 0 && r_lo <= r_hi) {
-      model_mv(rh, ur);
+    if (need_r) {
       const double vv = dot_dev(ur, ur, n, red);
       const double sds = dot3_dev(rh, dh, rh, n, red);
       const double qa = gp ? 0.5 * vv : 0.5 * (vv + sds);
@@ -468,7 +564,7 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     double g_hi = (to_trg < to_bg) ? to_trg : to_bg;
     for (int j = tid; j < n; j += NS_NT) tmp[j] = -gh[j];
     __syncthreads();
-    model_mv(tmp, ug);                                           // J_h (-g_h)
+    if constexpr (!MV3) model_mv(tmp, ug);                       // J_h (-g_h)  (MV3: the pass above)
     const double gvv = dot_dev(ug, ug, n, red);
     const double gsds = dot3_dev(tmp, dh, tmp, n, red);
     const double ga = gp ? 0.5 * gvv : 0.5 * (gvv + gsds);
@@ -547,9 +643,14 @@ hipError_t launch_trf_step(const TrfState& st, const LmState* lm, const double* 
                            const double* alpha_in, double active_rtol, const TrfStepOut& out,
                            hipStream_t s) {
   const size_t lds = sizeof(double) * 8 * (size_t)st.ld;
-  hipLaunchKernelGGL(trf_step_kernel, dim3(st.B), dim3(NS_NT), lds, s, st,
-                     lm ? lm->fast : nullptr, lm ? lm->ph : nullptr, lm ? lm->sc : nullptr,
-                     lm ? lm->st : nullptr, Delta, alpha_in, active_rtol, out);
+  if (st.n >= 128)
+    hipLaunchKernelGGL(trf_step_kernel<true>, dim3(st.B), dim3(NS_NT), lds, s, st,
+                       lm ? lm->fast : nullptr, lm ? lm->ph : nullptr, lm ? lm->sc : nullptr,
+                       lm ? lm->st : nullptr, Delta, alpha_in, active_rtol, out);
+  else
+    hipLaunchKernelGGL(trf_step_kernel<false>, dim3(st.B), dim3(NS_NT), lds, s, st,
+                       lm ? lm->fast : nullptr, lm ? lm->ph : nullptr, lm ? lm->sc : nullptr,
+                       lm ? lm->st : nullptr, Delta, alpha_in, active_rtol, out);
   return hipGetLastError();
 }
 
