@@ -473,7 +473,10 @@ struct blsq_trf_plan {
   bool optimistic = true;           // BLSQ_OPTIMISTIC = 0 switches it off
   bool guess_ok = true;             // the last verdict of this plan was "all fast": only then is the next one guessed
   bool pending = false;
-  int* pend_pin = nullptr;          // 2 pinned ints of this plan
+  // Second guess (N <= 80): every problem is settled inside the Cholesky kernel (certificate + rank gate),
+  // so the certificate and gate launches are not even enqueued; checked with the same read-back.
+  bool guess_settled = false, pend_tail = false;
+  int* pend_pin = nullptr;          // 4 pinned ints of this plan
   hipEvent_t pend_ev = nullptr;
   const double* pend_dJ = nullptr; const double* pend_df = nullptr;
   int pend_ldJ = 0, pend_scale_mode = 0;
@@ -496,6 +499,7 @@ struct blsq_dogbox_plan {
   DogStepOut out{};
   // optimistic verdict of blsq_dogbox_factor_dev (as blsq_trf_plan)
   bool optimistic = true, guess_ok = true, pending = false;
+  bool guess_settled = false, pend_tail = false;   // second guess: every problem settled inside the Cholesky kernel
   int* pend_pin = nullptr;
   hipEvent_t pend_ev = nullptr;
   const double* pend_dJ = nullptr; const double* pend_df = nullptr;
@@ -834,18 +838,8 @@ int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode) {
   return trf_finish(p);
 }
 
-// prep from the Gram, Cholesky of H with the pivot gate, conditioning gate; *nfb = problems of this
-// call that must go to the Householder tree (their indices are flagged in tree.fb_mask()).
-int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, bool defer = false) {
-  blsq_ctx* ctx = p->ctx;
+GramCholArgs trf_chol_args(blsq_trf_plan* p, const int* mask) {
   QrTree& t = p->tree;
-  if (!t.fb_zeroed) HIPCHK(ctx, hipMemsetAsync(t.fb_count(), 0, 2 * sizeof(int), ctx->stream));
-  t.fb_zeroed = false;
-  p->st.Rt = t.Rfinal(); p->st.Gk = t.gram_keep.as<double>(); p->st.path = t.path_rw();
-  ctx->begin(K_PREP);
-  hipError_t e = launch_trf_prep(p->st, scale_mode, 1, mask, 0, ctx->stream);
-  ctx->end();
-  if (e != hipSuccess) return ctx->fail(e, "launch_trf_prep(gram)");
   GramCholArgs c{};
   c.Gsrc = t.gram_keep.as<double>(); c.G = p->st.X; c.NPAD = p->ld; c.n = p->n;
   c.colscale = p->st.d; c.diag_vec = p->st.ediag; c.stride_vec = p->ld;
@@ -855,17 +849,25 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, 
   c.rinv = t.gram_rinv.as<double>(); c.ywork = t.gram_ywork.as<double>(); c.k2_out = t.gram_k2.as<double>();
   c.cert_done = t.gram_cert.as<int>();
   c.colinfo = p->aug_colinfo.as<double>();
-  ctx->begin(K_AUG_CHOL);
-  e = launch_gram_chol(c, p->B, ctx->stream);
-  ctx->end();
-  if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(aug)");
+  if (p->ld <= 80) {                        // (the register-resident kernel also does the rank gate's sure case)
+    c.lmfin.fast = p->lm.fast; c.lmfin.ncols_jac = p->lm.ncols_jac; c.lmfin.sc = p->lm.sc; c.lmfin.st = p->lm.st;
+    c.lmfin.settled = t.fb_count() + 2;
+    c.lmfin.m = p->lm.m; c.lmfin.enable = (p->lm_gate_mask >> 1) & 1;
+  }
+  return c;
+}
+
+// the second half of the certificate + the rank gate of the trust-region solver (counters:
+// fb_count()[0] problems that leave the path, [1] problems for the SVD)
+int trf_gate_tail(blsq_trf_plan* p, const GramCholArgs& c) {
+  blsq_ctx* ctx = p->ctx;
+  QrTree& t = p->tree;
   ctx->begin(K_GRAM_GATE);
-  e = launch_gram_gate(c, p->B, ctx->stream);
+  hipError_t e = launch_gram_gate(c, p->B, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_gram_gate");
-  // The rank gate of the trust-region solver runs BEFORE the verdict is read back: in the common case
-  // (no problem leaves this path) its result stands, and the same read-back tells whether anybody
-  // needs the Jacobi SVD at all.  (The step counters of the memset above: [0] failed, [1] to the SVD.)
+  // The rank gate runs BEFORE the verdict is read back: in the common case (no problem leaves this
+  // path) its result stands, and the same read-back tells whether anybody needs the Jacobi SVD at all.
   p->lm.path = t.path_rw();
   p->lm.colinfo = p->aug_colinfo.as<double>();
   p->lm.jac_count = t.fb_count() + 1;
@@ -873,21 +875,51 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, 
   e = launch_lm_gate(p->lm, p->lm_gate_mask, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_lm_gate");
+  return 0;
+}
+
+// prep from the Gram, Cholesky of H with the pivot gate, conditioning gate; *nfb = problems of this
+// call that must go to the Householder tree (their indices are flagged in tree.fb_mask()).
+int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, bool defer = false) {
+  blsq_ctx* ctx = p->ctx;
+  QrTree& t = p->tree;
+  if (!t.fb_zeroed) HIPCHK(ctx, hipMemsetAsync(t.fb_count(), 0, 3 * sizeof(int), ctx->stream));
+  t.fb_zeroed = false;
+  p->st.Rt = t.Rfinal(); p->st.Gk = t.gram_keep.as<double>(); p->st.path = t.path_rw();
+  ctx->begin(K_PREP);
+  hipError_t e = launch_trf_prep(p->st, scale_mode, 1, mask, 0, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_trf_prep(gram)");
+  const GramCholArgs c = trf_chol_args(p, mask);
+  ctx->begin(K_AUG_CHOL);
+  e = launch_gram_chol(c, p->B, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(aug)");
+  // second guess (N <= 80): the Cholesky kernel settles EVERY problem itself — certificate by its first
+  // bound, rank gate by the column-norm bound — as it did in the last call: then the certificate and gate
+  // launches would both be empty and are not enqueued (trf_resolve checks the settled counter)
+  const bool skip_tail = defer && p->guess_settled && c.lmfin.fast != nullptr;
+  int rc;
+  if (skip_tail) {
+    p->lm.path = t.path_rw();
+    p->lm.colinfo = p->aug_colinfo.as<double>();
+  } else if ((rc = trf_gate_tail(p, c))) return rc;
   if (defer) {                              // the counters travel; the verdict is read by trf_resolve
-    HIPCHK(ctx, hipMemcpyAsync(p->pend_pin, t.fb_count(), 2 * sizeof(int), hipMemcpyDeviceToHost,
+    HIPCHK(ctx, hipMemcpyAsync(p->pend_pin, t.fb_count(), 3 * sizeof(int), hipMemcpyDeviceToHost,
                                ctx->stream));
     HIPCHK(ctx, hipEventRecord(p->pend_ev, ctx->stream));
-    p->pending = true;
+    p->pending = true; p->pend_tail = skip_tail;
     *nfb = 0;
     p->gate_done = true;
     p->njac = 0;
   } else {
-    HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 1, t.fb_count(), 2 * sizeof(int), hipMemcpyDeviceToHost,
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 1, t.fb_count(), 3 * sizeof(int), hipMemcpyDeviceToHost,
                                ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *nfb = ctx->pinned[1];
     p->gate_done = (*nfb == 0);
     p->njac = p->gate_done ? ctx->pinned[2] : -1;
+    if (!mask) p->guess_settled = (ctx->pinned[3] == p->B);
   }
   t.note_paths(ctx, *nfb, mask != nullptr);
   p->path = t.path_rw();
@@ -942,11 +974,26 @@ int trf_resolve(blsq_trf_plan* p, bool* redo) {
   blsq_ctx* ctx = p->ctx;
   p->pending = false;
   HIPCHK(ctx, hipEventSynchronize(p->pend_ev));
-  const int nfb = p->pend_pin[0], njac = p->pend_pin[1];
-  if (nfb == 0 && njac == 0) return 0;
-  p->guess_ok = false;
-  if (redo) *redo = true;
+  int nfb = p->pend_pin[0], njac = p->pend_pin[1];
+  const bool settled = (p->pend_pin[2] == p->B);
   QrTree& t = p->tree;
+  if (p->pend_tail) {
+    if (settled) return 0;                  // (settled: certified and gated in the Cholesky kernel — nfb = njac = 0)
+    // wrong second guess: the launches that were left out, then the verdict as a synchronous call reads it
+    p->guess_settled = false;
+    if (redo) *redo = true;
+    int rc_;
+    if ((rc_ = trf_gate_tail(p, trf_chol_args(p, nullptr)))) return rc_;
+    HIPCHK(ctx, hipMemcpyAsync(p->pend_pin, t.fb_count(), 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    nfb = p->pend_pin[0]; njac = p->pend_pin[1];
+    if (nfb > 0 || njac > 0) p->guess_ok = false;
+  } else {
+    p->guess_settled = settled;
+    if (nfb == 0 && njac == 0) return 0;
+    p->guess_ok = false;
+    if (redo) *redo = true;
+  }
   ctx->gram_fast -= nfb; ctx->gram_fallback += nfb;      // (note_paths counted everybody as fast)
   t.any_qr = nfb > 0; t.any_gram = nfb < p->B; t.path_valid = true;
   p->gate_done = (nfb == 0);
@@ -1103,7 +1150,7 @@ extern "C" int blsq_trf_plan_create(blsq_ctx* ctx, int B, int m, int n, blsq_trf
   if (rc == 0) {
     const char* oe = getenv("BLSQ_OPTIMISTIC");
     p->optimistic = !(oe && oe[0] == '0');
-    hipError_t e = hipHostMalloc((void**)&p->pend_pin, 2 * sizeof(int), hipHostMallocDefault);
+    hipError_t e = hipHostMalloc((void**)&p->pend_pin, 4 * sizeof(int), hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->pend_ev, hipEventDisableTiming);
     if (e != hipSuccess) rc = ctx->fail(e, "optimistic-verdict resources");
   }
@@ -1136,7 +1183,7 @@ static int trf_put_bounds(blsq_trf_plan* p, const double* x, const double* lb, c
   if (kind == hipMemcpyDeviceToDevice) {                // one launch instead of four strided copies
     // (the two gate counters of the factor call that follows are cleared by the same launch)
     PackVecs pv{{x, lb, ub, scale, nullptr}, {p->st.x, p->st.lb, p->st.ub, p->st.scale, nullptr},
-                (zero_counts && p->tree.gram) ? p->tree.fb_count() : nullptr, 2};
+                (zero_counts && p->tree.gram) ? p->tree.fb_count() : nullptr, 3};
     hipError_t e = launch_pack_vecs(pv, p->n, p->ld, p->B, ctx->stream);
     if (e != hipSuccess) return ctx->fail(e, "launch_pack_vecs");
     p->tree.fb_zeroed = zero_counts && p->tree.gram;
@@ -1557,7 +1604,7 @@ int dog_put(blsq_dogbox_plan* p, const double* x, const double* lb, const double
   int rc;
   if (kind == hipMemcpyDeviceToDevice) {
     PackVecs pv{{x, lb, ub, scale, on_bound}, {p->st.x, p->st.lb, p->st.ub, p->st.scale, p->st.on_bound},
-                (zero_counts && p->tree.gram) ? p->tree.fb_count() : nullptr, 2};
+                (zero_counts && p->tree.gram) ? p->tree.fb_count() : nullptr, 3};
     hipError_t e = launch_pack_vecs(pv, p->n, p->ld, p->B, ctx->stream);
     if (e != hipSuccess) return ctx->fail(e, "launch_pack_vecs");
     p->tree.fb_zeroed = zero_counts && p->tree.gram;
@@ -1631,6 +1678,46 @@ int dog_after_triangle(blsq_dogbox_plan* p, int scale_mode) {
   return dog_finish(p, nullptr, true, false);
 }
 
+GramCholArgs dog_chol_args(blsq_dogbox_plan* p, const int* mask) {
+  QrTree& t = p->tree;
+  GramCholArgs c{};
+  c.Gsrc = t.gram_keep.as<double>(); c.G = p->st.X; c.NPAD = p->ld; c.n = p->n;
+  c.ncols_dev = p->st.ncols; c.gather = p->st.free_idx; c.stride_vec = p->ld;
+  c.mask = mask; c.fb_mask = t.fb_mask(); c.fail_count = t.fb_count(); c.path_out = t.path_rw();
+  c.fail_list = t.fb_list();
+  c.dsc = t.gram_dsc.as<double>();
+  c.rinv = t.gram_rinv.as<double>(); c.ywork = t.gram_ywork.as<double>(); c.k2_out = t.gram_k2.as<double>();
+  c.cert_done = t.gram_cert.as<int>();
+  c.colinfo = p->colinfo.as<double>();
+  if (p->ld <= 80) {                        // (the register-resident kernel also finishes the gate / Newton / Cauchy work)
+    int* gf_ = p->gate_ints.as<int>();
+    c.dog.g = p->st.g; c.dog.newton = p->st.newton; c.dog.cauchy = p->st.cauchy;
+    c.dog.fast = gf_; c.dog.ncols_jac = gf_ + p->B; c.dog.done = gf_ + 2 * (size_t)p->B;
+    c.dog.settled = t.fb_count() + 2;
+    c.dog.m = p->m; c.dog.enable = p->svdfree_enable;
+  }
+  return c;
+}
+
+// the second half of the certificate + rank gate + Newton / Cauchy steps of the problems the Cholesky
+// kernel has not settled itself (counters: fb_count()[0] problems that leave the path, [1] that need the SVD)
+int dog_gate_tail(blsq_dogbox_plan* p, const GramCholArgs& c) {
+  blsq_ctx* ctx = p->ctx;
+  QrTree& t = p->tree;
+  ctx->begin(K_GRAM_GATE);
+  hipError_t e = launch_gram_gate(c, p->B, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_gram_gate");
+  int* gfast = p->gate_ints.as<int>();
+  p->st.fast = gfast;
+  ctx->begin(K_LM_GATE);
+  e = launch_dog_gate_solve(p->st, gfast, gfast + p->B, p->svdfree_enable, t.path_rw(),
+                            p->colinfo.as<double>(), t.fb_count() + 1, c.dog.g ? c.dog.done : nullptr, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_dog_gate_solve");
+  return 0;
+}
+
 // The whole factor call from device-resident [J f].  Normal-equations path (as TRF): g and the
 // column norms from the Gram, the triangle of [J[:, free] | f] as the Cholesky factor of the gathered
 // principal sub-matrix G[free ++ rhs, free ++ rhs], and the conditioning gate applied to THAT factor
@@ -1647,67 +1734,44 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
     return dog_after_triangle(p, scale_mode);
   }
   if ((rc = t.run_gram_only(ctx, dJ, df, ldJ, mask, false))) return rc;
-  if (!t.fb_zeroed) HIPCHK(ctx, hipMemsetAsync(t.fb_count(), 0, 2 * sizeof(int), ctx->stream));
+  if (!t.fb_zeroed) HIPCHK(ctx, hipMemsetAsync(t.fb_count(), 0, 3 * sizeof(int), ctx->stream));
   t.fb_zeroed = false;
   p->st.Rt = t.Rfinal(); p->st.Gk = t.gram_keep.as<double>(); p->st.path = t.path_rw();
   ctx->begin(K_PREP);
   hipError_t e = launch_dog_prep(p->st, scale_mode, 1, mask, 0, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_dog_prep(gram)");
-  GramCholArgs c{};
-  c.Gsrc = t.gram_keep.as<double>(); c.G = p->st.X; c.NPAD = p->ld; c.n = p->n;
-  c.ncols_dev = p->st.ncols; c.gather = p->st.free_idx; c.stride_vec = p->ld;
-  c.mask = mask; c.fb_mask = t.fb_mask(); c.fail_count = t.fb_count(); c.path_out = t.path_rw();
-  c.fail_list = t.fb_list();
-  c.dsc = t.gram_dsc.as<double>();
-  c.rinv = t.gram_rinv.as<double>(); c.ywork = t.gram_ywork.as<double>(); c.k2_out = t.gram_k2.as<double>();
-  c.cert_done = t.gram_cert.as<int>();
-  c.colinfo = p->colinfo.as<double>();
-  int* gdone = p->gate_ints.as<int>() + 2 * (size_t)p->B;
-  const bool fin = p->ld <= 80;             // (the register-resident kernel also finishes the gate / Newton / Cauchy work)
-  if (fin) {
-    int* gf_ = p->gate_ints.as<int>();
-    c.dog.g = p->st.g; c.dog.newton = p->st.newton; c.dog.cauchy = p->st.cauchy;
-    c.dog.fast = gf_; c.dog.ncols_jac = gf_ + p->B; c.dog.done = gdone;
-    c.dog.m = p->m; c.dog.enable = p->svdfree_enable;
-  }
+  const GramCholArgs c = dog_chol_args(p, mask);
   ctx->begin(K_AUG_CHOL);
   e = launch_gram_chol(c, p->B, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(free block)");
-  ctx->begin(K_GRAM_GATE);
-  e = launch_gram_gate(c, p->B, ctx->stream);
-  ctx->end();
-  if (e != hipSuccess) return ctx->fail(e, "launch_gram_gate");
-  {                                         // rank gate + Newton / Cauchy steps before the read-back (as TRF)
-    int* gfast = p->gate_ints.as<int>();
-    p->st.fast = gfast;
-    ctx->begin(K_LM_GATE);
-    e = launch_dog_gate_solve(p->st, gfast, gfast + p->B, p->svdfree_enable, t.path_rw(),
-                              p->colinfo.as<double>(), t.fb_count() + 1, fin ? gdone : nullptr, ctx->stream);
-    ctx->end();
-    if (e != hipSuccess) return ctx->fail(e, "launch_dog_gate_solve");
-  }
   const bool defer = may_defer && p->optimistic && p->guess_ok && p->svdfree_enable && !mask && p->pend_pin &&
                      p->pend_ev;
+  // second guess (N <= 80): the Cholesky kernel settles EVERY problem itself, as it did in the last call —
+  // then the certificate, gate and solve launches would all be empty and are not enqueued at all
+  const bool skip_tail = defer && p->guess_settled && c.dog.g != nullptr;
+  p->st.fast = p->gate_ints.as<int>();
+  if (!skip_tail && (rc = dog_gate_tail(p, c))) return rc;
   int nfb = 0;
   if (defer) {                              // guess: nobody leaves the path, nobody needs the SVD (dog_resolve checks)
-    HIPCHK(ctx, hipMemcpyAsync(p->pend_pin, t.fb_count(), 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(p->pend_pin, t.fb_count(), 3 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipEventRecord(p->pend_ev, ctx->stream));
-    p->pending = true;
+    p->pending = true; p->pend_tail = skip_tail;
     p->pend_dJ = dJ; p->pend_df = df; p->pend_ldJ = ldJ; p->pend_scale_mode = scale_mode;
     p->gate_done = true;
     p->njac = 0;
   } else {
-    HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 1, t.fb_count(), 2 * sizeof(int), hipMemcpyDeviceToHost,
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 1, t.fb_count(), 3 * sizeof(int), hipMemcpyDeviceToHost,
                                ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     nfb = ctx->pinned[1];
     p->gate_done = (nfb == 0);
     p->njac = p->gate_done ? ctx->pinned[2] : -1;
-    if (!mask) p->guess_ok = (nfb == 0 && p->njac == 0);
+    if (!mask) { p->guess_ok = (nfb == 0 && p->njac == 0); p->guess_settled = (ctx->pinned[3] == p->B); }
   }
   t.note_paths(ctx, nfb, mask != nullptr);
+  if (skip_tail) { p->gate_done = false; return 0; }
   if (nfb > 0) {
     if ((rc = t.run_levels(ctx, dJ, df, ldJ, t.fb_mask(), t.fb_list(), nfb))) return rc;
     ctx->begin(K_PREP);
@@ -1726,10 +1790,25 @@ int dog_resolve(blsq_dogbox_plan* p, bool* redo) {
   QrTree& t = p->tree;
   p->pending = false;
   HIPCHK(ctx, hipEventSynchronize(p->pend_ev));
-  const int nfb = p->pend_pin[0], njac = p->pend_pin[1];
-  if (nfb == 0 && njac == 0) return 0;
-  p->guess_ok = false;
-  if (redo) *redo = true;
+  int nfb = p->pend_pin[0], njac = p->pend_pin[1];
+  const bool settled = (p->pend_pin[2] == p->B);
+  if (p->pend_tail) {
+    if (settled) return 0;                  // (settled: certified and finished in the Cholesky kernel — nfb = njac = 0)
+    // wrong second guess: the launches that were left out, then the verdict as a synchronous call reads it
+    p->guess_settled = false;
+    if (redo) *redo = true;
+    int rc_;
+    if ((rc_ = dog_gate_tail(p, dog_chol_args(p, nullptr)))) return rc_;
+    HIPCHK(ctx, hipMemcpyAsync(p->pend_pin, t.fb_count(), 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    nfb = p->pend_pin[0]; njac = p->pend_pin[1];
+    if (nfb > 0 || njac > 0) p->guess_ok = false;
+  } else {
+    p->guess_settled = settled;
+    if (nfb == 0 && njac == 0) return 0;
+    p->guess_ok = false;
+    if (redo) *redo = true;
+  }
   ctx->gram_fast -= nfb; ctx->gram_fallback += nfb;
   t.any_qr = nfb > 0; t.any_gram = nfb < p->B; t.path_valid = true;
   p->gate_done = (nfb == 0);
@@ -1767,7 +1846,7 @@ extern "C" int blsq_dogbox_plan_create(blsq_ctx* ctx, int B, int m, int n,
   if (rc == 0) {
     const char* oe = getenv("BLSQ_OPTIMISTIC");
     p->optimistic = !(oe && oe[0] == '0');
-    hipError_t e = hipHostMalloc((void**)&p->pend_pin, 2 * sizeof(int), hipHostMallocDefault);
+    hipError_t e = hipHostMalloc((void**)&p->pend_pin, 4 * sizeof(int), hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->pend_ev, hipEventDisableTiming);
     if (e != hipSuccess) rc = ctx->fail(e, "optimistic-verdict resources");
   }

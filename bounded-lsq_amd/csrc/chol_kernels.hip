@@ -415,8 +415,8 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
   //        K2 = ||R'||_1 ||R'||_inf ||Y||_1 ||Y||_inf ,   Y = R'^-T  column block by column block.
   //    K2 <= GRAM_K2_MAX settles the problem here; otherwise the separate kernel decides (it also
   //    has the tighter Frobenius bound).
+  bool passed = false;
   if (a.cert_done) {
-    bool passed = false;
     double k2 = 0.0;
     if (!fail) {
       const int NTn = (n + 15) / 16;
@@ -513,6 +513,19 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
       if (passed && a.k2_out) a.k2_out[b] = k2;
     }
   }
+  // 5b. TRF finish (GramCholArgs::lmfin): the `sure` branch of lm_gate_kernel, same expressions
+  if (a.lmfin.fast && !fail && passed && a.colinfo && a.lmfin.enable != 0 && a.lmfin.m >= n && tid == 0) {
+    const double mn = tv[0], sm = tv[1];
+    const double smin_lb = GRAM_SMIN_PROVEN * mn, smax_ub = sqrt(sm);
+    if (is_finite(sm) && sm > 0.0 && smin_lb > LM_GATE_MARGIN * LM_EPS * a.lmfin.m * smax_ub) {
+      a.lmfin.fast[b] = 1;
+      a.lmfin.ncols_jac[b] = 0;
+      a.lmfin.sc[(long)b * 16 + SC_SMAX] = smax_ub;
+      a.lmfin.sc[(long)b * 16 + SC_SMIN] = smin_lb;
+      a.lmfin.st[(long)b * 4 + ST_PHASE] = LM_IDLE;
+      if (a.lmfin.settled) atomicAdd(a.lmfin.settled, 1);
+    }
+  }
   // 6. dogbox finish (GramCholArgs::dog): what dog_gate_solve_kernel computes for a problem on this path —
   //    Cauchy step -(g.g)/(J_f g . J_f g) g_f with |J_f g_f| = |R g_f|, and, when the column-norm bound
   //    already proves the free block full rank (the `sure` case there), the Newton step -R_f^-1 c_f —
@@ -596,6 +609,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
     if (tid == 0) {
       a.dog.done[b] = finished ? 1 : 0;
       if (finished) { a.dog.fast[b] = 1; a.dog.ncols_jac[b] = 0; }
+      if (finished && passed && a.dog.settled) atomicAdd(a.dog.settled, 1);
     }
   }
 }

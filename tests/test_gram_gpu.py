@@ -523,6 +523,91 @@ def test_optimistic_verdict_of_the_dogbox_device_api(bl, monkeypatch):
             assert np.array_equal(x1, x0)
 
 
+def test_second_guess_of_the_trf_device_api(bl, monkeypatch):
+    """N <= 80, TRF: after a call in which the Cholesky kernel settled every problem (first certificate
+    bound + the rank gate's column-norm bound), the certificate and gate launches of the next call are
+    not enqueued.  Guess holds / fails softly (a column of norm 1e-12) / fails hard (certificate; rank
+    deficiency) / holds again: the bits of the synchronous mode at every call."""
+    from bounded_lsq import _synth, _abi
+    B, m, n = 6, 700, 64
+    good = _synth.trf_batch(520, B, m, n)
+    other = _synth.trf_batch(521, B, m, n)
+    tiny = {k: v.copy() for k, v in good.items()}
+    tiny["J"][4][:, 7] *= 1e-12
+    tiny["lb"][4] = -np.inf; tiny["ub"][4] = np.inf
+    hard = {k: v.copy() for k, v in good.items()}
+    hard["J"][1] = _equicorrelated(1, m, n, 1 - 1e-9, 3)[0]
+    hard["lb"][1] = -np.inf; hard["ub"][1] = np.inf
+    hard["J"][3][:, n - 1] = hard["J"][3][:, 0]
+    hard["lb"][3] = -np.inf; hard["ub"][3] = np.inf
+    seq = [good, other, good, tiny, other, good, hard, good, other, good]
+    Delta = np.array([0.5, 0.05, 5.0, 0.2, 0.3, 1.0])
+    for scale_mode in (0, 1):
+        runs = []
+        for opt in ("1", "0"):
+            monkeypatch.setenv("BLSQ_OPTIMISTIC", opt)
+            ctx = _abi.Context(0)
+            sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
+            dD, dA = ctx.to_device(Delta), ctx.to_device(np.zeros(B))
+            outs = []
+            for P in seq:
+                d = {k: ctx.to_device(P[k]) for k in ("J", "f", "x", "lb", "ub", "scale")}
+                sol.factor_dev(d["J"], d["f"], d["x"], d["lb"], d["ub"], d["scale"], scale_mode)
+                sol.step_dev(dD, dA)
+                S = sol.fetch_step()
+                outs.append((S.step.copy(), np.asarray(S.alpha).copy(), np.asarray(S.n_iter).copy(), S.hits.copy(),
+                             sol.fetch_factor().g.copy(), ctx.to_host(d["scale"], (B, n), np.float64)))
+                for v in d.values():
+                    ctx.free(v)
+            runs.append(outs)
+            sol.close(); ctx.free(dD); ctx.free(dA); ctx.close()
+        for call, (o1, o0) in enumerate(zip(*runs)):
+            for x1, x0 in zip(o1, o0):
+                assert np.array_equal(x1, x0, equal_nan=True), (scale_mode, call)
+
+
+def test_second_guess_of_the_dogbox_device_api(bl, monkeypatch):
+    """N <= 80: once a call has seen EVERY problem settled inside the Cholesky kernel (certified by the
+    first bound, Cauchy and Newton steps written there), the next call does not enqueue the certificate /
+    gate / solve launches at all and checks the settled counter when it resolves.  A sequence of calls
+    in which that guess holds, fails softly (a column of norm 1e-12: the rank gate must look at the
+    problem, nothing leaves the path), fails hard (a problem for the Householder tree) and holds again
+    gives the bits of the synchronous mode at every call."""
+    from bounded_lsq import _synth, _abi
+    B, m, n = 6, 700, 64
+    good = _synth.dogbox_batch(510, B, m, n)
+    other = _synth.dogbox_batch(511, B, m, n)
+    tiny = {k: v.copy() for k, v in good.items()}
+    tiny["J"][4][:, 7] *= 1e-12
+    tiny["lb"][4] = -np.inf; tiny["ub"][4] = np.inf; tiny["on_bound"][4] = 0
+    hard = {k: v.copy() for k, v in good.items()}
+    hard["J"][2] = _equicorrelated(1, m, n, 1 - 1e-9, 3)[0]
+    hard["lb"][2] = -np.inf; hard["ub"][2] = np.inf; hard["on_bound"][2] = 0
+    seq = [good, other, good, tiny, other, good, hard, good, other, good]
+    Delta = np.full(B, 0.05)
+    runs = []
+    for opt in ("1", "0"):
+        monkeypatch.setenv("BLSQ_OPTIMISTIC", opt)
+        ctx = _abi.Context(0)
+        sol = bl.DogboxStepSolver(B, m, n, ctx=ctx)
+        dD = ctx.to_device(Delta)
+        outs = []
+        for P in seq:
+            d = {k: ctx.to_device(P[k]) for k in ("J", "f", "x", "lb", "ub", "scale", "on_bound")}
+            sol.factor_dev(d["J"], d["f"], d["x"], d["lb"], d["ub"], d["scale"], d["on_bound"])
+            sol.step_dev(dD)
+            S = sol.fetch_step()
+            _, nw, ca = sol.fetch_factor(want_steps=True)
+            outs.append((S.step.copy(), S.on_bound_new.copy(), S.predicted_reduction.copy(), nw.copy(), ca.copy()))
+            for v in d.values():
+                ctx.free(v)
+        runs.append(outs)
+        sol.close(); ctx.free(dD); ctx.close()
+    for call, (o1, o0) in enumerate(zip(*runs)):
+        for x1, x0 in zip(o1, o0):
+            assert np.array_equal(x1, x0, equal_nan=True), call
+
+
 def test_chunk_pairs_summed_in_the_kernel_match_the_reduction_pass(bl, monkeypatch):
     """Two row chunks (2048 < m <= 4096), 16 column tiles and at least 256 problems: one workgroup
     takes both chunks and adds them in the kernel, (0 + P0) + P1 — what the separate reduction pass
