@@ -851,7 +851,7 @@ GramCholArgs trf_chol_args(blsq_trf_plan* p, const int* mask) {
   c.colinfo = p->aug_colinfo.as<double>();
   if (p->ld <= 80) {                        // (the register-resident kernel also does the rank gate's sure case)
     c.lmfin.fast = p->lm.fast; c.lmfin.ncols_jac = p->lm.ncols_jac; c.lmfin.sc = p->lm.sc; c.lmfin.st = p->lm.st;
-    c.lmfin.settled = t.fb_count() + 2;
+    c.unsettled = t.fb_count() + 2;
     c.lmfin.m = p->lm.m; c.lmfin.enable = (p->lm_gate_mask >> 1) & 1;
   }
   return c;
@@ -919,7 +919,7 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, 
     *nfb = ctx->pinned[1];
     p->gate_done = (*nfb == 0);
     p->njac = p->gate_done ? ctx->pinned[2] : -1;
-    if (!mask) p->guess_settled = (ctx->pinned[3] == p->B);
+    if (!mask) p->guess_settled = (c.unsettled && ctx->pinned[3] == 0);
   }
   t.note_paths(ctx, *nfb, mask != nullptr);
   p->path = t.path_rw();
@@ -975,7 +975,7 @@ int trf_resolve(blsq_trf_plan* p, bool* redo) {
   p->pending = false;
   HIPCHK(ctx, hipEventSynchronize(p->pend_ev));
   int nfb = p->pend_pin[0], njac = p->pend_pin[1];
-  const bool settled = (p->pend_pin[2] == p->B);
+  const bool settled = (p->ld <= 80 && p->pend_pin[2] == 0);
   QrTree& t = p->tree;
   if (p->pend_tail) {
     if (settled) return 0;                  // (settled: certified and gated in the Cholesky kernel — nfb = njac = 0)
@@ -1693,7 +1693,7 @@ GramCholArgs dog_chol_args(blsq_dogbox_plan* p, const int* mask) {
     int* gf_ = p->gate_ints.as<int>();
     c.dog.g = p->st.g; c.dog.newton = p->st.newton; c.dog.cauchy = p->st.cauchy;
     c.dog.fast = gf_; c.dog.ncols_jac = gf_ + p->B; c.dog.done = gf_ + 2 * (size_t)p->B;
-    c.dog.settled = t.fb_count() + 2;
+    c.unsettled = t.fb_count() + 2;
     c.dog.m = p->m; c.dog.enable = p->svdfree_enable;
   }
   return c;
@@ -1768,7 +1768,7 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
     nfb = ctx->pinned[1];
     p->gate_done = (nfb == 0);
     p->njac = p->gate_done ? ctx->pinned[2] : -1;
-    if (!mask) { p->guess_ok = (nfb == 0 && p->njac == 0); p->guess_settled = (ctx->pinned[3] == p->B); }
+    if (!mask) { p->guess_ok = (nfb == 0 && p->njac == 0); p->guess_settled = (c.unsettled && ctx->pinned[3] == 0); }
   }
   t.note_paths(ctx, nfb, mask != nullptr);
   if (skip_tail) { p->gate_done = false; return 0; }
@@ -1791,7 +1791,7 @@ int dog_resolve(blsq_dogbox_plan* p, bool* redo) {
   p->pending = false;
   HIPCHK(ctx, hipEventSynchronize(p->pend_ev));
   int nfb = p->pend_pin[0], njac = p->pend_pin[1];
-  const bool settled = (p->pend_pin[2] == p->B);
+  const bool settled = (p->ld <= 80 && p->pend_pin[2] == 0);
   if (p->pend_tail) {
     if (settled) return 0;                  // (settled: certified and finished in the Cholesky kernel — nfb = njac = 0)
     // wrong second guess: the launches that were left out, then the verdict as a synchronous call reads it

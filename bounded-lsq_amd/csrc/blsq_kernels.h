@@ -107,21 +107,24 @@ struct GramCholArgs {
     int* fast;            // [B] out
     int* ncols_jac;       // [B] out
     int* done;            // [B] out: 1 = finished here
-    int* settled;         // counter (or null): += 1 per problem finished here AND certified here — when it
-                          // reaches the batch size, the certificate / gate / solve launches have nothing to do
     int m, enable;
   } dog;
   // TRF finish (gram_chol_reg_kernel only; fast == nullptr: none): what lm_gate_kernel writes for a
   // problem of this path whose rank the column-norm bound settles (fast flag, singular-value bounds, idle
-  // phase); counted in `settled` together with the certificate, as above
+  // phase)
   struct LmFinish {
     int* fast;            // [B]
     int* ncols_jac;       // [B]
     double* sc;           // [B][16] (SC_SMAX, SC_SMIN)
     int* st;              // [B][4]  (ST_PHASE)
-    int* settled;
     int m, enable;
   } lmfin;
+  // gram_chol_reg_kernel with `dog` or `lmfin`: counter (or null) of the problems of the launch the kernel
+  // does NOT settle completely — certified by the first bound AND finished by the block above.  While it
+  // stays 0 the certificate / gate / solve launches that follow have nothing to do.  (Counting the
+  // exceptions keeps the common case free of atomics: a thousand waves finishing together and adding to
+  // one address cost 9 us.)
+  int* unsettled;
 };
 // A problem stays on the normal-equations path only if the PROVEN bound K2 >= kappa_2(R'^T R') of its
 // equilibrated system is at most GRAM_K2_MAX (chol_kernels.hip, gram_cond_kernel).  Consequence used

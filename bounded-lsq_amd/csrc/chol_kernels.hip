@@ -232,14 +232,17 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
   const int NPAD = a.NPAD;
   double* sh = sh_all + (size_t)wv * (8 * (size_t)NPAD + 256 + MT * 256 + 64 + 16);
   auto wsync = []() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); };
+  auto unsettle = [&]() { if (tid == 0 && a.unsettled) atomicAdd(a.unsettled, 1); };
   if (a.mask && a.mask[b] <= 1) {
     if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
+    unsettle();
     return;
   }
   if (a.skip_path && a.skip_path[b] != 0) return;
   const int N = a.ncols_dev ? a.ncols_dev[b] : a.n + 1;
   if (N <= 1) {                                         // (dogbox: every variable active — nothing to factor)
     if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
+    unsettle();
     return;
   }
   const int n = N - 1;
@@ -338,6 +341,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
       a.fb_mask[b] = a.n + 1; { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }   // (the tree factors ALL n + 1 columns)
       if (a.path_out) a.path_out[b] = a.n + 1;
     }
+    unsettle();
     return;
   }
   // strictly lower tiles and everything beyond 16 NT are part of the triangle's image: zero
@@ -514,17 +518,21 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
     }
   }
   // 5b. TRF finish (GramCholArgs::lmfin): the `sure` branch of lm_gate_kernel, same expressions
-  if (a.lmfin.fast && !fail && passed && a.colinfo && a.lmfin.enable != 0 && a.lmfin.m >= n && tid == 0) {
-    const double mn = tv[0], sm = tv[1];
-    const double smin_lb = GRAM_SMIN_PROVEN * mn, smax_ub = sqrt(sm);
-    if (is_finite(sm) && sm > 0.0 && smin_lb > LM_GATE_MARGIN * LM_EPS * a.lmfin.m * smax_ub) {
-      a.lmfin.fast[b] = 1;
-      a.lmfin.ncols_jac[b] = 0;
-      a.lmfin.sc[(long)b * 16 + SC_SMAX] = smax_ub;
-      a.lmfin.sc[(long)b * 16 + SC_SMIN] = smin_lb;
-      a.lmfin.st[(long)b * 4 + ST_PHASE] = LM_IDLE;
-      if (a.lmfin.settled) atomicAdd(a.lmfin.settled, 1);
+  if (a.lmfin.fast && tid == 0) {
+    bool finished = false;
+    if (!fail && passed && a.colinfo && a.lmfin.enable != 0 && a.lmfin.m >= n) {
+      const double mn = tv[0], sm = tv[1];
+      const double smin_lb = GRAM_SMIN_PROVEN * mn, smax_ub = sqrt(sm);
+      if (is_finite(sm) && sm > 0.0 && smin_lb > LM_GATE_MARGIN * LM_EPS * a.lmfin.m * smax_ub) {
+        a.lmfin.fast[b] = 1;
+        a.lmfin.ncols_jac[b] = 0;
+        a.lmfin.sc[(long)b * 16 + SC_SMAX] = smax_ub;
+        a.lmfin.sc[(long)b * 16 + SC_SMIN] = smin_lb;
+        a.lmfin.st[(long)b * 4 + ST_PHASE] = LM_IDLE;
+        finished = true;
+      }
     }
+    if (!finished) unsettle();
   }
   // 6. dogbox finish (GramCholArgs::dog): what dog_gate_solve_kernel computes for a problem on this path —
   //    Cauchy step -(g.g)/(J_f g . J_f g) g_f with |J_f g_f| = |R g_f|, and, when the column-norm bound
@@ -609,7 +617,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
     if (tid == 0) {
       a.dog.done[b] = finished ? 1 : 0;
       if (finished) { a.dog.fast[b] = 1; a.dog.ncols_jac[b] = 0; }
-      if (finished && passed && a.dog.settled) atomicAdd(a.dog.settled, 1);
+      if (!(finished && passed)) unsettle();
     }
   }
 }
@@ -1440,10 +1448,15 @@ hipError_t launch_gram_chol(const GramCholArgs& a_in, int B, hipStream_t s) {
   if (a.NPAD <= 80) {                                   // one wave per problem, eight per workgroup
     // (register-resident right-looking kernel; BLSQ_CHOL_REG = 0: the left-looking one-wave kernel)
     const char* rge = getenv("BLSQ_CHOL_REG");
-    if (rge && rge[0] == '0')
+    if (rge && rge[0] == '0') {
+      // (this kernel has no finish blocks: nothing is settled, nobody is done)
+      hipError_t me = hipSuccess;
+      if (a.unsettled) me = hipMemsetD32Async((hipDeviceptr_t)a.unsettled, 1, 1, s);
+      if (me == hipSuccess && a.dog.done) me = hipMemsetAsync(a.dog.done, 0, sizeof(int) * (size_t)B, s);
+      if (me != hipSuccess) return me;
       hipLaunchKernelGGL(gram_chol_kernel<1>, dim3((B + GR_NW - 1) / GR_NW), dim3(GR_NT), per * GR_NW,
                          s, a);
-    else {
+    } else {
       const size_t per_reg = sizeof(double) * (8 * (size_t)a.NPAD + 256 + 5 * 256 + 64 + 16);
       static std::atomic<size_t> granted[64];
       hipError_t ge = gram_grant_lds(gram_chol_reg_kernel, per_reg * REG_NW, granted);
