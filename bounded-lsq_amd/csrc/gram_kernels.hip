@@ -673,15 +673,17 @@ __global__ __launch_bounds__(GR_NT, 2) void gram8_kernel(GramArgs a) {
 // ---- narrow problems (NT <= 5 column tiles): no LDS staging ------------------------------------
 // The MFMA operand fragment of column tile c at k-step s is X[4 s + lr][16 c + lc]: 16 lanes read
 // 128 contiguous bytes of a row — a coalesced global load straight into the operand register.
-// So with few column tiles every wave takes its own k-steps (4 rows each, wave w: k-steps w, w + 8,
-// ...) for ALL output tiles, keeps two rounds of four k-steps of loads in flight (the loads of round
+// So with few column tiles every wave takes its own k-steps (4 rows each, wave w of NWD: k-steps w,
+// w + NWD, ...) for ALL output tiles, keeps two rounds of four k-steps of loads in flight (the loads of round
 // i + 1 are issued before round i is consumed: 512 x 64, 1024 problems 181 -> 95 us), and never meets
-// the other waves until the final, fixed-order reduction of the eight partial Grams through LDS.
-template <int NTT, bool RHS>
-__global__ __launch_bounds__(GR_NT, (NTT <= 2 ? 4 : 2)) void gram_direct_kernel(GramArgs a) {
+// the other waves until the final, fixed-order reduction of the NWD partial Grams through LDS.
+// (NWD = 2, 4 or 8 waves per workgroup by the row count: launch_gram.)
+template <int NTT, bool RHS, int NWD>
+__global__ __launch_bounds__(64 * NWD, (NTT <= 2 ? 4 : 2)) void gram_direct_kernel(GramArgs a) {
+  constexpr int NTD = 64 * NWD;                         // NWD waves per workgroup
   constexpr int NTILE = NTT * (NTT + 1) / 2;
   constexpr int KU = 4;                                 // k-steps per round (two rounds in flight per wave)
-  extern __shared__ double lds[];                       // [GR_NW][256]
+  extern __shared__ double lds[];                       // [NWD][256]
   const int b = blockIdx.y;
   if (a.mask && a.mask[b] <= 1) return;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -703,12 +705,12 @@ __global__ __launch_bounds__(GR_NT, (NTT <= 2 ? 4 : 2)) void gram_direct_kernel(
 #pragma unroll
   for (int c = 0; c < NTT; ++c) gf[c] = 0.0;
   const int last = r_hi > r_lo ? r_hi - 1 : r_lo;
-  constexpr int RSTEP = 4 * GR_NW * KU;                 // rows the workgroup consumes per round
+  constexpr int RSTEP = 4 * NWD * KU;                 // rows the workgroup consumes per round
   // raw loads of one round (clamped, unconditional — nothing here waits for the data) ...
   auto load_round = [&](int r0, double (&fr)[KU][NTT], double (&fv)[KU]) {
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
-      const int row = r0 + 4 * GR_NW * u + lr;
+      const int row = r0 + 4 * NWD * u + lr;
       const int rc = row < r_hi ? row : last;
       if (RHS) fv[u] = Fb[rc];
 #pragma unroll
@@ -724,7 +726,7 @@ __global__ __launch_bounds__(GR_NT, (NTT <= 2 ? 4 : 2)) void gram_direct_kernel(
   auto use_round = [&](int r0, double (&fr)[KU][NTT], double (&fv)[KU]) {
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
-      const bool rin = r0 + 4 * GR_NW * u + lr < r_hi;
+      const bool rin = r0 + 4 * NWD * u + lr < r_hi;
       if (RHS) fv[u] = rin ? fv[u] : 0.0;
 #pragma unroll
       for (int c = 0; c < NTT; ++c) {
@@ -769,11 +771,11 @@ __global__ __launch_bounds__(GR_NT, (NTT <= 2 ? 4 : 2)) void gram_direct_kernel(
     for (int tt = 0; tt < PH; ++tt) {
       if (t0 + tt < NTILE) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) lds[(tt * GR_NW + w) * 256 + g * 64 + lane] = acc[t0 + tt][g];
+        for (int g = 0; g < 4; ++g) lds[(tt * NWD + w) * 256 + g * 64 + lane] = acc[t0 + tt][g];
       }
     }
     __syncthreads();
-    for (int e = tid; e < PH * 256; e += GR_NT) {
+    for (int e = tid; e < PH * 256; e += NTD) {
       const int tt = e >> 8, el = e & 255;
       int q = t0 + tt, i = 0;
       if (q < NTILE) {
@@ -782,7 +784,7 @@ __global__ __launch_bounds__(GR_NT, (NTT <= 2 ? 4 : 2)) void gram_direct_kernel(
         if (j < NT) {
           double sum = 0.0;
 #pragma unroll
-          for (int ww = 0; ww < GR_NW; ++ww) sum += lds[(tt * GR_NW + ww) * 256 + el];
+          for (int ww = 0; ww < NWD; ++ww) sum += lds[(tt * NWD + ww) * 256 + el];
           const int g = el >> 6, ln = el & 63;
           G[(long)(16 * i + (ln >> 4) + 4 * g) * a.NPAD + 16 * j + (ln & 15)] = sum;
         }
@@ -794,19 +796,19 @@ __global__ __launch_bounds__(GR_NT, (NTT <= 2 ? 4 : 2)) void gram_direct_kernel(
   // rhs column: [wave][lane row][column] partials -> column totals (wave-major, then lane row)
 #pragma unroll
   for (int c = 0; c < NTT; ++c) lds[(w * 4 + lr) * 64 + 16 * c + lc] = gf[c];
-  if (lc == 0) lds[2048 + w * 4 + lr] = gff;
+  if (lc == 0) lds[NWD * 256 + w * 4 + lr] = gff;
   __syncthreads();
   if (tid < n) {
     double sum = 0.0;
-    for (int q = 0; q < 4 * GR_NW; ++q) sum += lds[q * 64 + tid];
+    for (int q = 0; q < 4 * NWD; ++q) sum += lds[q * 64 + tid];
     G[(long)tid * a.NPAD + n] = sum;
   }
   if (tid == 0) {
     double sum = 0.0;
-    for (int q = 0; q < 4 * GR_NW; ++q) sum += lds[2048 + q];
+    for (int q = 0; q < 4 * NWD; ++q) sum += lds[NWD * 256 + q];
     G[(long)n * a.NPAD + n] = sum;
   }
-  for (int e = tid; e < a.NPAD * (16 * NT - (n + 1)); e += GR_NT) {   // padding of the rhs tile column
+  for (int e = tid; e < a.NPAD * (16 * NT - (n + 1)); e += NTD) {   // padding of the rhs tile column
     const int r = e / (16 * NT - (n + 1)), c = n + 1 + e % (16 * NT - (n + 1));
     if ((r >> 4) <= (c >> 4)) G[(long)r * a.NPAD + c] = 0.0;
   }
@@ -890,16 +892,31 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s, d
     if (ge != hipSuccess) return ge;                                                          \
     hipLaunchKernelGGL((gram_kernel<SL, CB>), dim3(chunks, B, tg), dim3(GR_NT), lds, s, a);   \
   } while (0)
-#define BLSQ_GRAM_DIRECT(NTT, RHS)                                                            \
+#define BLSQ_GRAM_DIRECT_NW(NTT, RHS, NWD)                                                    \
   do {                                                                                        \
     constexpr int nt_ = (NTT) * ((NTT) + 1) / 2;                                              \
-    const size_t dl_ = sizeof(double) * ((nt_ < 5 ? nt_ : 5) * GR_NW * 256 + 64);            \
+    const size_t dl_ = sizeof(double) * ((nt_ < 5 ? nt_ : 5) * (NWD) * 256 + 64);            \
     static std::atomic<size_t> granted[64];                                                   \
-    hipError_t ge = gram_grant_lds(gram_direct_kernel<NTT, RHS>, dl_, granted);               \
+    hipError_t ge = gram_grant_lds(gram_direct_kernel<NTT, RHS, NWD>, dl_, granted);          \
     if (ge != hipSuccess) return ge;                                                          \
-    hipLaunchKernelGGL((gram_direct_kernel<NTT, RHS>), dim3(chunks, B), dim3(GR_NT), dl_, s, a); \
+    hipLaunchKernelGGL((gram_direct_kernel<NTT, RHS, NWD>), dim3(chunks, B), dim3(64 * (NWD)), dl_, s, a); \
     return hipGetLastError();                                                                 \
   } while (0)
+#define BLSQ_GRAM_DIRECT(NTT, RHS)                                                            \
+  do {                                                                                        \
+    if (direct_nw == 4) BLSQ_GRAM_DIRECT_NW(NTT, RHS, 4);                                     \
+    else if (direct_nw == 2) BLSQ_GRAM_DIRECT_NW(NTT, RHS, 2);                                \
+    else BLSQ_GRAM_DIRECT_NW(NTT, RHS, 8);                                                    \
+  } while (0)
+  // waves per workgroup of the direct kernel: about 256 rows per wave (a function of m only, so a
+  // problem's bits do not depend on its batch).  A short problem on eight waves is four rounds of loads
+  // per wave between a cold start and an eight-way reduction, and one workgroup fills the CU: 1024
+  // problems of 512 x 64 pass in four lock-step generations.  On two waves, four workgroups share the CU
+  // and drift apart: 96 -> 78 us.  BLSQ_GRAM_DIRECT_NW = 2 | 4 | 8 forces one.
+  const char* dnw_e = getenv("BLSQ_GRAM_DIRECT_NW");
+  const int rows_wg = a.m < a.rows_per_chunk ? a.m : a.rows_per_chunk;
+  // (up to 128 rows eight waves need a single round of loads: nothing to drift, lowest latency)
+  const int direct_nw = dnw_e ? atoi(dnw_e) : (rows_wg <= 128 ? 8 : rows_wg <= 512 ? 2 : rows_wg <= 1024 ? 4 : 8);
   {
     const char* env = getenv("BLSQ_GRAM_DIRECT_MAX_NT");     // tuning / tests: 0 disables
     const int dmax = env ? atoi(env) : 4;                      // measured: direct wins up to 4 column tiles
@@ -919,6 +936,7 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s, d
     }
   }
 #undef BLSQ_GRAM_DIRECT
+#undef BLSQ_GRAM_DIRECT_NW
   {
     // 8 column tiles of J^T J (n = 113 .. 128): the k-split static-tile kernel, for EVERY batch size
     // (its summation order defines the result for these widths).  BLSQ_GRAM8 = 0: the generic kernel.

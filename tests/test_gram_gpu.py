@@ -523,6 +523,38 @@ def test_optimistic_verdict_of_the_dogbox_device_api(bl, monkeypatch):
             assert np.array_equal(x1, x0)
 
 
+def test_direct_kernel_wave_counts(bl, monkeypatch):
+    """Narrow problems (at most four column tiles): the direct Gram kernel runs two, four or eight
+    waves per workgroup by the row count (about 256 rows per wave; BLSQ_GRAM_DIRECT_NW forces one).
+    The wave count fixes the summation order, nothing else: every choice gives g = J^T f to rounding and
+    the same step to far below the parity bar — ragged row counts, one or several row chunks."""
+    from bounded_lsq import _synth, _abi
+    for (B, m, n) in [(5, 512, 64), (3, 300, 40), (4, 1000, 30), (2, 129, 64), (3, 2500, 17), (2, 33, 5)]:
+        P = _synth.trf_batch(800 + m, B, m, n)
+        Delta = np.full(B, 0.3)
+        outs = {}
+        for nw in ("default", "2", "4", "8"):
+            if nw == "default":
+                monkeypatch.delenv("BLSQ_GRAM_DIRECT_NW", raising=False)
+            else:
+                monkeypatch.setenv("BLSQ_GRAM_DIRECT_NW", nw)
+            ctx = _abi.Context(0)
+            sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
+            sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+            S = sol.step(Delta, np.zeros(B))
+            outs[nw] = (sol.fetch_factor().g.copy(), S.step.copy(), S.hits.copy())
+            sol.close(); ctx.close()
+        want = 8 if m <= 128 else 2 if m <= 512 else 4 if m <= 1024 else 8
+        for k in range(3):
+            assert np.array_equal(outs["default"][k], outs[str(want)][k]), (m, n, k)
+        for nw in ("2", "4", "8"):
+            for b in range(B):
+                gx = (P["J"][b].astype(np.longdouble).T @ P["f"][b].astype(np.longdouble)).astype(np.float64)
+                assert rel(outs[nw][0][b], gx) < 1e-13, (m, n, nw)
+                assert rel(outs[nw][1][b], outs["8"][1][b]) < 1e-11, (m, n, nw)
+            assert np.array_equal(outs[nw][2], outs["8"][2]), (m, n, nw)
+
+
 def test_second_guess_of_the_trf_device_api(bl, monkeypatch):
     """N <= 80, TRF: after a call in which the Cholesky kernel settled every problem (first certificate
     bound + the rank gate's column-norm bound), the certificate and gate launches of the next call are
