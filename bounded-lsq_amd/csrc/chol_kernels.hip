@@ -977,7 +977,13 @@ hipError_t launch_lm_rounds_reg(const GramCholArgs& c, const LmState& lm, const 
 // LDS row buffer, and every wave updates its own trailing tiles from that buffer — no global-memory
 // round trip inside the factorisation (the left-looking kernel above re-reads finished rows from L2).
 // Same arguments, same outputs, same gate bookkeeping as gram_chol_kernel.
-template <int SL>
+// SL tile slots per worker wave, the first KL of them kept in LDS instead of registers: the cyclic
+// tile table gives slot t the tiles 7 t .. 7 t + 6 in row-major order, so the first slots hold the top
+// rows — solved after at most three trailing updates and dead afterwards.  With all 22 slots in
+// registers (176 VGPRs) the compiler spilled 76 VGPRs to scratch and reloaded / stored them in
+// every row-block step; with eight slots in LDS (112 KB) 28 remain (two Newton rounds of 4096 x 256,
+// 512 problems: 0.404 -> 0.376 ms; same operations in the same order, same bits).
+template <int SL, int KL>
 __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) {
   extern __shared__ double sh[];
   __shared__ double red[32];
@@ -1013,6 +1019,7 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
   double* Dt = td + NPAD;          // [256]
   double* Ri = Dt + 256;           // [256]
   double* Rrow = Ri + 256;         // [NT][256] finished tiles of the current row block
+  double* accL = Rrow + (NPAD / 16) * 256;   // [KL][7][256] the LDS-resident tile slots
   const double* csv = a.colscale ? a.colscale + (long)b * a.stride_vec : nullptr;
   const double* edv = a.diag_vec ? a.diag_vec + (long)b * a.stride_vec : nullptr;
   const double sa = a.diag_sqrt ? a.diag_sqrt[b] : 0.0;
@@ -1095,7 +1102,20 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
     // read before anything is written
     const int ww = w - 1;
     int ti[SL], tj[SL];
-    v4d acc[SL];
+    v4d accR[SL - KL];                                  // slots KL .. SL-1 (registers)
+    auto slot = [&](int t) -> double* { return accL + ((size_t)t * NWK + ww) * 256 + lane; };   // [g * 64]
+#define RL_ACC_GET(t, dst)                                                        \
+    do {                                                                          \
+      if ((t) < KL) { const double* p_ = slot(t);                                 \
+        dst = v4d{p_[0], p_[64], p_[128], p_[192]}; }                             \
+      else dst = accR[(t) < KL ? 0 : (t) - KL];                                   \
+    } while (0)
+#define RL_ACC_PUT(t, src)                                                        \
+    do {                                                                          \
+      if ((t) < KL) { double* p_ = slot(t);                                       \
+        p_[0] = (src)[0]; p_[64] = (src)[1]; p_[128] = (src)[2]; p_[192] = (src)[3]; } \
+      else accR[(t) < KL ? 0 : (t) - KL] = src;                                   \
+    } while (0)
 #pragma unroll
     for (int t = 0; t < SL; ++t) {
       int q = ww + NWK * t;
@@ -1104,7 +1124,7 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
       while (valid && q >= NT - i) { q -= NT - i; ++i; }
       ti[t] = valid ? i : -1;
       tj[t] = valid ? i + q : -1;
-      acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+      v4d a0 = v4d{0.0, 0.0, 0.0, 0.0};
       if (valid) {
         const int j = tj[t];
         const double scj = sc[16 * j + lc];
@@ -1118,13 +1138,14 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
             v = Gs[(unsigned)(sr_ * NPAD + sc_)] * sc[row] * scj;
           }
           if (j == i && lr + 4 * g == lc) v += td[row];
-          acc[t][g] = v;
+          a0[g] = v;
         }
         if (i == 0 && j == 0) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) Dt[(lr + 4 * g) * 16 + lc] = acc[t][g];
+          for (int g = 0; g < 4; ++g) Dt[(lr + 4 * g) * 16 + lc] = a0[g];
         }
       }
+      RL_ACC_PUT(t, a0);
     }
     __syncthreads();                                    // X: all source reads done before the first store
     zero_fill();
@@ -1140,8 +1161,10 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
 #pragma unroll
             for (int g = 0; g < 4; ++g) X[g] = Dt[(lr + 4 * g) * 16 + lc];
           } else {
+            v4d S;
+            RL_ACC_GET(t, S);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) X = gmfma(Ri[(4 * s + lr) * 16 + lc], acc[t][s], X);
+            for (int s = 0; s < 4; ++s) X = gmfma(Ri[(4 * s + lr) * 16 + lc], S[s], X);
           }
           const double sj = sq[16 * j + lc];
           const double dj = dl[16 * j + lc];
@@ -1164,10 +1187,13 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
       for (int t = 0; t < SL; ++t) {
         if (ti[t] == kb + 1 && tj[t] == kb + 1) {
           const double* Ra = Rrow + ti[t] * 256 + lr * 16 + lc;
+          v4d S;
+          RL_ACC_GET(t, S);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc[t] = gmfma(-Ra[64 * s], Ra[64 * s], acc[t]);
+          for (int s = 0; s < 4; ++s) S = gmfma(-Ra[64 * s], Ra[64 * s], S);
+          RL_ACC_PUT(t, S);
 #pragma unroll
-          for (int g = 0; g < 4; ++g) Dt[(lr + 4 * g) * 16 + lc] = acc[t][g];
+          for (int g = 0; g < 4; ++g) Dt[(lr + 4 * g) * 16 + lc] = S[g];
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           if (lane == 0) __hip_atomic_store(&flagsh, kb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -1177,11 +1203,16 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
         if (ti[t] > kb && !(ti[t] == kb + 1 && tj[t] == kb + 1)) {
           const double* Ra = Rrow + ti[t] * 256 + lr * 16 + lc;
           const double* Rb = Rrow + tj[t] * 256 + lr * 16 + lc;
+          v4d S;
+          RL_ACC_GET(t, S);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc[t] = gmfma(-Ra[64 * s], Rb[64 * s], acc[t]);
+          for (int s = 0; s < 4; ++s) S = gmfma(-Ra[64 * s], Rb[64 * s], S);
+          RL_ACC_PUT(t, S);
         }
       }
     }
+#undef RL_ACC_GET
+#undef RL_ACC_PUT
   }
   __syncthreads();
   if (tid == 0 && a.fb_mask) {
@@ -1475,11 +1506,12 @@ hipError_t launch_gram_chol(const GramCholArgs& a_in, int B, hipStream_t s) {
     constexpr int ncu = 256;                           // MI355X: 8 XCDs x 32 CUs
     const bool rl = rl_env >= 0 ? rl_env != 0 : (a.expect > 0 ? a.expect : B) <= ncu;
     if (rl) {
-      const size_t lds = per + sizeof(double) * 256 * (size_t)(a.NPAD / 16);
+      constexpr int RL_KL = 8;                          // tile slots per worker wave kept in LDS
+      const size_t lds = per + sizeof(double) * 256 * ((size_t)(a.NPAD / 16) + (size_t)RL_KL * (GR_NW - 1));
       static std::atomic<size_t> granted[64];
-      hipError_t ge = gram_grant_lds(gram_chol_rl_kernel<22>, lds, granted);
+      hipError_t ge = gram_grant_lds(gram_chol_rl_kernel<22, RL_KL>, lds, granted);
       if (ge != hipSuccess) return ge;
-      hipLaunchKernelGGL(gram_chol_rl_kernel<22>, dim3(B), dim3(GR_NT), lds, s, a);
+      hipLaunchKernelGGL((gram_chol_rl_kernel<22, RL_KL>), dim3(B), dim3(GR_NT), lds, s, a);
     } else {
       hipLaunchKernelGGL(gram_chol_kernel<8>, dim3(B), dim3(GR_NT), per, s, a);
     }
