@@ -1285,13 +1285,15 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_cond_kernel(GramCholArgs a) {
   // ---- ||R'||_1 (thread per column) and ||R'||_inf (wave per row) ----
   double r1 = 0.0;
   for (int j = tid; j < n; j += PT) {
+    // (32 rows of loads in flight per pass: the passes are serialised by their waits, and the longest
+    //  column has n rows; same order of additions as a plain loop over the rows)
     double sum = 0.0;
-    for (int i0 = 0; i0 <= j; i0 += 8) {
-      double rv[8];
+    for (int i0 = 0; i0 <= j; i0 += 32) {
+      double rv[32];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) rv[u] = T[(long)((i0 + u <= j) ? i0 + u : j) * NPAD + j];
+      for (int u = 0; u < 32; ++u) rv[u] = T[(long)((i0 + u <= j) ? i0 + u : j) * NPAD + j];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) if (i0 + u <= j) sum += fabs(rv[u]);
+      for (int u = 0; u < 32; ++u) if (i0 + u <= j) sum += fabs(rv[u]);
     }
     r1 = fmax(r1, sum * dl[j]);
   }
@@ -1308,11 +1310,31 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_cond_kernel(GramCholArgs a) {
       if (lc == 0 && i < n) rowsR[i] = sum;
     }
   } else {
-    for (int i = w; i < n; i += NWP) {
-      double sum = 0.0;
-      for (int j = i + lane; j < n; j += WAVE) sum += fabs(T[(long)i * NPAD + j]) * dl[j];
-      sum = wave_sum(sum);
-      if (lane == 0) rowsR[i] = sum;
+    // four rows of a wave per pass, their loads issued together (clamped, unconditional; n <= 256: at
+    // most four 64-lane chunks per row); per lane the same additions in the same order as row by row
+    for (int i0 = w; i0 < n; i0 += 4 * NWP) {
+      double rv[4][4], dv[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = (i0 + NWP * q < n) ? i0 + NWP * q : n - 1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int j = i + lane + WAVE * c;
+          const int jc = j < n ? j : n - 1;
+          rv[q][c] = T[(long)i * NPAD + jc];
+          dv[q][c] = dl[jc];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + NWP * q;
+        double sum = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (i < n && i + lane + WAVE * c < n) sum += fabs(rv[q][c]) * dv[q][c];
+        sum = wave_sum(sum);
+        if (lane == 0 && i < n) rowsR[i] = sum;
+      }
     }
   }
   psync();
