@@ -48,12 +48,14 @@ __device__ __forceinline__ void tri_mtv(const double* R, int n, int ld, const do
                                         double* u) {
   for (int j = threadIdx.x; j < n; j += TRI_NT) {
     double acc = 0.0;
-    for (int i0 = 0; i0 <= j; i0 += 8) {    // 8 rows per pass, unconditional (clamped) loads in flight together
-      double rv[8];
+    // 32 rows per pass, unconditional (clamped) loads in flight together: the passes are serialised by
+    // their waits, and the longest column has n rows (8 per pass: 32 round trips at n = 256)
+    for (int i0 = 0; i0 <= j; i0 += 32) {
+      double rv[32];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) rv[k] = R[(long)((i0 + k <= j) ? i0 + k : j) * ld + j];
+      for (int k = 0; k < 32; ++k) rv[k] = R[(long)((i0 + k <= j) ? i0 + k : j) * ld + j];
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
+      for (int k = 0; k < 32; ++k)
         if (i0 + k <= j) acc = fma(rv[k], s[i0 + k], acc);
     }
     u[j] = acc;
