@@ -745,6 +745,7 @@ int trf_alloc_state(blsq_trf_plan* p) {
     LmState& lm = p->lm;
     lm.B = B; lm.m = p->m_total; lm.n = p->n; lm.ld = ld;
     lm.Raug = p->X.as<double>(); lm.sa = p->lm_sa.as<double>(); lm.Xa = p->lm_Xa.as<double>();
+    lm.g_h = p->st.g_h;
     int* ii = p->lm_ints.as<int>();
     lm.fast = ii; lm.ncols_jac = ii + B; lm.ncols_lm = ii + 2 * (size_t)B; lm.st = ii + 3 * (size_t)B;
     lm.active_count = ii + 7 * (size_t)B;

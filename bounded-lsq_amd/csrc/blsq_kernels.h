@@ -227,6 +227,9 @@ struct LmState {
   const int* path;        // optional [B]: != 0 -> the problem's Newton systems are factored by QR,
                           // 0 -> by Cholesky of the modified Gram (nullptr: QR for all)
   int round;              // evaluation number of this launch (host-set)
+  const double* g_h;      // optional [B][ld]: the gradient of the scaled problem, d * (J^T f) (TrfState::g_h).
+                          // ||A^T b|| of trust_region.py:119 for the augmented A = [J D; E], b = [f; 0] IS its
+                          // norm; without it lm_start forms R_aug^T c_aug — one more pass over the triangle
   int fused_gram;         // 1: problems with path[b] == 0 belong to lm_rounds_reg_kernel (N <= 80) — lm_start
                           // and the round kernels leave them alone (a problem's arithmetic must not depend
                           // on whether its batch also holds Householder-path problems)

@@ -174,8 +174,15 @@ __global__ __launch_bounds__(TRI_NT) void lm_start_kernel(LmState lm, const doub
   for (int i = tid; i < n; i += TRI_NT) p[i] = R[(long)i * ld + n];     // c_aug
   __syncthreads();
   // alpha_upper = ||A^T b|| / Delta
-  tri_mtv(R, n, ld, p, q);
-  const double gnorm = sqrt(tri_dot(q, q, n, red));
+  double gnorm;
+  if (lm.g_h) {                               // A^T b = D J^T f: known since the prep kernel
+    for (int i = tid; i < n; i += TRI_NT) q[i] = lm.g_h[(long)b * ld + i];
+    __syncthreads();
+    gnorm = sqrt(tri_dot(q, q, n, red));
+  } else {
+    tri_mtv(R, n, ld, p, q);
+    gnorm = sqrt(tri_dot(q, q, n, red));
+  }
   tri_solve_upper_pf(R, n, ld, invd, p, pfbuf);                           // R^{-1} c
   const double pn = sqrt(tri_dot(p, p, n, red));
   for (int i = tid; i < n; i += TRI_NT) {
