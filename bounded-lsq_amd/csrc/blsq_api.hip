@@ -740,6 +740,7 @@ int trf_alloc_state(blsq_trf_plan* p) {
   ALLOC(p->lm_sc, sizeof(double) * (size_t)B * 16);
   ALLOC(p->lm_ph, sizeof(double) * vs);
   HIPCHK(ctx, hipMemsetAsync(p->lm_sa.p, 0, p->lm_sa.bytes, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(p->lm_Xa.p, 0, p->lm_Xa.bytes, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(p->lm_ints.p, 0, p->lm_ints.bytes, ctx->stream));
   {
     LmState& lm = p->lm;
@@ -1066,6 +1067,7 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
     c.batch_list = p->lm.active_list + (size_t)(round & 1) * p->B;
     c.skip_path = p->path;
     c.count_dev = count_dev; c.expect = expect;
+    c.skip_zero = 1;                                    // (lm_Xa: zeroed at allocation, read by lm_update's solves only)
     ctx->begin(K_LM_CHOL);
     hipError_t ee = launch_gram_chol(c, grid, ctx->stream);
     ctx->end();

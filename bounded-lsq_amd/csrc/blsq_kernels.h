@@ -77,6 +77,9 @@ struct GramCholArgs {
   long stride_vec;
   const int* batch_list;  // optional compacted problem indices (grid = their number)
   int count;              // problems of this launch (set by launch_gram_chol)
+  int skip_zero;          // 1: the part of the slot outside the factor is not written (the caller's buffer holds
+                          // zeros there and its readers never look: the Newton-round factors, read by the
+                          // triangular solves only) — half of the bytes a factorisation stores are those zeros
   const int* count_dev;   // optional [1]: the launch is over an upper bound; entries beyond *count_dev leave
   int expect;             // > 0: number of problems the launch is expected to work on (kernel choice; default: its size)
   // optional principal sub-matrix (dogbox: free columns ++ rhs): H = Gsrc[idx, idx] with

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
     }
   }
   // strictly lower tiles are part of the triangle's image: zero
-  for (int r = 16 + w; r < NPAD; r += NWP) {
+  for (int r = 16 + w; r < (a.skip_zero ? 0 : NPAD); r += NWP) {
     const int cend = r & ~15;
     for (int c = lane; c < cend; c += WAVE) Gb[(long)r * NPAD + c] = 0.0;
   }
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
     }
     psync();
   }
-  if (16 * NT < NPAD) {                                  // sub-matrix: the rest of the slot is zero
+  if (16 * NT < NPAD && !a.skip_zero) {                  // sub-matrix: the rest of the slot is zero
     for (int r = w; r < NPAD; r += NWP) {
       const int c0 = (r < 16 * NT) ? 16 * NT : (r & ~15);
       for (int c = c0 + lane; c < NPAD; c += WAVE) Gb[(long)r * NPAD + c] = 0.0;
@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
   const int ntile = NT * (NT + 1) / 2;
   // zeros outside the factor: strictly lower tiles, and everything beyond 16 NT (sub-matrix use)
   auto zero_fill = [&]() {
-    for (int r = w; r < NPAD; r += GR_NW) {
+    for (int r = w; r < (a.skip_zero ? 0 : NPAD); r += GR_NW) {
       const int cend = (r < 16 * NT) ? (r & ~15) : NPAD;
       for (int c = lane; c < cend; c += WAVE) Gb[(unsigned)(r * NPAD + c)] = 0.0;
       if (r < 16 * NT)
