@@ -464,6 +464,10 @@ struct blsq_trf_plan {
   int lm_enable = 1;                // SVD-free trust-region path allowed at all (BLSQ_NO_SVDFREE)
   int lm_gate_mask = 3;             // launch_lm_gate: bit 0 Householder-path problems, bit 1 normal-equations-path problems
   bool gate_done = false;           // lm_gate already ran in this factor call (no problem left the normal-equations path)
+  // The triangle slots st.X hold zeros outside the factors as long as only the Cholesky kernels have
+  // written them (zeroed at allocation); the stacked QR and the Jacobi SVD write there.  While clean, the
+  // Cholesky of the augmented system does not store those zeros again (half of its bytes).
+  bool x_dirty = true;
   int lm_expect0 = 0;               // problems the first Newton round of the last step call worked on (kernel choice hint)
   int njac = -1;                    // problems it sent to the Jacobi SVD (-1: unknown)
   // Optimistic verdict (blsq_trf_factor_dev): the factor call does not wait for the gate's two counters;
@@ -786,6 +790,7 @@ int trf_alloc_state(blsq_trf_plan* p) {
 int trf_finish(blsq_trf_plan* p) {
   blsq_ctx* ctx = p->ctx;
   hipError_t e;
+  if (p->use_qr || p->njac != 0 || !p->gate_done) p->x_dirty = true;   // (a stacked QR or a Jacobi launch may follow)
   if (p->use_qr) {
     QrArgs q = p->tree.base_args();
     q.ncols_dev = p->path;                // (nullptr: all problems)
@@ -892,7 +897,9 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, 
   hipError_t e = launch_trf_prep(p->st, scale_mode, 1, mask, 0, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_trf_prep(gram)");
-  const GramCholArgs c = trf_chol_args(p, mask);
+  GramCholArgs c = trf_chol_args(p, mask);
+  c.skip_zero = p->x_dirty ? 0 : 1;
+  if (!mask) p->x_dirty = false;                        // (every slot is rewritten, zeros included, by this launch)
   ctx->begin(K_AUG_CHOL);
   e = launch_gram_chol(c, p->B, ctx->stream);
   ctx->end();

@@ -555,6 +555,36 @@ def test_direct_kernel_wave_counts(bl, monkeypatch):
             assert np.array_equal(outs[nw][2], outs["8"][2]), (m, n, nw)
 
 
+def test_zeros_outside_the_factor_are_stored_only_when_needed(bl):
+    """N > 80: the Cholesky of the augmented system does not store the zeros outside the triangle while
+    the plan knows they are still there (only the stacked QR and the Jacobi SVD write into that part of
+    the slots); the Newton-round factors never store them.  A plan that goes clean -> dirty (a problem for
+    the Householder tree, a rank-deficient one for the SVD) -> clean again gives, call by call, the bits of
+    a fresh plan."""
+    from bounded_lsq import _synth
+    B, m, n = 5, 900, 130
+    good = _synth.trf_batch(530, B, m, n)
+    other = _synth.trf_batch(531, B, m, n)
+    hard = {k: v.copy() for k, v in good.items()}
+    hard["J"][1] = _equicorrelated(1, m, n, 1 - 1e-9, 3)[0]
+    hard["lb"][1] = -np.inf; hard["ub"][1] = np.inf
+    hard["J"][3][:, n - 1] = hard["J"][3][:, 0]
+    hard["lb"][3] = -np.inf; hard["ub"][3] = np.inf
+    Delta = np.array([0.5, 0.05, 5.0, 0.2, 0.3])
+    sol = bl.TrfStepSolver(B, m, n)
+    for call, P in enumerate([good, other, hard, good, other, hard, hard, good, good]):
+        outs = []
+        for s_ in (sol, bl.TrfStepSolver(B, m, n)):
+            s_.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+            S = s_.step(Delta, np.zeros(B))
+            outs.append((S.step.copy(), np.asarray(S.alpha).copy(), np.asarray(S.n_iter).copy(), S.hits.copy()))
+            if s_ is not sol:
+                s_.close()
+        for x1, x0 in zip(*outs):
+            assert np.array_equal(x1, x0, equal_nan=True), call
+    sol.close()
+
+
 def test_second_guess_of_the_trf_device_api(bl, monkeypatch):
     """N <= 80, TRF: after a call in which the Cholesky kernel settled every problem (first certificate
     bound + the rank gate's column-norm bound), the certificate and gate launches of the next call are
