@@ -27,8 +27,11 @@ dA = ctx.to_device(np.zeros(B))
 for gram in ("1", "0"):
     os.environ["BLSQ_GRAM"] = gram
     sol = TrfStepSolver(B, m, n, ctx=ctx)
-    sol.factor_dev(d["J"], d["f"], d["x"], d["lb"], d["ub"], d["scale"])
-    sol.step_dev(dD, dA)
-    ctx.sync()
+    # three step-solves on the normal-equations path: the first launch of a kernel is cold (code
+    # object load, clocks ramping, first touch of its buffers) and tools/pmc_mfma.py leaves it out
+    for _ in range(3 if gram == "1" else 1):
+        sol.factor_dev(d["J"], d["f"], d["x"], d["lb"], d["ub"], d["scale"])
+        sol.step_dev(dD, dA)
+        ctx.sync()
     sol.close()
 print(json.dumps(info))
