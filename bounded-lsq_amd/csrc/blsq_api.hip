@@ -464,11 +464,13 @@ struct blsq_trf_plan {
   int lm_enable = 1;                // SVD-free trust-region path allowed at all (BLSQ_NO_SVDFREE)
   int lm_gate_mask = 3;             // launch_lm_gate: bit 0 Householder-path problems, bit 1 normal-equations-path problems
   bool gate_done = false;           // lm_gate already ran in this factor call (no problem left the normal-equations path)
+  bool lm_counts_clean = false;     // the Newton-round counters are zero (left so by the last step kernel)
   // The triangle slots st.X hold zeros outside the factors as long as only the Cholesky kernels have
   // written them (zeroed at allocation); the stacked QR and the Jacobi SVD write there.  While clean, the
   // Cholesky of the augmented system does not store those zeros again (half of its bytes).
   bool x_dirty = true;
   int lm_expect0 = 0;               // problems the first Newton round of the last step call worked on (kernel choice hint)
+  int lm_rounds_last = 12;          // Newton rounds that had work in the last step call (run-ahead only over those)
   int njac = -1;                    // problems it sent to the Jacobi SVD (-1: unknown)
   // Optimistic verdict (blsq_trf_factor_dev): the factor call does not wait for the gate's two counters;
   // it assumes "every problem stays on the normal-equations path, nobody needs the SVD", and the NEXT
@@ -1055,7 +1057,8 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
       p->lm.fused_gram = 1;
     }
   }
-  HIPCHK(ctx, hipMemsetAsync(counts, 0, 16 * sizeof(int), ctx->stream));
+  if (!p->lm_counts_clean) HIPCHK(ctx, hipMemsetAsync(counts, 0, 16 * sizeof(int), ctx->stream));
+  p->lm_counts_clean = false;
   ctx->begin(K_LM_SOLVE);
   e = launch_lm_start(p->lm, dDelta, dalpha_in, ctx->stream);
   ctx->end();
@@ -1084,13 +1087,20 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
   if (!p->use_qr && p->use_chol && p->lm_enable) {
     int bound = p->B;                                   // upper bound of the count of the round being enqueued
     int expect = p->lm_expect0 > 0 ? p->lm_expect0 : p->B;   // (kernel choice only: last call's first count)
-    if (p->lm_expect0 < 0) {
-      // the last call needed no round at all: look before launching an empty one
-      HIPCHK(ctx, hipEventSynchronize(ctx->lm_ev[0]));
-      if (pin[0] == 0) return 0;
-      bound = expect = pin[0];
-    }
+    // Rounds that had work in the LAST call of this plan are enqueued ahead of their counter, as described
+    // above; from the first round that was empty last time on, the host looks at the counter first — the
+    // GPU idles for one host round trip (~10 us) instead of running a round of three empty launches.
+    const int ahead_rounds = p->lm_rounds_last;
+    int done_rounds = 0;
     for (int round = 0; round < 12; ++round) {
+      const bool ahead = round < ahead_rounds;
+      if (!ahead) {
+        HIPCHK(ctx, hipEventSynchronize(ctx->lm_ev[round & 1]));
+        const int active = pin[round];
+        if (round == 0) p->lm_expect0 = active > 0 ? active : -1;
+        if (active == 0) break;
+        bound = expect = active;
+      }
       e = chol_round(round, bound, expect, counts + round);
       if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(lm)");
       ctx->begin(K_LM_SOLVE);
@@ -1099,12 +1109,16 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
       ctx->end();
       if (e != hipSuccess) return ctx->fail(e, "launch_lm_update");
       HIPCHK(ctx, read_back(round + 1));
-      HIPCHK(ctx, hipEventSynchronize(ctx->lm_ev[round & 1]));
-      const int active = pin[round];                    // what round `round` really worked on
-      if (round == 0) p->lm_expect0 = active > 0 ? active : -1;
-      if (active == 0) break;                           // (the round just enqueued is empty)
-      bound = expect = active;
+      if (ahead) {
+        HIPCHK(ctx, hipEventSynchronize(ctx->lm_ev[round & 1]));
+        const int active = pin[round];                  // what round `round` really worked on
+        if (round == 0) p->lm_expect0 = active > 0 ? active : -1;
+        if (active == 0) break;                         // (the round just enqueued is empty)
+        bound = expect = active;
+      }
+      done_rounds = round + 1;
     }
+    p->lm_rounds_last = done_rounds;
     return 0;
   }
   HIPCHK(ctx, hipEventSynchronize(ctx->lm_ev[0]));
@@ -1245,6 +1259,7 @@ extern "C" int blsq_trf_step_dev(blsq_trf_plan* p, const double* dDelta, const d
                                    ctx->stream);
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_trf_step");
+    p->lm_counts_clean = true;              // (the step kernel leaves the round counters zeroed)
     bool redo = false;
     if ((rc = trf_resolve(p, &redo))) return rc;
     if (!redo) break;
