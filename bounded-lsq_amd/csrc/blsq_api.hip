@@ -1030,9 +1030,10 @@ int trf_resolve(blsq_trf_plan* p, bool* redo) {
 // the count to launch them — only an upper bound (the previous round's count).  When every problem
 // is on the normal-equations path the host therefore runs one round AHEAD of what it knows: it
 // enqueues round r, then waits for the counter of round r (written by round r - 1, i.e. while
-// round r executes).  The GPU never idles on a host round trip; the price is one round of empty
-// launches at the end.  Problems on the Householder path (stacked QR per round: several launches
-// sized by the count) keep the synchronous loop.
+// round r executes).  The GPU does not idle on a host round trip for the rounds that had work in the
+// plan's last call; from the first round that was empty then, the counter is read before the round is
+// enqueued (no round of empty launches at the end).  Problems on the Householder path (stacked QR per
+// round: several launches sized by the count) keep the synchronous loop.
 int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_in) {
   blsq_ctx* ctx = p->ctx;
   int* counts = p->lm.active_count;
