@@ -585,6 +585,32 @@ def test_zeros_outside_the_factor_are_stored_only_when_needed(bl):
     sol.close()
 
 
+def test_round_loop_follows_the_round_count_of_the_last_call(bl):
+    """N > 80: the Newton rounds are enqueued ahead of their counters only as far as the plan's LAST step
+    call had work; beyond that the host looks first.  Step calls whose round counts go 0 -> several ->
+    1 -> 0 -> several on one plan (trust radii from 'Gauss-Newton step inside' to 'far outside') give the
+    bits of a fresh plan, which runs ahead through every round."""
+    from bounded_lsq import _synth
+    B, m, n = 6, 900, 130
+    P = _synth.trf_batch(540, B, m, n)
+    sol = bl.TrfStepSolver(B, m, n)
+    sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+    seen = set()
+    for call, dl in enumerate([1e6, 1e-3, 0.3, 1e6, 1e-6, 0.05, 1e6, 1e6, 1e-2]):
+        Delta = np.full(B, dl)
+        S = sol.step(Delta, np.zeros(B))
+        ref = bl.TrfStepSolver(B, m, n)
+        ref.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+        R = ref.step(Delta, np.zeros(B))
+        ref.close()
+        for x1, x0 in ((S.step, R.step), (np.asarray(S.alpha), np.asarray(R.alpha)),
+                       (np.asarray(S.n_iter), np.asarray(R.n_iter)), (S.hits, R.hits)):
+            assert np.array_equal(x1, x0, equal_nan=True), call
+        seen.add(int(np.max(np.asarray(S.n_iter))))
+    sol.close()
+    assert 0 in seen and max(seen) >= 2, seen          # (the sequence really had calls without and with rounds)
+
+
 def test_second_guess_of_the_trf_device_api(bl, monkeypatch):
     """N <= 80, TRF: after a call in which the Cholesky kernel settled every problem (first certificate
     bound + the rank gate's column-norm bound), the certificate and gate launches of the next call are
