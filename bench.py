@@ -306,22 +306,36 @@ class Bench:
         return out
 
 
-def time_steps(bench, steps, warmup, fence):
+def time_steps(bench, steps, warmup, fence, min_time=0.0, reduce_max=None):
+    """W warm-up steps, then `steps` timed steps between two fences (barrier + device sync).
+    min_time > 0: if that region was shorter, it is repeated as ONE region of r x steps steps with
+    r = ceil(min_time / elapsed) — every rank derives r from the same max-over-ranks figure — and that
+    longer region is what is reported.  -> (elapsed of this rank, steps actually timed)"""
     ctx = bench.ctx
     for _ in range(warmup):
         bench.step()
-    fence()
-    ctx.timing(True)
-    ctx.timing_reset()
-    ctx.gram_stats(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        bench.step()
-    ctx.sync()
-    elapsed = time.perf_counter() - t0
-    fence()
-    ctx.timing(False)
-    return elapsed
+
+    def region(k):
+        fence()
+        ctx.timing(True)
+        ctx.timing_reset()
+        ctx.gram_stats(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(k):
+            bench.step()
+        ctx.sync()
+        el = time.perf_counter() - t0
+        fence()
+        ctx.timing(False)
+        return el
+    elapsed = region(steps)
+    if min_time > 0.0:
+        seen = reduce_max(elapsed) if reduce_max else elapsed
+        if seen < min_time:
+            reps = int(min(400, max(2, -(-min_time // max(seen, 1e-6)))))
+            steps = steps * reps
+            elapsed = region(steps)
+    return elapsed, steps
 
 
 def record(bench, cfg_name, elapsed, steps, warmup, world, probe):
@@ -399,7 +413,7 @@ def side_run(name, ctx, steps, warmup, probe, **kw):
     """A short run of another config on the same ctx -> compact record (never `value`)."""
     b = Bench(name, ctx, 0, 1, **kw)
     try:
-        el = time_steps(b, steps, warmup, ctx.sync)
+        el, steps = time_steps(b, steps, warmup, ctx.sync)
         r = record(b, name, el, steps, warmup, 1, probe)
         par = b.parity(2)
     finally:
@@ -449,6 +463,9 @@ def main():
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-pointer (PCIe-inclusive) leg")
     ap.add_argument("--no-probe", action="store_true", help="skip the measured-peak probes")
     ap.add_argument("--check", type=int, default=2, help="problems checked against the oracle")
+    ap.add_argument("--min-time", type=float, default=1.0,
+                    help="shortest timed region in seconds: a shorter --steps region is repeated as one region of "
+                         "r x steps steps (reported as `steps`, with `steps_requested`); 0: exactly --steps")
     args = ap.parse_args()
     name = args.config
     default_steps = {"c2": 250, "c2-single": 500, "c3": 400, "c4": 300, "c5": 400}[name]
@@ -517,6 +534,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def all_ranks(v):
+        """every rank's value, rank order (rank 0 reports them: the driver can check N = 1 against BENCH)"""
+        if dist is None:
+            return [v]
+        import torch
+        t = torch.tensor([v], dtype=torch.float64, device=tdev())
+        g = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(g, t)
+        return [float(x.item()) for x in g]
+
     probe = None
     if not args.no_probe:
         try:
@@ -532,11 +559,22 @@ def main():
         ctx.comm_init(world, rank, bcast_comm_id())
         comm_ready = True
     bench = Bench(name, ctx, rank, world, batch=args.batch, m=args.m, n=args.n, comm_ready=comm_ready)
-    elapsed = max_over_ranks(time_steps(bench, steps, warmup, fence))
+    steps_requested = steps
+    own_elapsed, steps = time_steps(bench, steps, warmup, fence, args.min_time, max_over_ranks)
+    elapsed = max_over_ranks(own_elapsed)
     out = record(bench, name, elapsed, steps, warmup, world, probe) if rank == 0 else None
+    per_rank = all_ranks(own_elapsed)
+    if out is not None:
+        out["steps_requested"] = steps_requested
+        units_rank = (1 if bench.kind == "tsqr" else bench.B) * steps
+        out["per_rank"] = {"elapsed_s": per_rank, "step_solves_per_s": [units_rank / e for e in per_rank],
+                           "note": "each rank's own clock over the same fenced region; `value` uses the max"}
+        if bench.kind == "tsqr" or comm_ready:
+            out["rccl"] = ctx.comm_info()
     parity = bench.parity(args.check) if (rank == 0 and args.check > 0) else None
 
     extras = {}
+    side_hung = False
     if world == 1 and main_line:
         B, m, n = bench.B, bench.m, bench.n
         if not args.no_householder:
@@ -545,8 +583,8 @@ def main():
             os.environ["BLSQ_GRAM"] = "0"                      # read when a plan is created
             bh = Bench(name, ctx, 0, 1, batch=args.batch)
             os.environ.pop("BLSQ_GRAM", None)
-            kh = max(2, min(steps, 20))
-            eh = time_steps(bh, kh, 1, ctx.sync)
+            kh = max(2, min(steps_requested, 20))
+            eh, kh = time_steps(bh, kh, 1, ctx.sync)
             extras["householder_only"] = {
                 "value": B * kh / eh, "unit": "step-solves/s", "ms_per_step": 1e3 * eh / kh, "steps": kh,
                 "kernels_ms_per_step": {k: round(v[0] / kh, 4) for k, v in ctx.timing_read().items() if v[0] > 0},
@@ -574,8 +612,8 @@ def main():
                 P["ub"][:] = np.inf
             for key, mut in (("mixed_conditioning", mixed), ("mixed_conditioning_unbounded", mixed_unbounded)):
                 bm = Bench(name, ctx, 0, 1, batch=args.batch, mutate=mut)
-                km = max(2, min(steps, 20))
-                em = time_steps(bm, km, 1, ctx.sync)
+                km = max(2, min(steps_requested, 20))
+                em, km = time_steps(bm, km, 1, ctx.sync)
                 gsm = ctx.gram_stats()
                 extras[key] = {
                     "value": B * km / em, "unit": "step-solves/s", "ms_per_step": 1e3 * em / km, "steps": km,
@@ -607,6 +645,7 @@ def main():
                 side[sn], hung = with_timeout(lambda sn=sn, ks=ks: side_run(sn, ctx, ks, 3, probe), 180,
                                               "side config " + sn)
                 if hung:
+                    side_hung = True
                     break
             extras["side_configs"] = side
     if world > 1 and main_line and not args.no_side:
@@ -617,8 +656,10 @@ def main():
             b5 = Bench("c5", ctx, rank, world, comm_ready=True)
             try:
                 k5 = 100
-                e5 = max_over_ranks(time_steps(b5, k5, 5, fence))
+                e5, k5 = time_steps(b5, k5, 5, fence)
+                e5 = max_over_ranks(e5)
                 r5 = record(b5, "c5", e5, k5, 5, world, probe) if rank == 0 else None
+                info5 = ctx.comm_info()
             finally:
                 b5.close()
             if r5 is None:
@@ -628,7 +669,8 @@ def main():
                     "steps": k5, "kernels_ms_per_step": r5["kernels_ms_per_step"],
                     "mfma_ceiling_frac_survey": r5["value"] * alg_flops("trf", 250_000 * world, 128)
                     / (PEAK_FP64_TFLOPS * 1e12 * world),
-                    "collective": "ncclAllReduce(sum) of the 144 x 144 Gram on the library's stream"}
+                    "collective": "ncclAllReduce(sum) of the 144 x 144 Gram on the library's stream",
+                    "rccl": info5}
         c5, hung = with_timeout(c5_leg, 240, "c5 over RCCL")
         if rank == 0:
             extras["c5_tsqr"] = c5
@@ -642,14 +684,35 @@ def main():
                 out["parity"] = parity
                 print(json.dumps(out), flush=True)
             sys.stdout.flush()
-            os._exit(0)
+            # non-zero: the launcher must see a failed multi-GPU leg as a failure.  No further GPU call on
+            # this ctx (a helper thread may still sit in the stuck collective), no teardown, no re-exec.
+            os._exit(3)
 
     if rank == 0:
         out.update(extras)
         out["cpu_baseline"] = cpu
         out["speedup_vs_cpu"] = (out["value"] / cpu["value"]) if cpu else None
         out["parity"] = parity
+        # compact digest of the side figures as the LAST key (a log tail of 2000 characters keeps it):
+        # name -> [step-solves/s, ms per step, roofline fraction of the dominant kernel or null]
+        digest = {}
+        for k, v in (extras.get("side_configs") or {}).items():
+            if isinstance(v, dict) and "value" in v:
+                digest[k] = [round(v["value"], 1), round(v["ms_per_step"], 4), round(v["roofline"]["frac"], 3)]
+            else:
+                digest[k] = v
+        for k in ("householder_only", "mixed_conditioning", "mixed_conditioning_unbounded", "h2d_inclusive"):
+            if k in extras:
+                digest[k] = [round(extras[k]["value"], 1), round(extras[k]["ms_per_step"], 4), None]
+        if "c5_tsqr" in extras and isinstance(extras["c5_tsqr"], dict) and "value" in extras["c5_tsqr"]:
+            digest["c5_tsqr"] = [round(extras["c5_tsqr"]["value"], 1), round(extras["c5_tsqr"]["ms_per_step"], 4), None]
+        out["side_summary"] = digest
         print(json.dumps(out), flush=True)
+    if side_hung:
+        # a side leg never came back: its helper thread still drives this ctx and stream, so nothing more
+        # is enqueued behind it (close() would wait on the stuck work) — the line is out, leave, non-zero
+        sys.stdout.flush()
+        os._exit(4)
     bench.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -62,6 +62,7 @@ SIGNATURES = {
     "blsq_comm_get_id": (C.c_int, [vp, vp, C.c_size_t]),
     "blsq_comm_init": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_size_t]),
     "blsq_comm_destroy": (C.c_int, [vp]),
+    "blsq_comm_library": (C.c_char_p, [c_int32_p]),
     "blsq_comm_size": (C.c_int, [vp]),
     "blsq_comm_rank": (C.c_int, [vp]),
     "blsq_comm_allreduce_max": (C.c_int, [vp, c_double_p, C.c_int]),
@@ -150,14 +151,23 @@ class Context:
             raise BlsqError("%s failed (%d): %s" % (what, rc, (msg or b"").decode()))
 
     def close(self):
-        if getattr(self, "h", None):
-            for pl in list(getattr(self, "_plans", ())):
+        """Close every adopted plan / driver, then destroy the context — exactly once: the plan set
+        is taken first, so a plan that owns this context and closes it from its own close()
+        (OuterDriver with ctx=None) finds nothing left to walk."""
+        if not getattr(self, "h", None) or getattr(self, "_closing", False):
+            return
+        self._closing = True
+        plans, self._plans = list(getattr(self, "_plans", ())), weakref.WeakSet()
+        try:
+            for pl in plans:                     # (plans destroy their handles through the live ctx)
                 try:
                     pl.close()
-                except Exception:
+                except (BlsqError, OSError, AttributeError):
                     pass
-            self.lib.blsq_ctx_destroy(self.h)
-            self.h = None
+        finally:
+            h, self.h = self.h, None
+            self._closing = False
+            self.lib.blsq_ctx_destroy(h)
 
     def __del__(self):
         try:
@@ -212,6 +222,14 @@ class Context:
         buf = C.create_string_buffer(bytes(comm_id), len(comm_id))
         self.check(self.lib.blsq_comm_init(self.h, int(nranks), int(rank), buf, len(comm_id)),
                    "blsq_comm_init")
+
+    def comm_info(self):
+        """-> dict(library=<path of the collective library in use>, version=<ncclGetVersion code>,
+        ranks=<size of this ctx's communicator>, rank=...)"""
+        v = C.c_int32(0)
+        path = self.lib.blsq_comm_library(C.byref(v))
+        return {"library": (path or b"").decode(), "version": int(v.value),
+                "ranks": int(self.lib.blsq_comm_size(self.h)), "rank": int(self.lib.blsq_comm_rank(self.h))}
 
     def comm_destroy(self):
         self.check(self.lib.blsq_comm_destroy(self.h), "blsq_comm_destroy")

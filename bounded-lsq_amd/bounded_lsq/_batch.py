@@ -38,7 +38,7 @@ def _bounds_2d(bounds, B, n):
 
 def least_squares_batch(fun, x0, jac, bounds=(-np.inf, np.inf), method='trf',
                         ftol=EPS ** 0.5, xtol=EPS ** 0.5, gtol=EPS ** 0.5, max_nfev=None,
-                        scaling=1.0, diff_step=None, args=(), kwargs={}, ctx=None, driver='host'):
+                        scaling=1.0, diff_step=None, args=(), kwargs=None, ctx=None, driver='host'):
     """Solve B bound-constrained least-squares problems of identical shape.
 
     fun : callable, ``fun(X) -> (B, m)`` residuals for ``X`` (B, n)
@@ -60,6 +60,7 @@ def least_squares_batch(fun, x0, jac, bounds=(-np.inf, np.inf), method='trf',
     lb, ub = _bounds_2d(bounds, B, n)
     if not callable(fun):
         raise ValueError("`fun` must be callable (vectorised over the batch).")
+    kwargs = dict(kwargs) if kwargs else {}
     if args or kwargs:                                        # least_squares.py:351-355, 367-371
         user_fun, user_jac = fun, jac
 

@@ -41,31 +41,52 @@ def tri_ld(n):
 
 
 def exchange_id_tcp(rank, world, addr, port, make_id, timeout=120.0):
-    """Rank 0 calls ``make_id()`` (-> bytes) and serves it to the other world - 1 ranks on
-    (addr, port); they connect (retrying until `timeout`) and receive it.  Returns the id on
-    every rank.  Plain sockets: no dependency beyond the standard library."""
+    """Rank 0 calls ``make_id()`` (-> bytes) and serves it on (addr, port); every other rank connects
+    (retrying while the server is not up yet), names itself by its rank and receives the id.  Each
+    rank is served exactly once, all of them within ONE deadline of `timeout` seconds; a connection
+    that does not name a rank still missing is dropped without consuming a slot.  Returns the id on
+    every rank.  Plain sockets: no dependency beyond the standard library.  (The id is a rendezvous
+    token for processes of one job on one host or fabric, not a secret.)"""
     rank, world = int(rank), int(world)
+    deadline = time.time() + timeout
     if rank == 0:
         payload = bytes(make_id())
         if world == 1:
             return payload
+        missing = set(range(1, world))
         with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind((addr, int(port)))
             srv.listen(world)
-            srv.settimeout(timeout)
-            for _ in range(world - 1):
-                conn, _peer = srv.accept()
+            while missing:
+                left = deadline - time.time()
+                if left <= 0:
+                    raise TimeoutError("ranks %s did not fetch the communicator id within %.0f s"
+                                       % (sorted(missing), timeout))
+                srv.settimeout(left)
+                try:
+                    conn, _peer = srv.accept()
+                except socket.timeout:
+                    continue
                 with conn:
-                    conn.sendall(struct.pack("<I", len(payload)) + payload)
+                    try:
+                        conn.settimeout(min(5.0, max(0.1, deadline - time.time())))
+                        who = struct.unpack("<I", _recv_exact(conn, 4))[0]
+                        if who not in missing:
+                            continue                       # stranger or duplicate: no slot consumed
+                        conn.sendall(struct.pack("<I", len(payload)) + payload)
+                        missing.discard(who)
+                    except (ConnectionError, socket.timeout, struct.error):
+                        continue                           # that rank will come again
         return payload
-    deadline = time.time() + timeout
     while True:
         try:
             with socket.create_connection((addr, int(port)), timeout=5.0) as sk:
+                sk.settimeout(max(0.1, deadline - time.time()))
+                sk.sendall(struct.pack("<I", rank))
                 head = _recv_exact(sk, 4)
                 return _recv_exact(sk, struct.unpack("<I", head)[0])
-        except (ConnectionRefusedError, socket.timeout, OSError):
+        except (ConnectionRefusedError, socket.timeout):   # server not up yet / slow: try again
             if time.time() > deadline:
                 raise
             time.sleep(0.05)

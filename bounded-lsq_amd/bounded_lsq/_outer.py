@@ -30,7 +30,8 @@ def raise_step_errors(status):
     bad = np.nonzero(np.asarray(status) < 0)[0]
     if bad.size:
         b = int(bad[0])
-        raise ValueError("problem %d: %s" % (b, STATUS_MESSAGES[-int(status[b])]))
+        code = -int(status[b])
+        raise ValueError("problem %d: %s" % (b, STATUS_MESSAGES.get(code, "step status %d" % code)))
 
 
 class OuterDriver:
@@ -51,13 +52,13 @@ class OuterDriver:
         self.ctx.adopt(self)
 
     def close(self):
-        if getattr(self, "h", None):
-            if self.ctx is not None and getattr(self.ctx, "h", None):
-                self.ctx.lib.blsq_outer_destroy(self.h)
-            self.h = None
-        if self._own_ctx and self.ctx is not None:
-            self.ctx.close()
-            self.ctx = None
+        h, self.h = getattr(self, "h", None), None
+        ctx = self.ctx
+        if h and ctx is not None and getattr(ctx, "h", None):
+            ctx.lib.blsq_outer_destroy(h)
+        if self._own_ctx and ctx is not None:
+            self.ctx = None                      # (before ctx.close(): it walks its plans, this one included)
+            ctx.close()
 
     def __enter__(self):
         return self

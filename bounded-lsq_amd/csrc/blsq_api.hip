@@ -56,6 +56,10 @@ struct blsq_ctx {
   // collective over the ranks of one tall problem (RCCL over xGMI; blsq_comm_*)
   ncclComm_t comm = nullptr;
   int comm_ranks = 1, comm_rank = 0;
+  // plans of this ctx (an optimistic factor call leaves a verdict pending on its plan: blsq_sync and
+  // the calls that may invalidate the caller's J resolve it, see ctx_resolve_pending)
+  std::vector<blsq_trf_plan*> trf_plans;
+  std::vector<blsq_dogbox_plan*> dog_plans;
 
   int fail(hipError_t e, const char* where) {
     err = std::string(where) + ": " + hipGetErrorString(e);
@@ -116,12 +120,16 @@ struct Rccl {
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
-  std::string err;
+  decltype(&ncclGetVersion) GetVersion = nullptr;     // optional
+  std::string err, path;
   bool load() {
     if (lib) return true;
     std::vector<std::string> cand;
     Dl_info info;
-    if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+    // BLSQ_RCCL_PATH: this library and no other (a wrong path is an error, not a reason to look elsewhere)
+    const char* forced = getenv("BLSQ_RCCL_PATH");
+    if (forced && forced[0]) cand.push_back(forced);
+    else if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
       std::string dir(info.dli_fname);
       const size_t k = dir.rfind('/');
       if (k != std::string::npos) {
@@ -130,11 +138,13 @@ struct Rccl {
         cand.push_back(dir + "/librccl.so");
       }
     }
-    cand.push_back("librccl.so.1");
-    cand.push_back("/opt/rocm/lib/librccl.so.1");
+    if (!(forced && forced[0])) {
+      cand.push_back("librccl.so.1");
+      cand.push_back("/opt/rocm/lib/librccl.so.1");
+    }
     for (const auto& c : cand) {
       lib = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
-      if (lib) break;
+      if (lib) { path = c; break; }
     }
     if (!lib) { err = std::string("dlopen(librccl): ") + dlerror(); return false; }
 #define BLSQ_RCCL_SYM(name)                                                 \
@@ -143,6 +153,11 @@ struct Rccl {
     BLSQ_RCCL_SYM(GetUniqueId) BLSQ_RCCL_SYM(CommInitRank) BLSQ_RCCL_SYM(CommDestroy)
     BLSQ_RCCL_SYM(AllGather) BLSQ_RCCL_SYM(AllReduce) BLSQ_RCCL_SYM(GetErrorString)
 #undef BLSQ_RCCL_SYM
+    GetVersion = reinterpret_cast<decltype(GetVersion)>(dlsym(lib, "ncclGetVersion"));
+    {                                                  // the resolved file, not the name it was asked by
+      Dl_info li;
+      if (dladdr((void*)GetUniqueId, &li) && li.dli_fname) path = li.dli_fname;
+    }
     return true;
   }
 };
@@ -448,6 +463,7 @@ struct blsq_trf_plan {
   DevBuf aug_colinfo;               // [B][2] column-norm summary of R_aug (Gram-path problems)
   // TSQR (multi-rank) extras
   int nranks = 1, m_total = 0;
+  bool ranks_agreed = false;        // the ranks have compared their plan configuration (first factor call)
   DevBuf Rcomb;                     // [1][NPAD*NPAD] merged triangle
   DevBuf Rstack;                    // [nranks][NPAD*NPAD] gathered triangles (blsq_tsqr_factor_dev)
   // n-space state
@@ -562,8 +578,14 @@ extern "C" const char* blsq_last_error(const blsq_ctx* ctx) {
   return ctx ? ctx->err.c_str() : "null ctx";
 }
 
+// Every verdict an optimistic factor call left pending on a plan of this ctx is read, and a wrong guess
+// repaired (Householder tree on the caller's J, which is why this runs in blsq_sync and before the
+// library frees or overwrites device memory: after blsq_sync nothing of the caller's J / f is read again).
+static int ctx_resolve_pending(blsq_ctx* ctx);
+
 extern "C" int blsq_sync(blsq_ctx* ctx) {
   if (!ctx) return -1;
+  { int rc_ = ctx_resolve_pending(ctx); if (rc_) return rc_; }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->collect();
   return 0;
@@ -610,6 +632,13 @@ extern "C" int blsq_comm_destroy(blsq_ctx* ctx) {
   return 0;
 }
 
+extern "C" const char* blsq_comm_library(int* version_out) {
+  int v = 0;
+  if (g_rccl.lib && g_rccl.GetVersion) g_rccl.GetVersion(&v);
+  if (version_out) *version_out = v;
+  return g_rccl.path.c_str();
+}
+
 extern "C" int blsq_comm_size(const blsq_ctx* ctx) { return ctx ? ctx->comm_ranks : 0; }
 extern "C" int blsq_comm_rank(const blsq_ctx* ctx) { return ctx ? ctx->comm_rank : -1; }
 
@@ -645,11 +674,13 @@ extern "C" int blsq_dev_malloc(blsq_ctx* ctx, size_t bytes, void** dptr) {
 }
 extern "C" int blsq_dev_free(blsq_ctx* ctx, void* dptr) {
   if (!ctx) return -1;
+  { int rc_ = ctx_resolve_pending(ctx); if (rc_) return rc_; }   // (it may be the J of a pending verdict)
   HIPCHK(ctx, hipFree(dptr));
   return 0;
 }
 extern "C" int blsq_memcpy_h2d(blsq_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (!ctx) return -1;
+  { int rc_ = ctx_resolve_pending(ctx); if (rc_) return rc_; }   // (dst may be the J of a pending verdict)
   HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
@@ -833,7 +864,9 @@ int trf_finish(blsq_trf_plan* p) {
   return 0;
 }
 
-int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode) {
+// redo: the problems were prepared from their Gram already in this factor call — start again from the
+// scale the caller passed (a 'jac' scaling update is applied once, to the caller's vector)
+int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode, int redo = 0) {
   blsq_ctx* ctx = p->ctx;
   p->st.Rt = Rt; p->st.Gk = nullptr; p->st.path = nullptr;
   p->path = nullptr; p->use_chol = false; p->use_qr = true;
@@ -841,7 +874,7 @@ int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode) {
   p->tree.path_valid = false; p->tree.any_gram = false; p->tree.any_qr = true;
   p->gate_done = false;
   ctx->begin(K_PREP);
-  hipError_t e = launch_trf_prep(p->st, scale_mode, 0, nullptr, 0, ctx->stream);
+  hipError_t e = launch_trf_prep(p->st, scale_mode, 0, nullptr, redo, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_trf_prep");
   return trf_finish(p);
@@ -959,7 +992,18 @@ int trf_factor_core(blsq_trf_plan* p, const double* dJ, const double* df, int ld
                     const int* mask, bool may_defer = false) {
   blsq_ctx* ctx = p->ctx;
   int rc;
-  p->pending = false;                       // (a verdict nobody asked for belongs to an overwritten factor)
+  if (p->pending) {
+    // a verdict nobody asked for belongs to a factor that is being overwritten: no repair, but it is still
+    // read — the path statistics and the decision whether to guess again depend on it
+    p->pending = false;
+    HIPCHK(ctx, hipEventSynchronize(p->pend_ev));
+    const int nfb_ = p->pend_pin[0], njac_ = p->pend_pin[1];
+    if (p->pend_tail) { if (!(p->ld <= 80 && p->pend_pin[2] == 0)) p->guess_settled = false; }
+    else if (nfb_ > 0 || njac_ > 0) {
+      p->guess_ok = false;
+      ctx->gram_fast -= nfb_; ctx->gram_fallback += nfb_;
+    }
+  }
   if (!p->tree.gram) {
     if ((rc = p->tree.run_levels(ctx, dJ, df, ldJ, mask))) return rc;
     return trf_after_triangle(p, p->tree.Rfinal(), scale_mode);
@@ -1181,6 +1225,7 @@ extern "C" int blsq_trf_plan_create(blsq_ctx* ctx, int B, int m, int n, blsq_trf
   }
   if (rc != 0) { blsq_trf_plan_destroy(p); return rc; }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->trf_plans.push_back(p);
   *out = p;
   return 0;
 }
@@ -1188,6 +1233,7 @@ extern "C" int blsq_trf_plan_create(blsq_ctx* ctx, int B, int m, int n, blsq_trf
 extern "C" int blsq_trf_plan_destroy(blsq_trf_plan* p) {
   if (!p) return -1;
   hipStreamSynchronize(p->ctx->stream);
+  { auto& v = p->ctx->trf_plans; v.erase(std::remove(v.begin(), v.end(), p), v.end()); }
   if (p->pend_pin) hipHostFree(p->pend_pin);
   if (p->pend_ev) hipEventDestroy(p->pend_ev);
   p->tree.release(); p->Rcomb.release(); p->Rstack.release();
@@ -1449,6 +1495,7 @@ extern "C" int blsq_tsqr_plan_create(blsq_ctx* ctx, int m_local, long long m_tot
   }
   if (rc != 0) { blsq_trf_plan_destroy(p); return rc; }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->trf_plans.push_back(p);
   *out = p;
   return 0;
 }
@@ -1471,7 +1518,7 @@ extern "C" int blsq_tsqr_local_dev(blsq_trf_plan* p, const double* dJ_block,
 namespace {
 // merge the stack of nranks triangles (rank order) and run the n-space path on the result
 int tsqr_merge_and_finish(blsq_trf_plan* p, const double* dtri_stack, int scale_mode,
-                          double* dscale_io) {
+                          double* dscale_io, int redo = 0) {
   blsq_ctx* ctx = p->ctx;
   const int NPAD = p->ld;
   const double* src = dtri_stack;
@@ -1496,7 +1543,7 @@ int tsqr_merge_and_finish(blsq_trf_plan* p, const double* dtri_stack, int scale_
     flip ^= 1;
     ntri = nleaf;
   }
-  int rc = trf_after_triangle(p, src, scale_mode);
+  int rc = trf_after_triangle(p, src, scale_mode, redo);
   if (rc) return rc;
   if (scale_mode != BLSQ_SCALE_GIVEN) {
     HIPCHK(ctx, hipMemcpyAsync(dscale_io, p->st.scale, sizeof(double) * p->n,
@@ -1549,25 +1596,60 @@ extern "C" int blsq_tsqr_factor_dev(blsq_trf_plan* p, const double* dJ_block, co
                                  hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
   };
+  // max AND min over the ranks of a few integers (the ranks' copies must be equal): nv <= 4 values
+  auto agree = [&](const int* vals, int nv, const char* what) -> int {
+    double* d = p->Rstack.as<double>();                   // (free until the all-gather)
+    double h[8];
+    for (int i = 0; i < nv; ++i) { h[2 * i] = (double)vals[i]; h[2 * i + 1] = -(double)vals[i]; }
+    HIPCHK(ctx, hipMemcpyAsync(d, h, sizeof(double) * 2 * nv, hipMemcpyHostToDevice, ctx->stream));
+    RCCLCHK(ctx, g_rccl.AllReduce(d, d, (size_t)(2 * nv), ncclDouble, ncclMax, ctx->comm, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h, d, sizeof(double) * 2 * nv, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < nv; ++i)
+      if (h[2 * i] != -h[2 * i + 1]) {
+        ctx->err = std::string("blsq_tsqr_factor_dev: the ranks disagree on ") + what +
+                   " (x, bounds, scale, scale_mode, the plan's n / m_total and the BLSQ_* environment must be "
+                   "identical on every rank)";
+        return BLSQ_ERR_RANKS_DISAGREE;
+      }
+    return 0;
+  };
+  if (p->nranks > 1 && !p->ranks_agreed) {
+    // once per plan, BEFORE the first data collective: a rank whose front end is switched off would enter
+    // the all-gather while the others sit in the Gram's all-reduce
+    const int cfg[3] = {p->tree.gram ? 1 : 0, p->n, p->m_total};
+    if ((rc = agree(cfg, 3, "the plan (normal-equations front end on / off, n, m_total)"))) return rc;
+    p->ranks_agreed = true;
+  }
+  int redo = 0;
   if (p->tree.gram) {
     if ((rc = p->tree.run_gram_only(ctx, dJ_block, df_block, p->n, nullptr, /*collective=*/true))) return rc;
     int nfb = 0;
     if ((rc = trf_gram_stage(p, scale_mode, nullptr, &nfb))) return rc;   // replicated: same verdict everywhere
+    if (p->nranks > 1) {
+      // ... which is checked, not assumed: the route (return here, or enter the all-gather below) is taken
+      // from the max AND the min of the verdict over the ranks.  Ranks that disagree (inputs or environment
+      // that differ between them) all fail with the same code instead of one of them waiting in a
+      // collective the others never enter.
+      const int vd[2] = {nfb, scale_mode};
+      if ((rc = agree(vd, 2, "the gate's verdict"))) return rc;
+    }
     if (nfb == 0) {
       if ((rc = trf_finish(p))) return rc;
       return put_scale();
     }
+    redo = 1;                                             // (prepared from the Gram once already)
   }
   // Householder route: this rank's triangle, all-gather, replicated merge
   if ((rc = p->tree.run_levels(ctx, dJ_block, df_block, p->n, nullptr))) return rc;
   if (p->nranks == 1) {
-    if ((rc = trf_after_triangle(p, p->tree.Rfinal(), scale_mode))) return rc;
+    if ((rc = trf_after_triangle(p, p->tree.Rfinal(), scale_mode, redo))) return rc;
     return put_scale();
   }
   const size_t tri = (size_t)p->ld * p->ld;
   RCCLCHK(ctx, g_rccl.AllGather(p->tree.Rfinal(), p->Rstack.as<double>(), tri, ncclDouble, ctx->comm,
                                 ctx->stream));
-  return tsqr_merge_and_finish(p, p->Rstack.as<double>(), scale_mode, dscale_io);
+  return tsqr_merge_and_finish(p, p->Rstack.as<double>(), scale_mode, dscale_io, redo);
 }
 
 // =============================================================== dogbox ====
@@ -1754,7 +1836,16 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
   blsq_ctx* ctx = p->ctx;
   QrTree& t = p->tree;
   int rc;
-  p->pending = false;
+  if (p->pending) {                         // (as trf_factor_core: read the dropped verdict, no repair)
+    p->pending = false;
+    HIPCHK(ctx, hipEventSynchronize(p->pend_ev));
+    const int nfb_ = p->pend_pin[0], njac_ = p->pend_pin[1];
+    if (p->pend_tail) { if (!(p->ld <= 80 && p->pend_pin[2] == 0)) p->guess_settled = false; }
+    else if (nfb_ > 0 || njac_ > 0) {
+      p->guess_ok = false;
+      ctx->gram_fast -= nfb_; ctx->gram_fallback += nfb_;
+    }
+  }
   if (!t.gram) {
     if ((rc = t.run_levels(ctx, dJ, df, ldJ, mask))) return rc;
     return dog_after_triangle(p, scale_mode);
@@ -1878,6 +1969,7 @@ extern "C" int blsq_dogbox_plan_create(blsq_ctx* ctx, int B, int m, int n,
   }
   if (rc != 0) { blsq_dogbox_plan_destroy(p); return rc; }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->dog_plans.push_back(p);
   *out = p;
   return 0;
 }
@@ -1885,6 +1977,7 @@ extern "C" int blsq_dogbox_plan_create(blsq_ctx* ctx, int B, int m, int n,
 extern "C" int blsq_dogbox_plan_destroy(blsq_dogbox_plan* p) {
   if (!p) return -1;
   hipStreamSynchronize(p->ctx->stream);
+  { auto& v = p->ctx->dog_plans; v.erase(std::remove(v.begin(), v.end(), p), v.end()); }
   if (p->pend_pin) hipHostFree(p->pend_pin);
   if (p->pend_ev) hipEventDestroy(p->pend_ev);
   p->tree.release();
@@ -2069,6 +2162,14 @@ extern "C" int blsq_dogbox_step(blsq_dogbox_plan* p, const double* Delta, double
   if (rc) return rc;
   return blsq_dogbox_fetch_step(p, step, x_new, on_bound_new, tr_hit, predicted_reduction,
                                 step_scaled_norm, fallback, status);
+}
+
+static int ctx_resolve_pending(blsq_ctx* ctx) {
+  for (blsq_trf_plan* p : ctx->trf_plans)
+    if (p->pending) { int rc = trf_resolve(p, nullptr); if (rc) return rc; }
+  for (blsq_dogbox_plan* p : ctx->dog_plans)
+    if (p->pending) { int rc = dog_resolve(p, nullptr); if (rc) return rc; }
+  return 0;
 }
 
 // ==================================================== batched outer drivers ===

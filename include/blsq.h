@@ -94,8 +94,13 @@ int blsq_trf_step(blsq_trf_plan* plan, const double* Delta /*B*/, double* alpha_
  * conditioning certificate (which problems must take the Householder route) but assumes the common one
  * — "none" — and the NEXT call on the plan reads the verdict: blsq_trf_step_dev enqueues its kernels
  * first and, should the guess have been wrong, runs the Householder stage and the step once more
- * (same results either way).  Consequence for the caller: dJ / df / dscale_io must stay valid until
- * that next call.  Environment BLSQ_OPTIMISTIC=0: the factor call waits itself. */
+ * (same results either way).  LIFETIME RULE for the caller: dJ / df / dscale_io must stay valid AND
+ * unmodified until the verdict has been read — by the next blsq_*_step_dev / blsq_*_fetch_* call on the
+ * plan, or by blsq_sync(ctx), which resolves every pending verdict of the ctx (so does blsq_dev_free and
+ * blsq_memcpy_h2d: memory handed back to, or overwritten through, the library is never read afterwards).
+ * After blsq_sync nothing of the caller's J / f is read again.  A second *_factor_dev on the plan drops
+ * the first one's verdict (it is still read for the path statistics).  Environment BLSQ_OPTIMISTIC=0:
+ * the factor call waits itself and the rule is void. */
 int blsq_trf_factor_dev(blsq_trf_plan* plan, const double* dJ, const double* df,
                         const double* dx, const double* dlb, const double* dub,
                         double* dscale_io, int scale_mode);
@@ -183,8 +188,19 @@ int blsq_dogbox_fetch_step(blsq_dogbox_plan* plan, double* step, double* x_new,
  * blsq_tsqr_local_dev / blsq_tsqr_combine_dev expose the two halves of the Householder route for
  * hosts that exchange the triangles themselves (`tri` buffers: dense row-major
  * blsq_tsqr_tri_ld(n)^2 doubles, stack in rank order).
+ * Every rank takes the SAME route: the gate's verdict is compared over the ranks (one 16-byte
+ * ncclAllReduce(max) behind the Gram's) and the call fails with BLSQ_ERR_RANKS_DISAGREE on every rank
+ * if they differ (x / bounds / scale / scale_mode / BLSQ_* environment must be identical everywhere).
  * Return codes of failed RCCL calls: 10000 + ncclResult_t.
+ * The collective library is resolved at the first blsq_comm_* call: $BLSQ_RCCL_PATH if set (a full
+ * path to a librccl-compatible shared object; tests/ use it for a socket-based stand-in that lets two
+ * processes share ONE GPU, which RCCL itself refuses), otherwise librccl.so.1 next to the HIP runtime
+ * the process already uses, then the loader's search path.  blsq_comm_library() reports the choice.
  */
+#define BLSQ_ERR_RANKS_DISAGREE 20001
+/* path of the collective library in use ("" before the first blsq_comm_* call) and its
+ * ncclGetVersion() code (0 if the library has no such entry) */
+const char* blsq_comm_library(int* version_out);
 int blsq_comm_id_bytes(void);
 int blsq_comm_get_id(blsq_ctx* ctx, void* id_out, size_t bytes);
 int blsq_comm_init(blsq_ctx* ctx, int nranks, int rank, const void* id, size_t bytes);

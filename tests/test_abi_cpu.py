@@ -52,3 +52,68 @@ def test_product_package_does_not_import_oracle():
         if fn.endswith(".py"):
             txt = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+[^\n]*oracle", txt, flags=re.M), fn
+
+
+class _MockLib:
+    """Counts the destroy calls of the C-ABI (no GPU needed)."""
+
+    def __init__(self):
+        self.calls = []
+
+    def blsq_ctx_destroy(self, h):
+        self.calls.append(("ctx", h))
+        return 0 if h else -1
+
+    def blsq_outer_destroy(self, h):
+        self.calls.append(("outer", h))
+        return 0
+
+    def blsq_trf_plan_destroy(self, h):
+        self.calls.append(("trf", h))
+        return 0
+
+
+def _mock_ctx_and_driver(own_ctx):
+    import weakref
+    from bounded_lsq import _abi, _outer, _hip_step
+    lib = _MockLib()
+    ctx = object.__new__(_abi.Context)
+    ctx.lib, ctx.h, ctx.device_id, ctx._plans = lib, 11, 0, weakref.WeakSet()
+    drv = object.__new__(_outer.OuterDriver)
+    drv.ctx, drv._own_ctx, drv.h = ctx, own_ctx, 22
+    ctx.adopt(drv)
+    sol = object.__new__(_hip_step.TrfStepSolver)
+    sol.ctx, sol.lib, sol.h = ctx, lib, 33
+    ctx.adopt(sol)
+    return lib, ctx, drv, sol
+
+
+@pytest.mark.parametrize("first", ["driver", "ctx"])
+def test_close_of_a_driver_that_owns_its_context_destroys_everything_once(first):
+    """OuterDriver(ctx=None).close() closes its ctx, whose close() walks its plans, the driver
+    included: each handle must be destroyed exactly once, with no recursion, whichever end starts."""
+    lib, ctx, drv, sol = _mock_ctx_and_driver(own_ctx=True)
+    (drv if first == "driver" else ctx).close()
+    assert sorted(lib.calls) == [("ctx", 11), ("outer", 22), ("trf", 33)]
+    assert lib.calls[-1] == ("ctx", 11)                      # plans go before their context
+    drv.close(); ctx.close(); sol.close()                    # idempotent
+    assert len(lib.calls) == 3
+    assert ctx.h is None and drv.h is None and sol.h is None
+
+
+def test_close_of_a_driver_on_a_borrowed_context_leaves_the_context_alone():
+    lib, ctx, drv, sol = _mock_ctx_and_driver(own_ctx=False)
+    drv.close()
+    assert lib.calls == [("outer", 22)] and ctx.h == 11
+    ctx.close()
+    assert sorted(lib.calls) == [("ctx", 11), ("outer", 22), ("trf", 33)]
+
+
+def test_unknown_negative_status_raises_value_error_not_key_error():
+    import numpy as np
+    from bounded_lsq._outer import raise_step_errors
+    with pytest.raises(ValueError, match="problem 1"):
+        raise_step_errors(np.array([0, -77, 0]))
+    with pytest.raises(ValueError, match="`s` is zero"):
+        raise_step_errors(np.array([-1]))
+    raise_step_errors(np.array([0, 1, 3]))                   # termination codes: nothing raised

@@ -127,3 +127,92 @@ def test_tall_problem_exchange_patterns_gloo_world2(tmp_path):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
+
+
+# ---- the stand-in collective library of the two-ranks-on-one-GPU tests (tests/stub_ccl) -------------
+STUB = os.path.join(ROOT, "tests", "stub_ccl", "libblsq_stub_ccl.so")
+
+def _stub_script(tmp_path):
+    """(written as a plain script: the worker drives the stub through ctypes in host mode)"""
+    src = r'''
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(%(root)r, "bounded-lsq_amd"))
+from bounded_lsq._multi import exchange_id_tcp
+rank, world, port, mode = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+lib = C.CDLL(%(stub)r)
+class Uid(C.Structure):
+    _fields_ = [("b", C.c_ubyte * 128)]
+lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, Uid, C.c_int]
+lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+lib.ncclCommDestroy.argtypes = [C.c_void_p]
+F64, SUM, MAX = 8, 0, 2                      # ncclFloat64, ncclSum, ncclMax (rccl.h)
+def make_id():
+    u = Uid()
+    assert lib.ncclGetUniqueId(C.byref(u)) == 0
+    return bytes(bytearray(u.b))
+raw = exchange_id_tcp(rank, world, "127.0.0.1", port, make_id)
+uid = Uid()
+C.memmove(C.byref(uid), raw, 128)
+comm = C.c_void_p()
+assert lib.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0
+rng = np.random.default_rng(100 + rank)
+a = rng.standard_normal(1000)
+out = np.empty_like(a)
+assert lib.ncclAllReduce(a.ctypes.data, out.ctypes.data, a.size, F64, SUM, comm, None) == 0
+ref = np.random.default_rng(100).standard_normal(1000)
+for r in range(1, world):
+    ref = ref + np.random.default_rng(100 + r).standard_normal(1000)          # rank order
+assert np.array_equal(out, ref)                                            # the same bits on every rank
+v = np.array([float(rank), -float(rank)])
+assert lib.ncclAllReduce(v.ctypes.data, v.ctypes.data, 2, F64, MAX, comm, None) == 0   # in place
+assert v.tolist() == [world - 1.0, 0.0]
+g = np.full(7, float(rank)); stack = np.empty(7 * world)
+assert lib.ncclAllGather(g.ctypes.data, stack.ctypes.data, 7, F64, comm, None) == 0
+assert np.array_equal(stack, np.repeat(np.arange(world, dtype=float), 7))   # slot r = rank r
+if mode == "mismatch":                      # one rank enters another collective: an error everywhere, no hang
+    if rank == 1:
+        rc = lib.ncclAllGather(g.ctypes.data, stack.ctypes.data, 7, F64, comm, None)
+    else:
+        rc = lib.ncclAllReduce(a.ctypes.data, out.ctypes.data, a.size, F64, SUM, comm, None)
+    assert rc == 5, rc                      # ncclInvalidUsage
+lib.ncclCommDestroy(comm)
+open(os.path.join(%(out)r, "stub%%d.ok" %% rank), "w").write("ok")
+'''
+    script = tmp_path / "stubw.py"
+    script.write_text(src % {"root": ROOT, "stub": STUB, "out": str(tmp_path)})
+    return script
+
+
+def _need_stub():
+    import pytest
+    if not os.path.exists(STUB):
+        out = subprocess.run(["make", "-C", os.path.dirname(STUB)], capture_output=True, text=True)
+        if out.returncode != 0 or not os.path.exists(STUB):
+            pytest.fail("tests/stub_ccl does not build:\n" + out.stdout[-1500:] + out.stderr[-1500:])
+
+
+def _run_stub_world(tmp_path, world, mode):
+    _need_stub()
+    script = _stub_script(tmp_path)
+    port = _free_port()
+    env = dict(os.environ, BLSQ_STUB_HOST="1")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(port), mode], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, out[-2000:]
+    assert all((tmp_path / ("stub%d.ok" % r)).exists() for r in range(world))
+
+
+def test_stand_in_collectives_world3_host_mode(tmp_path):
+    """The socket stand-in the GPU tests load through BLSQ_RCCL_PATH delivers what RCCL delivers: the
+    all-reduce sums in rank order to the SAME bits on every rank (in place too), the all-gather stacks in
+    rank order."""
+    _run_stub_world(tmp_path, 3, "plain")
+
+
+def test_stand_in_refuses_mismatched_collectives(tmp_path):
+    _run_stub_world(tmp_path, 2, "mismatch")
