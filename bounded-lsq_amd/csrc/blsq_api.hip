@@ -204,6 +204,8 @@ struct QrTree {
                                     // systems are diagonal modifications of them)
   DevBuf gram_rinv, gram_ywork, gram_k2;   // conditioning certificate: inverse diagonal tiles, Y = R'^-T, bound [B]
   DevBuf gram_cert;                        // [B] ints: 1 = proven inside the factor kernel (N <= 80)
+  DevBuf gram_cflag, gram_ctau;            // [B] certificate stage 3: problems left to the shifted factorisation, their shifts
+  double k2_max = 0.0;                     // the gate for this plan's row count (gram_k2_max)
   bool fb_zeroed = false;                  // the gate counters were cleared by pack_vecs_kernel of this factor call
   // per-problem path of the CURRENT triangles: gram_path()[b] = n + 1 (Householder tree) or 0 (Gram).
   // any_gram / any_qr: whether a problem of either kind can exist (host-side upper bounds)
@@ -274,6 +276,11 @@ struct QrTree {
       if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Gram gate bound)");
       e = gram_cert.alloc(sizeof(int) * (size_t)B);
       if (e != hipSuccess) return ctx->fail(e, "hipMalloc(Gram certificate flags)");
+      e = gram_cflag.alloc(sizeof(int) * (size_t)B);
+      if (e == hipSuccess) e = gram_ctau.alloc(sizeof(double) * (size_t)B);
+      if (e == hipSuccess) e = hipMemsetAsync(gram_cflag.p, 0, gram_cflag.bytes, ctx->stream);
+      if (e != hipSuccess) return ctx->fail(e, "hipMalloc(certificate stage 3)");
+      k2_max = gram_k2_max(rows);
       e = hipMemsetAsync(gram_cert.p, 0, gram_cert.bytes, ctx->stream);
       if (e != hipSuccess) return ctx->fail(e, "hipMemsetAsync(Gram certificate flags)");
       e = hipMemsetAsync(gram_k2.p, 0, gram_k2.bytes, ctx->stream);
@@ -292,6 +299,7 @@ struct QrTree {
     V.release(); T.release();
     gram_part.release(); gram_dsc.release(); gram_ints.release(); gram_keep.release();
     gram_rinv.release(); gram_ywork.release(); gram_k2.release(); gram_cert.release();
+    gram_cflag.release(); gram_ctau.release();
   }
   // [J f] -> triangle by the normal equations where the conditioning gate allows it.
   // Returns the number of problems left for the Householder tree in *nfallback; their indices
@@ -325,12 +333,15 @@ struct QrTree {
     c.path_out = fb + B + 4;
     c.dsc = gram_dsc.as<double>();
     c.rinv = gram_rinv.as<double>(); c.ywork = gram_ywork.as<double>(); c.k2_out = gram_k2.as<double>();
+    c.k2_max = k2_max; c.pivot_floor = 1.0 / k2_max;
+    c.cert_flag = gram_cflag.as<int>(); c.cert_tau = gram_ctau.as<double>();
     ctx->begin(K_GRAM_CHOL);
     e = launch_gram_chol(c, B, ctx->stream);
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol");
     ctx->begin(K_GRAM_GATE);
     e = launch_gram_gate(c, B, ctx->stream);
+    if (e == hipSuccess) e = launch_gram_cert_shift(c, B, ctx->stream);
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_gram_gate");
     HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 1, cnt, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -890,6 +901,8 @@ GramCholArgs trf_chol_args(blsq_trf_plan* p, const int* mask) {
   c.dsc = t.gram_dsc.as<double>();
   c.rinv = t.gram_rinv.as<double>(); c.ywork = t.gram_ywork.as<double>(); c.k2_out = t.gram_k2.as<double>();
   c.cert_done = t.gram_cert.as<int>();
+  c.k2_max = t.k2_max; c.pivot_floor = 1.0 / t.k2_max;
+  c.cert_flag = t.gram_cflag.as<int>(); c.cert_tau = t.gram_ctau.as<double>();
   c.colinfo = p->aug_colinfo.as<double>();
   if (p->ld <= 80) {                        // (the register-resident kernel also does the rank gate's sure case)
     c.lmfin.fast = p->lm.fast; c.lmfin.ncols_jac = p->lm.ncols_jac; c.lmfin.sc = p->lm.sc; c.lmfin.st = p->lm.st;
@@ -906,6 +919,7 @@ int trf_gate_tail(blsq_trf_plan* p, const GramCholArgs& c) {
   QrTree& t = p->tree;
   ctx->begin(K_GRAM_GATE);
   hipError_t e = launch_gram_gate(c, p->B, ctx->stream);
+  if (e == hipSuccess) e = launch_gram_cert_shift(c, p->B, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_gram_gate");
   // The rank gate runs BEFORE the verdict is read back: in the common case (no problem leaves this
@@ -1482,6 +1496,7 @@ extern "C" int blsq_tsqr_plan_create(blsq_ctx* ctx, int m_local, long long m_tot
   const int G = merge_group(n);
   const size_t comb_rows = (size_t)((nranks + G - 1) / G) * (size_t)(G * NPAD);
   int rc = p->tree.build(ctx, 1, m_local, n, std::max((size_t)aug_rp, comb_rows));
+  if (rc == 0 && p->tree.gram) p->tree.k2_max = gram_k2_max(m_total);   // (the Gram sums over ALL ranks' rows)
   if (rc == 0) { p->ld = p->tree.NPAD; rc = trf_alloc_state(p); }
   if (rc == 0) {
     // two ping-pong levels for the combine tree
@@ -1796,6 +1811,8 @@ GramCholArgs dog_chol_args(blsq_dogbox_plan* p, const int* mask) {
   c.dsc = t.gram_dsc.as<double>();
   c.rinv = t.gram_rinv.as<double>(); c.ywork = t.gram_ywork.as<double>(); c.k2_out = t.gram_k2.as<double>();
   c.cert_done = t.gram_cert.as<int>();
+  c.k2_max = t.k2_max; c.pivot_floor = 1.0 / t.k2_max;
+  c.cert_flag = t.gram_cflag.as<int>(); c.cert_tau = t.gram_ctau.as<double>();
   c.colinfo = p->colinfo.as<double>();
   if (p->ld <= 80) {                        // (the register-resident kernel also finishes the gate / Newton / Cauchy work)
     int* gf_ = p->gate_ints.as<int>();
@@ -1814,6 +1831,7 @@ int dog_gate_tail(blsq_dogbox_plan* p, const GramCholArgs& c) {
   QrTree& t = p->tree;
   ctx->begin(K_GRAM_GATE);
   hipError_t e = launch_gram_gate(c, p->B, ctx->stream);
+  if (e == hipSuccess) e = launch_gram_cert_shift(c, p->B, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_gram_gate");
   int* gfast = p->gate_ints.as<int>();

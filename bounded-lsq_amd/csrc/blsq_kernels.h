@@ -98,6 +98,18 @@ struct GramCholArgs {
   // conditioning certificate (launch_gram_gate)
   double* ywork;          // [B][NPAD*NPAD] scratch: Y = R'^-T
   double* k2_out;         // optional [B] out: the proven bound on kappa_2 of the equilibrated system
+  double k2_max;          // the gate: a problem stays on the path iff its proven bound is <= k2_max (0: GRAM_K2_MAX);
+                          // the host scales it with the accumulation length of the Gram (gram_k2_max)
+  double pivot_floor;     // smallest acceptable squared pivot of R' (0: 1 / GRAM_K2_MAX, the early reject of a
+                          // gate-bearing factorisation: lambda_min(C) <= min r_jj^2, lambda_max(C) >= 1)
+  // Third stage of the certificate (launch_gram_cert_shift): a problem the two norm bounds cannot settle is
+  // decided by a Cholesky factorisation of the SHIFTED equilibrated system C - tau I, tau = Lambda / k2_max
+  // with Lambda >= lambda_max(C) proven by the norm stage: it runs to completion with pivots above the
+  // rounding floor iff lambda_min(C) > tau (up to n eps), i.e. iff kappa_2(C) <= Lambda / tau = k2_max.
+  int* cert_flag;         // optional [B]: gram_cond_kernel sets 1 for a problem it leaves undecided (instead of
+                          // rejecting it); the shifted launch works on exactly those and clears the flag
+  double* cert_tau;       // [B] the shift tau of such a problem (written by gram_cond_kernel)
+  int cert_shift;         // 1: THIS launch is the shifted factorisation (G = scratch; verdict -> fb_mask etc.)
   int* cert_done;         // optional [B]: 1 = the factor kernel itself proved K2 <= GRAM_K2_MAX (N <= 80: the
                           // register-resident kernel has R' at hand); launch_gram_gate then skips the problem
   // dogbox, N <= 80 (optional; g == nullptr: off): the register-resident kernel also does what
@@ -132,8 +144,23 @@ struct GramCholArgs {
 // A problem stays on the normal-equations path only if the PROVEN bound K2 >= kappa_2(R'^T R') of its
 // equilibrated system is at most GRAM_K2_MAX (chol_kernels.hip, gram_cond_kernel).  Consequence used
 // by the rank gates: lambda_max >= 1 (unit diagonal), so sigma_min(R') >= 1 / sqrt(GRAM_K2_MAX).
-constexpr double GRAM_K2_MAX = 2.5e5;
-constexpr double GRAM_SMIN_PROVEN = 2.0e-3;         // = 1 / sqrt(GRAM_K2_MAX)
+#ifndef BLSQ_K2_MAX
+#define BLSQ_K2_MAX 2.5e5
+#endif
+constexpr double GRAM_K2_MAX = BLSQ_K2_MAX;         // (calibration builds: EXTRA_DEFS=-DBLSQ_K2_MAX=...)
+constexpr double gram_csqrt(double x, double g = 1.0, int it = 64) {
+  return it == 0 ? g : gram_csqrt(x, 0.5 * (g + x / g), it - 1);
+}
+constexpr double GRAM_SMIN_PROVEN = 1.0 / gram_csqrt(GRAM_K2_MAX);   // = 1 / sqrt(GRAM_K2_MAX): 2e-3
+// Rounding-safe floor of the shifted factorisation's squared pivots: a floating-point Cholesky of a unit-
+// diagonal matrix of order N <= 272 that completes with every pivot above (N + 1) eps trace = 8e-12 proves
+// positive definiteness (Higham, Accuracy and Stability, Thm 10.7 with the a-posteriori bound of Rump 2006)
+constexpr double GRAM_CERT_PIVOT_FLOOR = 1.0e-9;
+// The gate as a function of the Gram's accumulation length: the entries of G are sums of m products
+// accumulated in row chunks (rows_per_chunk terms in the MFMA accumulator, then nchunks partial sums), so
+// their rounding error grows like a(m) = sqrt(rows_per_chunk) + sqrt(nchunks); the error constant of
+// DESIGN.md 3.0 was calibrated at m = 4096 (a = 46.7) and the gate is tightened by a(4096) / a(m) beyond.
+double gram_k2_max(long long m_total);
 bool gram_supported(int m, int n);
 int gram_chunks(int B, int m);
 // Gfinal / fused (optional): where the reduced Gram belongs; *fused = true means the launch produced it
@@ -144,6 +171,9 @@ hipError_t launch_gram_reduce(const double* Gpart, int chunks, int NPAD, double*
                               const int* mask, int B, hipStream_t s);
 hipError_t launch_gram_chol(const GramCholArgs& a, int B, hipStream_t s);
 hipError_t launch_gram_gate(const GramCholArgs& a, int B, hipStream_t s);
+// third stage of the certificate for the problems launch_gram_gate flagged (a.cert_flag / a.cert_tau):
+// same source, scalings and gather as the factor call `a` describes, output into a.ywork
+hipError_t launch_gram_cert_shift(const GramCholArgs& a, int B, hipStream_t s);
 
 // ------------------------------------------------------------- Jacobi -----
 // One-sided Jacobi on the ROWS of the n x (n+1) array [R | c] (row stride ld):

@@ -55,6 +55,11 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
     return;
   }
   if (a.skip_path && a.skip_path[b] != 0) return;
+  double tau = 0.0;                                     // certificate stage 3: factor C - tau I
+  if (a.cert_shift) {
+    if (!a.cert_flag[b]) return;                        // (uniform: only the problems the norm stage left open)
+    tau = a.cert_tau[b];
+  }
   // columns of this problem: all n (+ rhs), or the gathered free columns (+ rhs)
   const int N = a.ncols_dev ? a.ncols_dev[b] : a.n + 1;
   if (N <= 1) {                                         // (dogbox: every variable active — nothing to factor)
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
       d = d * fma(-0.5 * g * d, d, 1.5);
       s = g * d;
     }
-    dl[j] = d; sq[j] = s; sc[j] = cs * d; td[j] = add * d * d;
+    dl[j] = d; sq[j] = s; sc[j] = cs * d; td[j] = add * d * d - ((j < n) ? tau : 0.0);
     if (a.dsc) a.dsc[(long)b * NPAD + j] = d;
   }
   if (a.colinfo) {                                      // (uniform) column-norm summary for the rank gate
@@ -203,10 +208,15 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
     }
   }
   if (tid == 0 && a.fb_mask) {
-    const bool fail = !(pminsh >= GRAM_SMIN * GRAM_SMIN);
+    const double floor_ = a.pivot_floor > 0.0 ? a.pivot_floor : 1.0 / GRAM_K2_MAX;
+    const bool fail = !(pminsh >= floor_);
     a.fb_mask[b] = fail ? a.n + 1 : 0;
     if (a.path_out) a.path_out[b] = fail ? a.n + 1 : 0;
     if (fail) { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
+    if (a.cert_shift) {
+      a.cert_flag[b] = 0;
+      if (!fail && a.k2_out) a.k2_out[b] = a.k2_max;    // proven: kappa_2 <= Lambda / tau
+    }
   }
 }
 
@@ -239,6 +249,11 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
     return;
   }
   if (a.skip_path && a.skip_path[b] != 0) return;
+  double tau = 0.0;                                     // certificate stage 3: factor C - tau I
+  if (a.cert_shift) {
+    if (!a.cert_flag[b]) return;                        // (wave-uniform)
+    tau = a.cert_tau[b];
+  }
   const int N = a.ncols_dev ? a.ncols_dev[b] : a.n + 1;
   if (N <= 1) {                                         // (dogbox: every variable active — nothing to factor)
     if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
@@ -284,7 +299,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
       d = d * fma(-0.5 * g * d, d, 1.5);
       s_ = g * d;
     }
-    dl[j] = d; sq[j] = s_; sc[j] = cs * d; td[j] = add * d * d;
+    dl[j] = d; sq[j] = s_; sc[j] = cs * d; td[j] = add * d * d - ((j < n) ? tau : 0.0);
     sidx[j] = sj_ < NPAD ? sj_ : 0;                     // source row / column of index j (always a valid one)
     if (a.dsc) a.dsc[(long)b * NPAD + j] = d;
   }
@@ -408,11 +423,16 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
       wsync();                                          // (Dt / Ri are rewritten by the next chain)
     }
   }
-  const bool fail = !(pmin >= GRAM_SMIN * GRAM_SMIN);
+  const double kmax = a.k2_max > 0.0 ? a.k2_max : GRAM_K2_MAX;
+  const bool fail = !(pmin >= (a.pivot_floor > 0.0 ? a.pivot_floor : 1.0 / GRAM_K2_MAX));
   if (tid == 0 && a.fb_mask) {
     a.fb_mask[b] = fail ? a.n + 1 : 0;
     if (a.path_out) a.path_out[b] = fail ? a.n + 1 : 0;
     if (fail) { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
+    if (a.cert_shift) {
+      a.cert_flag[b] = 0;
+      if (!fail && a.k2_out) a.k2_out[b] = kmax;        // proven: kappa_2 <= Lambda / tau
+    }
   }
   // 5. The first bound of the conditioning certificate (gram_cond_kernel below: same quantities, same
   //    definition) while R' and the inverse diagonal tiles are still at hand:
@@ -510,7 +530,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
         for (int g = 0; g < 4; ++g) yinf = fmax(yinf, rsY[i][g]);
       yinf = wave_max(yinf);
       k2 = (r1 * rinf) * (y1 * yinf);
-      passed = k2 <= GRAM_K2_MAX;                       // (NaN fails)
+      passed = k2 <= kmax;                              // (NaN fails)
     }
     if (tid == 0) {
       a.cert_done[b] = passed ? 1 : 0;
@@ -1001,6 +1021,11 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
     return;
   }
   if (a.skip_path && a.skip_path[b] != 0) return;
+  double tau = 0.0;                                     // certificate stage 3: factor C - tau I
+  if (a.cert_shift) {
+    if (!a.cert_flag[b]) return;                        // (uniform)
+    tau = a.cert_tau[b];
+  }
   const int N = a.ncols_dev ? a.ncols_dev[b] : a.n + 1;
   if (N <= 1) {                                         // (dogbox: every variable active — nothing to factor)
     if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
@@ -1039,7 +1064,7 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
       d = d * fma(-0.5 * g * d, d, 1.5);
       s = g * d;
     }
-    dl[j] = d; sq[j] = s; sc[j] = cs * d; td[j] = add * d * d;
+    dl[j] = d; sq[j] = s; sc[j] = cs * d; td[j] = add * d * d - ((j < n) ? tau : 0.0);
     if (a.dsc) a.dsc[(long)b * NPAD + j] = d;
   }
   if (a.colinfo) {
@@ -1216,10 +1241,14 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
   }
   __syncthreads();
   if (tid == 0 && a.fb_mask) {
-    const bool fail = !(pminsh >= GRAM_SMIN * GRAM_SMIN);
+    const bool fail = !(pminsh >= (a.pivot_floor > 0.0 ? a.pivot_floor : 1.0 / GRAM_K2_MAX));
     a.fb_mask[b] = fail ? a.n + 1 : 0;
     if (a.path_out) a.path_out[b] = fail ? a.n + 1 : 0;
     if (fail) { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
+    if (a.cert_shift) {
+      a.cert_flag[b] = 0;
+      if (!fail && a.k2_out) a.k2_out[b] = a.k2_max;    // proven: kappa_2 <= Lambda / tau
+    }
   }
 }
 
@@ -1409,7 +1438,9 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_cond_kernel(GramCholArgs a) {
   y1 = reduce_max(y1);
   const double yinf = reduce_max(tid < 16 ? rmax : 0.0);
   double k2 = (r1 * rinf) * (y1 * yinf);
-  if (!(k2 <= GRAM_K2_MAX)) {                            // (uniform over the problem's threads)
+  const double kmax = a.k2_max > 0.0 ? a.k2_max : GRAM_K2_MAX;
+  double lam = fmin(r1 * rinf, (double)n);              // lambda_max(C) <= ||R'||_1 ||R'||_inf, <= trace(C) = n
+  if (!(k2 <= kmax)) {                                   // (uniform over the problem's threads)
     // The 1- / inf-norm products overestimate kappa_2 by 10 ... 1000 (profiles/r02p_gate_calibration.txt).
     // Second, tighter proven bound for a problem they reject:  lambda_max(C) <= ||C||_F  and
     // 1 / lambda_min(C) = ||C^-1||_2 <= ||C^-1||_F  with  C^-1 = Y^T Y  formed tile by tile (MFMA; only
@@ -1475,15 +1506,37 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_cond_kernel(GramCholArgs a) {
     }
     const double k2f = sqrt(cf) * sqrt(zf);
     if (k2f < k2) k2 = k2f;
+    lam = fmin(lam, sqrt(cf));                          // lambda_max(C) <= ||C||_F
   }
   if (tid == 0) {
     if (a.k2_out) a.k2_out[b] = k2;
-    if (!(k2 <= GRAM_K2_MAX)) {                          // (NaN fails)
-      a.fb_mask[b] = a.n + 1;
-      if (a.path_out) a.path_out[b] = a.n + 1;
-      { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
+    if (!(k2 <= kmax)) {                                 // (NaN fails)
+      if (a.cert_flag && is_finite(k2) && lam >= 1.0) {
+        // The norm bounds overestimate kappa_2 by 3.5 ... 13 where they decide: leave the verdict to the third
+        // stage, a Cholesky factorisation of C - tau I with tau = Lambda / k2_max (launch_gram_cert_shift) —
+        // it succeeds iff lambda_min(C) > tau, which proves kappa_2(C) <= Lambda / tau = k2_max.
+        a.cert_tau[b] = lam / kmax;
+        a.cert_flag[b] = 1;
+      } else {
+        a.fb_mask[b] = a.n + 1;
+        if (a.path_out) a.path_out[b] = a.n + 1;
+        { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
+      }
     }
   }
+}
+
+double gram_k2_max(long long m_total) {
+  auto acc = [](double m) {
+    const double chunk = m > 131072.0 ? 1024.0 : 2048.0;           // (gram_chunks: a function of m alone)
+    const double rows = m < chunk ? m : chunk;
+    return sqrt(rows) + sqrt(ceil(m / chunk));
+  };
+  const double f = acc(4096.0) / acc((double)(m_total > 1 ? m_total : 1));
+  double k = GRAM_K2_MAX * (f < 1.0 ? f : 1.0);
+  const char* env = getenv("BLSQ_GRAM_K2_MAX");                    // may only tighten the gate
+  if (env && env[0]) { const double v = atof(env); if (v > 0.0 && v < k) k = v; }
+  return k;
 }
 
 bool gram_supported(int m, int n) {
@@ -1540,6 +1593,20 @@ hipError_t launch_gram_chol(const GramCholArgs& a_in, int B, hipStream_t s) {
   }
   return hipGetLastError();
 }
+hipError_t launch_gram_cert_shift(const GramCholArgs& a_in, int B, hipStream_t s) {
+  if (!a_in.cert_flag || !a_in.cert_tau) return hipSuccess;
+  GramCholArgs a = a_in;
+  a.cert_shift = 1;
+  a.G = a.ywork;                                        // (Y of the norm stage is dead by now)
+  a.skip_zero = 1;
+  a.pivot_floor = GRAM_CERT_PIVOT_FLOOR;
+  a.dsc = nullptr; a.colinfo = nullptr; a.rinv = nullptr; a.cert_done = nullptr; a.unsettled = nullptr;
+  a.dog = GramCholArgs::DogFinish{}; a.lmfin = GramCholArgs::LmFinish{};
+  a.batch_list = nullptr; a.count_dev = nullptr; a.skip_path = nullptr; a.diag_sqrt = nullptr;
+  a.expect = B;                                         // (left-looking kernel: most workgroups leave at once)
+  return launch_gram_chol(a, B, s);
+}
+
 hipError_t launch_gram_gate(const GramCholArgs& a_in, int B, hipStream_t s) {
   GramCholArgs a = a_in;
   a.count = B;

@@ -28,8 +28,9 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-10
 
 
-def draw_case(rng, max_m=3000):
-    """One random batch: (kind, P, Delta)."""
+def draw_case(rng, max_m=3000, log_kappa=(0.0, 4.0)):
+    """One random batch: (kind, P, Delta); prescribed spectra with kappa(J) log-uniform over
+    10^log_kappa[0] .. 10^log_kappa[1]."""
     from bounded_lsq import _synth
     n = int(rng.choice([rng.integers(1, 17), rng.integers(17, 80), rng.integers(80, 271)]))
     m = int(n + rng.integers(0, 40)) if rng.random() < 0.2 else int(rng.integers(n, max_m))
@@ -37,7 +38,7 @@ def draw_case(rng, max_m=3000):
     kind = "trf" if rng.random() < 0.6 else "dogbox"
     seed = int(rng.integers(1 << 30))
     P = _synth.dogbox_batch(seed, B, m, n) if kind == "dogbox" else _synth.trf_batch(seed, B, m, n)
-    kappa = 10.0 ** rng.uniform(0, 4)
+    kappa = 10.0 ** rng.uniform(log_kappa[0], log_kappa[1])
     if rng.random() < 0.7 and m >= n:                       # prescribed spectrum
         for b in range(B):
             U, _ = np.linalg.qr(rng.standard_normal((m, n)))
@@ -75,7 +76,7 @@ def oracle_sensitivity(kind, P, b, Delta, So, mask, rng, trials=3):
     return move, mask_stable
 
 
-def run_sweep(count, seed, ctx, budget_s=None, verbose=False):
+def run_sweep(count, seed, ctx, budget_s=None, verbose=False, log_kappa=(0.0, 4.0)):
     """-> (records, violations).  record = (err, kind, B, m, n, cond, paths, excused)."""
     import bounded_lsq as bl
     rng = np.random.default_rng(seed)
@@ -85,7 +86,7 @@ def run_sweep(count, seed, ctx, budget_s=None, verbose=False):
     for case in range(count):
         if budget_s is not None and time.time() - t0 > budget_s:
             break
-        kind, P, Delta = draw_case(rng)
+        kind, P, Delta = draw_case(rng, log_kappa=log_kappa)
         B, m, n = P["J"].shape
         ctx.gram_stats(reset=True)
         if kind == "trf":
@@ -122,22 +123,40 @@ def run_sweep(count, seed, ctx, budget_s=None, verbose=False):
 
 
 def test_fuzz_sweep_against_oracle():
-    """~200 random batches (two seeds) inside a time budget; no violation of the bar above."""
+    """~200 random batches (two seeds) inside a time budget, kappa(J) up to 1e4: every problem within
+    1e-10 and bit-exact masks, NO case excused."""
     from bounded_lsq import _abi
     ctx = _abi.Context(0)
     try:
-        total, excused = 0, 0
+        total = 0
         for seed in (0, 1):
             recs, bad, paths = run_sweep(100, seed, ctx, budget_s=150)
             assert not bad, bad
             assert len(recs) >= 60, "time budget cut the sweep too short: %d problems" % len(recs)
             total += len(recs)
-            excused += sum(r[7] for r in recs)
+            assert sum(r[7] for r in recs) == 0, [r for r in recs if r[7]]   # the excuse is not needed here
             assert paths[0] > 0 and paths[1] > 0            # both factorisation paths exercised
-        # the excuse is for the rare ill-conditioned case, not a loophole
-        assert excused <= 0.1 * total, (excused, total)
-        print("fuzz: %d problems, %d beyond 1e-10 and excused by the oracle's own sensitivity"
-              % (total, excused))
+        print("fuzz: %d problems, kappa <= 1e4, none beyond 1e-10" % total)
+    finally:
+        ctx.close()
+
+
+def test_fuzz_sweep_of_ill_conditioned_problems():
+    """kappa(J) log-uniform over 1e4 .. 1e8: the Householder tree (and the Jacobi SVD) get real
+    coverage.  Here the reference's own answer moves by kappa * eps under a one-ulp change of J, so a case
+    may exceed 1e-10 if (and only if) the oracle itself moves that much — counted and reported."""
+    from bounded_lsq import _abi
+    ctx = _abi.Context(0)
+    try:
+        recs, bad, paths = run_sweep(70, 2, ctx, budget_s=100, log_kappa=(4.0, 8.0))
+        assert not bad, bad
+        assert len(recs) >= 40, "time budget cut the sweep too short: %d problems" % len(recs)
+        assert paths[1] >= len(recs) // 3                   # most prescribed-spectrum problems go through the tree
+        excused = sum(r[7] for r in recs)
+        print("fuzz (ill-conditioned): %d problems, paths (Gram, tree) %s, %d beyond 1e-10 and excused by the "
+              "oracle's own sensitivity, worst accepted error %.2e"
+              % (len(recs), paths, excused, max([r[0] for r in recs if not r[7]] + [0.0])))
+        assert excused <= 0.5 * len(recs), (excused, len(recs))
     finally:
         ctx.close()
 

@@ -86,3 +86,75 @@ def test_config5_single_rank_collective_route(tall, gram, monkeypatch):
     sol.close()
     ctx.comm_destroy()
     ctx.close()
+
+
+def _k2_max_of(m):
+    """gram_k2_max (csrc/chol_kernels.hip)"""
+    def acc(mm):
+        chunk = 1024.0 if mm > 131072 else 2048.0
+        return np.sqrt(min(mm, chunk)) + np.sqrt(np.ceil(mm / chunk))
+    return 2.5e5 * min(1.0, acc(4096.0) / acc(float(m)))
+
+
+def test_tall_problems_at_the_edge_of_the_gate():
+    """The error constant of the normal-equations path (step error <= c eps kappa_2, c <= 0.2
+    calibrated at m <= 4096) checked where the Gram's accumulation is 60x longer: 250 000 x 128 (the per-rank
+    block of BASELINE config 5), unbounded, equicorrelated columns and log-spaced spectra tuned so that the
+    TRUE condition number of the equilibrated J^T J sits in the last factor four below the gate — the sharp
+    third stage of the certificate keeps such problems on the fast path.  Step vs the oracle (gesdd on the
+    whole matrix) <= 1e-10; the constant c is printed.  Problems just beyond the gate must take the tree."""
+    import bounded_lsq as bl
+    from bounded_lsq import _abi
+    from oracle import blsq_oracle as orc
+    m, n = 250_000, 128
+    kmax = _k2_max_of(m)
+    assert 2.3e5 < kmax < 2.5e5
+    rng = np.random.default_rng(123)
+    eps = np.finfo(float).eps
+
+    def equicorr(rho):
+        Z = rng.standard_normal((m, n)); c = rng.standard_normal((m, 1))
+        return np.sqrt(1 - rho) * Z + np.sqrt(rho) * c
+
+    def logspaced(kappa):
+        U, _ = np.linalg.qr(rng.standard_normal((m, n)))
+        V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        return (U * np.logspace(0, -np.log10(kappa), n)) @ V.T * np.sqrt(m)
+
+    cases = [("equicorr", equicorr(1 - 128 / (0.45 * kmax))), ("equicorr", equicorr(1 - 128 / (0.8 * kmax))),
+             ("equicorr", equicorr(1 - 128 / (3.0 * kmax))),
+             ("logspaced", logspaced(330.0)), ("logspaced", logspaced(430.0)), ("logspaced", logspaced(900.0))]
+    ctx = _abi.Context(0)
+    sol = bl.TrfStepSolver(1, m, n, ctx=ctx)
+    x = rng.uniform(-1.0, 1.0, n)
+    lb = np.full(n, -np.inf); ub = np.full(n, np.inf)
+    near, cmax = 0, 0.0
+    for tag, J in cases:
+        f = rng.standard_normal(m)
+        sv = np.linalg.svd(J / np.linalg.norm(J, axis=0), compute_uv=False)
+        true_k2 = (sv[0] / sv[-1]) ** 2
+        ctx.gram_stats(reset=True)
+        sol.factor(J[None], f[None], x[None], lb[None], ub[None], np.ones((1, n)))
+        fast = ctx.gram_stats() == (1, 0)
+        k2 = float(sol.debug_cond()[0])
+        assert k2 == 0 or k2 >= true_k2 * (1 - 1e-6), (tag, k2, true_k2)       # the bound is one
+        if true_k2 <= kmax / 4:
+            assert fast, (tag, true_k2, k2)                                    # ... and sharp
+        if true_k2 > kmax * 1.001:
+            assert not fast, (tag, true_k2, k2)
+        F = orc.trf_factor(J, f, x, lb, ub, np.ones(n))
+        for Delta in (0.5 * np.linalg.norm(orc.trf_step(F, 1e300, 0.0).step), 1e300):
+            So = orc.trf_step(F, Delta, 0.0)
+            S = sol.step(np.array([Delta]), np.array([0.0]))
+            e = rel(S.step[0], So.step)
+            assert e < RTOL, (tag, true_k2, fast, Delta, e)
+            assert int(S.n_iter[0]) == So.n_iter
+            if fast:
+                cmax = max(cmax, e / (eps * true_k2))
+        near += bool(fast and true_k2 >= kmax / 4)
+        print("tall %-9s true kappa_2 %.3e (gate %.3e)  K2 %.3e  %s  step error %.2e"
+              % (tag, true_k2, kmax, k2, "fast path" if fast else "tree", e))
+    sol.close(); ctx.close()
+    print("tall problems near the gate on the fast path: %d, largest c = error / (eps kappa_2) = %.3f" % (near, cmax))
+    assert near >= 3, near
+    assert cmax < 0.2, cmax
