@@ -472,6 +472,10 @@ struct blsq_trf_plan {
   const int* path = nullptr;
   bool use_chol = false, use_qr = true;
   DevBuf aug_colinfo;               // [B][2] column-norm summary of R_aug (Gram-path problems)
+  DevBuf aug_lam;                   // [B] proven bound on lambda_max of the equilibrated H (LmState::lam)
+  DevBuf aug_hmax;                  // [B] largest diagonal entry of H (LmState::hmax: which Newton systems of a
+                                    // Householder-path problem may be factored from the Gram)
+  bool gram_valid = false;          // tree.gram_keep holds the Grams of the current factor call's problems
   // TSQR (multi-rank) extras
   int nranks = 1, m_total = 0;
   bool ranks_agreed = false;        // the ranks have compared their plan configuration (first factor call)
@@ -785,6 +789,8 @@ int trf_alloc_state(blsq_trf_plan* p) {
   ALLOC(p->lm_Xa, sizeof(double) * B * mat);
   ALLOC(p->lm_ints, sizeof(int) * ((size_t)B * 9 + 16));
   ALLOC(p->aug_colinfo, sizeof(double) * (size_t)B * 2);
+  ALLOC(p->aug_hmax, sizeof(double) * (size_t)B);
+  ALLOC(p->aug_lam, sizeof(double) * (size_t)B);
   ALLOC(p->lm_sc, sizeof(double) * (size_t)B * 16);
   ALLOC(p->lm_ph, sizeof(double) * vs);
   HIPCHK(ctx, hipMemsetAsync(p->lm_sa.p, 0, p->lm_sa.bytes, ctx->stream));
@@ -881,7 +887,7 @@ int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode, int r
   blsq_ctx* ctx = p->ctx;
   p->st.Rt = Rt; p->st.Gk = nullptr; p->st.path = nullptr;
   p->path = nullptr; p->use_chol = false; p->use_qr = true;
-  p->lm.path = nullptr; p->lm.colinfo = nullptr;
+  p->lm.path = nullptr; p->lm.colinfo = nullptr; p->lm.hmax = nullptr; p->gram_valid = false;
   p->tree.path_valid = false; p->tree.any_gram = false; p->tree.any_qr = true;
   p->gate_done = false;
   ctx->begin(K_PREP);
@@ -904,6 +910,7 @@ GramCholArgs trf_chol_args(blsq_trf_plan* p, const int* mask) {
   c.k2_max = t.k2_max; c.pivot_floor = 1.0 / t.k2_max;
   c.cert_flag = t.gram_cflag.as<int>(); c.cert_tau = t.gram_ctau.as<double>();
   c.colinfo = p->aug_colinfo.as<double>();
+  c.hmax = p->aug_hmax.as<double>(); c.lam_out = p->aug_lam.as<double>();
   if (p->ld <= 80) {                        // (the register-resident kernel also does the rank gate's sure case)
     c.lmfin.fast = p->lm.fast; c.lmfin.ncols_jac = p->lm.ncols_jac; c.lmfin.sc = p->lm.sc; c.lmfin.st = p->lm.st;
     c.unsettled = t.fb_count() + 2;
@@ -985,6 +992,16 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, 
   p->use_qr = t.any_qr;
   p->lm.path = p->path;
   p->lm.colinfo = p->use_chol ? p->aug_colinfo.as<double>() : nullptr;
+  // Newton systems of Householder-path problems from the Gram where alpha makes them provably well
+  // conditioned (LmState::hmax; BLSQ_LM_CHOL_QRPATH = 0: always the stacked QR)
+  {
+    const char* e_ = getenv("BLSQ_LM_CHOL_QRPATH");
+    const bool on = !(e_ && e_[0] == '0');
+    p->lm.hmax = on ? p->aug_hmax.as<double>() : nullptr;
+    p->lm.lam = p->aug_lam.as<double>();
+    p->lm.k2_max = t.k2_max;
+    p->gram_valid = true;
+  }
   return 0;
 }
 
@@ -1135,6 +1152,7 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
     c.colscale = p->st.d; c.diag_vec = p->st.ediag; c.diag_sqrt = p->lm.sa; c.stride_vec = p->ld;
     c.batch_list = p->lm.active_list + (size_t)(round & 1) * p->B;
     c.skip_path = p->path;
+    c.qr_mask = p->lm.hmax ? p->lm.ncols_lm : nullptr;
     c.count_dev = count_dev; c.expect = expect;
     c.skip_zero = 1;                                    // (lm_Xa: zeroed at allocation, read by lm_update's solves only)
     ctx->begin(K_LM_CHOL);
@@ -1142,8 +1160,32 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
     ctx->end();
     return ee;
   };
+  // the stacked QR of [R_aug; sqrt(alpha) I] for the problems of the round whose mask says so (LmState::ncols_lm)
+  auto qr_round = [&](int round, int grid, const int* count_dev) -> hipError_t {
+    // source = [R_aug | c_aug] read in place, stacked on a VIRTUAL sqrt(alpha) I block
+    QrArgs q = p->tree.base_args();
+    q.A = p->lm.Raug; q.strideA = (long)p->ld * p->ld; q.ldA = p->ld;
+    q.rowsA = aug_block_rows(p->n) + p->n;
+    q.vdiag_row0 = aug_block_rows(p->n); q.vdiag = p->lm.sa;
+    q.F = nullptr; q.strideF = 0; q.ncols_dev = p->lm.ncols_lm;
+    q.batch_list = p->lm.active_list + (size_t)(round & 1) * p->B;   // only the active problems
+    q.count_dev = count_dev;
+    q.rows_per_leaf = p->aug_RP; q.RP = p->aug_RP; q.LDP = p->aug_LDP;
+    q.Rout = p->lm.Xa;
+    q.stack_rows = aug_block_rows(p->n);
+    ctx->begin(K_LM_QR);
+    hipError_t ee = launch_qr(q, 1, grid, ctx->stream);
+    ctx->end();
+    return ee;
+  };
   HIPCHK(ctx, read_back(0));
-  if (!p->use_qr && p->use_chol && p->lm_enable) {
+  // Run-ahead loop: whenever the Grams of the current problems are at hand.  Householder-path problems join
+  // the Cholesky launch where their alpha allows it (LmState::hmax); the stacked QR of the round is enqueued
+  // only while the batch holds such problems at all, over the same upper bound, and leaves at once for a
+  // problem whose mask is 0.  Their triangles dirty the lm_Xa slots outside the factor: the solves never look.
+  const bool chol_any = p->gram_valid && p->lm_enable && (p->use_chol || p->lm.hmax != nullptr) &&
+                        !(p->lm.fused_gram && !p->lm.hmax);
+  if (chol_any) {
     int bound = p->B;                                   // upper bound of the count of the round being enqueued
     int expect = p->lm_expect0 > 0 ? p->lm_expect0 : p->B;   // (kernel choice only: last call's first count)
     // Rounds that had work in the LAST call of this plan are enqueued ahead of their counter, as described
@@ -1162,6 +1204,10 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
       }
       e = chol_round(round, bound, expect, counts + round);
       if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(lm)");
+      if (p->use_qr) {
+        e = qr_round(round, bound, counts + round);
+        if (e != hipSuccess) return ctx->fail(e, "launch_qr(lm)");
+      }
       ctx->begin(K_LM_SOLVE);
       p->lm.round = round;
       e = launch_lm_update(p->lm, bound, ctx->stream);
@@ -1188,20 +1234,8 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
       if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(lm)");
     }
     if (p->use_qr) {
-    // source = [R_aug | c_aug] read in place, stacked on a VIRTUAL sqrt(alpha) I block
-    QrArgs q = p->tree.base_args();
-    q.A = p->lm.Raug; q.strideA = (long)p->ld * p->ld; q.ldA = p->ld;
-    q.rowsA = aug_block_rows(p->n) + p->n;
-    q.vdiag_row0 = aug_block_rows(p->n); q.vdiag = p->lm.sa;
-    q.F = nullptr; q.strideF = 0; q.ncols_dev = p->lm.ncols_lm;
-    q.batch_list = p->lm.active_list + (size_t)(round & 1) * p->B;   // only the active problems
-    q.rows_per_leaf = p->aug_RP; q.RP = p->aug_RP; q.LDP = p->aug_LDP;
-    q.Rout = p->lm.Xa;
-    q.stack_rows = aug_block_rows(p->n);
-    ctx->begin(K_LM_QR);
-    e = launch_qr(q, 1, active, ctx->stream);
-    ctx->end();
-    if (e != hipSuccess) return ctx->fail(e, "launch_qr(lm)");
+      e = qr_round(round, active, nullptr);
+      if (e != hipSuccess) return ctx->fail(e, "launch_qr(lm)");
     }
     ctx->begin(K_LM_SOLVE);
     p->lm.round = round;
@@ -1256,7 +1290,7 @@ extern "C" int blsq_trf_plan_destroy(blsq_trf_plan* p) {
   p->o_info.release(); p->in_J.release(); p->in_f.release(); p->in_vec.release();
   p->in_scal.release();
   p->lm_sa.release(); p->lm_Xa.release(); p->lm_ints.release(); p->lm_sc.release();
-  p->lm_ph.release(); p->aug_colinfo.release();
+  p->lm_ph.release(); p->aug_colinfo.release(); p->aug_hmax.release(); p->aug_lam.release();
   delete p;
   return 0;
 }

@@ -16,6 +16,7 @@ struct QrArgs {
   long strideF;
   const int* ncols_dev;   // optional per-problem N; nullptr -> N
   const int* batch_list;  // optional compacted problem indices: workgroup y factors problem batch_list[y]
+  const int* count_dev;   // optional [1]: the launch is over an upper bound of the list; workgroups y >= *count_dev leave
   const int* require_path;  // optional [B]: problems with require_path[b] == 0 are skipped (they took the Gram path)
   int N;                  // columns to factor (incl. the rhs column if any)
   int rows_per_leaf;      // source rows per leaf (workgroup)
@@ -86,7 +87,13 @@ struct GramCholArgs {
   // idx = gather[b][0 .. N_b-2] ++ [n], N_b = ncols_dev[b] (0: nothing to do); gather is increasing
   const int* ncols_dev;   // [B]
   const int* gather;      // [B][stride_vec]
-  const int* skip_path;   // optional [B]: problems with skip_path[b] != 0 are skipped (they are on the QR path)
+  const int* skip_path;   // optional [B]: problems with skip_path[b] != 0 are skipped (they are on the QR path) ...
+  const int* qr_mask;     // ... unless qr_mask (optional [B]) says 0: a Newton system of a QR-path problem whose alpha
+                          // makes it provably well conditioned is factored here too (LmState::ncols_lm)
+  double* hmax;           // optional [B] out: max_j h_jj, the largest diagonal entry of the system factored
+  double* lam_out;        // optional [B] out: a proven upper bound on lambda_max of the equilibrated system: n (its
+                          // trace) from the factor kernel, min(||R'||_1 ||R'||_inf, ||C||_F, n) once gram_cond_kernel
+                          // has seen the problem
   int* path_out;          // optional [B] out (refreshed problems only): n + 1 = Householder tree, 0 = Gram
   const int* mask;        // optional, as above
   int* fb_mask;           // optional [B] out: n + 1 if the problem needs the Householder tree, else 0
@@ -263,6 +270,19 @@ struct LmState {
   const double* g_h;      // optional [B][ld]: the gradient of the scaled problem, d * (J^T f) (TrfState::g_h).
                           // ||A^T b|| of trust_region.py:119 for the augmented A = [J D; E], b = [f; 0] IS its
                           // norm; without it lm_start forms R_aug^T c_aug — one more pass over the triangle
+  // Newton systems of a HOUSEHOLDER-path problem by Cholesky of the modified Gram: H + alpha I is at least
+  // alpha I, so with C_alpha its unit-diagonal equilibration  lambda_min(C_alpha) >= alpha / (h_max + alpha)  and
+  // lambda_max(C_alpha) <= lambda_max(C) + 1 <= Lambda + 1  (x^T C_alpha x = y^T C y + alpha |D_alpha x|^2 with
+  // |y| <= |x|; Lambda: the certificate's bound on lambda_max(C), at worst the trace n):
+  //     kappa_2(C_alpha) <= (Lambda + 1) (h_max + alpha) / alpha
+  // — a PROVEN bound that costs nothing.  Where it is below the gate, i.e.
+  //     alpha >= 1.01 h_max (Lambda + 1) / (k2_max - Lambda - 1)
+  // (1 % margin for the re-prepared scalings), the round factors the system from the kept Gram exactly as for a
+  // normal-equations-path problem; only below that alpha the stacked QR of [R_aug; sqrt(alpha) I] runs.
+  // hmax == nullptr: always the QR.
+  const double* hmax;     // optional [B] (GramCholArgs::hmax of the augmented factorisation)
+  const double* lam;      // [B] Lambda (GramCholArgs::lam_out)
+  double k2_max;          // the gate
   int fused_gram;         // 1: problems with path[b] == 0 belong to lm_rounds_reg_kernel (N <= 80) — lm_start
                           // and the round kernels leave them alone (a problem's arithmetic must not depend
                           // on whether its batch also holds Householder-path problems)

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
     if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
     return;
   }
-  if (a.skip_path && a.skip_path[b] != 0) return;
+  if (a.skip_path && a.skip_path[b] != 0 && !(a.qr_mask && a.qr_mask[b] == 0)) return;
   double tau = 0.0;                                     // certificate stage 3: factor C - tau I
   if (a.cert_shift) {
     if (!a.cert_flag[b]) return;                        // (uniform: only the problems the norm stage left open)
@@ -106,8 +106,11 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
     psync();
     if (tid == 0) {
       double mn = __builtin_inf(), sm = 0.0;
-      for (int j = 0; j < n; ++j) { const double v = sq[j]; mn = v < mn ? v : mn; sm = fma(v, v, sm); }
+      double mx = 0.0;
+      for (int j = 0; j < n; ++j) { const double v = sq[j]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; sm = fma(v, v, sm); }
       a.colinfo[2 * (long)b] = mn; a.colinfo[2 * (long)b + 1] = sm;
+      if (a.hmax) a.hmax[b] = mx * mx;
+      if (a.lam_out) a.lam_out[b] = (double)n;
     }
   }
   // strictly lower tiles are part of the triangle's image: zero
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
     unsettle();
     return;
   }
-  if (a.skip_path && a.skip_path[b] != 0) return;
+  if (a.skip_path && a.skip_path[b] != 0 && !(a.qr_mask && a.qr_mask[b] == 0)) return;
   double tau = 0.0;                                     // certificate stage 3: factor C - tau I
   if (a.cert_shift) {
     if (!a.cert_flag[b]) return;                        // (wave-uniform)
@@ -306,8 +309,11 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
   wsync();
   if (a.colinfo && tid == 0) {                          // column-norm summary for the rank gate
     double mn = __builtin_inf(), sm = 0.0;
-    for (int j = 0; j < n; ++j) { const double v = sq[j]; mn = v < mn ? v : mn; sm = fma(v, v, sm); }
+    double mx = 0.0;
+    for (int j = 0; j < n; ++j) { const double v = sq[j]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; sm = fma(v, v, sm); }
     a.colinfo[2 * (long)b] = mn; a.colinfo[2 * (long)b + 1] = sm;
+    if (a.hmax) a.hmax[b] = mx * mx;
+    if (a.lam_out) a.lam_out[b] = (double)n;
     tv[0] = mn; tv[1] = sm;                             // (kept for the dogbox finish)
   }
   bad = __any(bad);
@@ -1020,7 +1026,7 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
     if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
     return;
   }
-  if (a.skip_path && a.skip_path[b] != 0) return;
+  if (a.skip_path && a.skip_path[b] != 0 && !(a.qr_mask && a.qr_mask[b] == 0)) return;
   double tau = 0.0;                                     // certificate stage 3: factor C - tau I
   if (a.cert_shift) {
     if (!a.cert_flag[b]) return;                        // (uniform)
@@ -1071,8 +1077,11 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
     __syncthreads();
     if (tid == 0) {
       double mn = __builtin_inf(), sm = 0.0;
-      for (int j = 0; j < n; ++j) { const double v = sq[j]; mn = v < mn ? v : mn; sm = fma(v, v, sm); }
+      double mx = 0.0;
+      for (int j = 0; j < n; ++j) { const double v = sq[j]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; sm = fma(v, v, sm); }
       a.colinfo[2 * (long)b] = mn; a.colinfo[2 * (long)b + 1] = sm;
+      if (a.hmax) a.hmax[b] = mx * mx;
+      if (a.lam_out) a.lam_out[b] = (double)n;
     }
   }
   bad = block_or(bad, red);
@@ -1510,6 +1519,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_cond_kernel(GramCholArgs a) {
   }
   if (tid == 0) {
     if (a.k2_out) a.k2_out[b] = k2;
+    if (a.lam_out && lam >= 1.0) a.lam_out[b] = lam;
     if (!(k2 <= kmax)) {                                 // (NaN fails)
       if (a.cert_flag && is_finite(k2) && lam >= 1.0) {
         // The norm bounds overestimate kappa_2 by 3.5 ... 13 where they decide: leave the verdict to the third
@@ -1603,6 +1613,7 @@ hipError_t launch_gram_cert_shift(const GramCholArgs& a_in, int B, hipStream_t s
   a.dsc = nullptr; a.colinfo = nullptr; a.rinv = nullptr; a.cert_done = nullptr; a.unsettled = nullptr;
   a.dog = GramCholArgs::DogFinish{}; a.lmfin = GramCholArgs::LmFinish{};
   a.batch_list = nullptr; a.count_dev = nullptr; a.skip_path = nullptr; a.diag_sqrt = nullptr;
+  a.qr_mask = nullptr; a.hmax = nullptr; a.lam_out = nullptr;
   a.expect = B;                                         // (left-looking kernel: most workgroups leave at once)
   return launch_gram_chol(a, B, s);
 }

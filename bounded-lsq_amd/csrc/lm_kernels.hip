@@ -143,6 +143,17 @@ hipError_t launch_lm_gate(const LmState& lm, int enable, hipStream_t s) {
   return hipGetLastError();
 }
 
+// which kernel factors the Newton system of problem b at this alpha: the stacked QR (n + 1) or the
+// Cholesky of the modified Gram (0) — LmState::hmax
+__device__ __forceinline__ int lm_qr_cols(const LmState& lm, int b, double alpha, int n) {
+  if (lm.path && lm.path[b] == 0) return 0;                       // normal-equations path: always the Gram
+  if (lm.hmax) {
+    const double hm = lm.hmax[b], L1 = lm.lam[b] + 1.0;
+    if (is_finite(hm) && hm > 0.0 && L1 >= 2.0 && lm.k2_max > L1 && alpha >= 1.01 * hm * L1 / (lm.k2_max - L1)) return 0;
+  }
+  return n + 1;
+}
+
 // restart rule of trust_region.py:128,134
 __device__ __forceinline__ double lm_restart(double lo, double hi) {
   const double gm = sqrt(lo * hi);
@@ -212,7 +223,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_start_kernel(LmState lm, const doub
     sc[SC_ALPHA] = alpha; sc[SC_LO] = lo; sc[SC_HI] = hi; sc[SC_PHI] = phi; sc[SC_DPHI] = dphi;
     sc[SC_DELTA] = Delta;
     st[ST_IT] = 0; st[ST_PHASE] = LM_EVAL; st[ST_NITER] = 0;
-    lm.sa[b] = sqrt(alpha); lm.ncols_lm[b] = (!lm.path || lm.path[b] != 0) ? n + 1 : 0;   // QR launch mask
+    lm.sa[b] = sqrt(alpha); lm.ncols_lm[b] = lm_qr_cols(lm, b, alpha, n);                   // QR launch mask
     lm.active_list[atomicAdd(lm.active_count, 1)] = b;          // list 0 feeds evaluation 0
   }
 }
@@ -298,7 +309,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_update_kernel(LmState lm) {
     sc[SC_ALPHA] = alpha; sc[SC_LO] = lo; sc[SC_HI] = hi; sc[SC_PHI] = phi; sc[SC_DPHI] = dphi;
     st[ST_IT] = it; st[ST_PHASE] = next_phase; st[ST_NITER] = n_iter;
     lm.sa[b] = sqrt(alpha);
-    lm.ncols_lm[b] = (next_phase != LM_IDLE && (!lm.path || lm.path[b] != 0)) ? n + 1 : 0;
+    lm.ncols_lm[b] = (next_phase != LM_IDLE) ? lm_qr_cols(lm, b, alpha, n) : 0;
     if (next_phase != LM_IDLE)
       lm.active_list[(long)((lm.round + 1) & 1) * lm.B + atomicAdd(lm.active_count + lm.round + 1, 1)] = b;
   }

@@ -110,6 +110,7 @@ __global__ __launch_bounds__(QR_NT, (MAXT <= 2 ? 4 : 2)) void qr_panel_kernel(Qr
   // Masked launches over a sparse set of problems go through a compacted index list: a grid
   // whose active workgroups alternate with idle ones lands them on half of the XCDs only
   // (workgroups are dealt round-robin to the 8 XCDs).
+  if (q.count_dev && (int)blockIdx.y >= *q.count_dev) return;   // (launched over an upper bound of the list)
   const int b = q.batch_list ? q.batch_list[blockIdx.y] : (int)blockIdx.y;
   if (q.require_path && q.require_path[b] == 0) return;   // uniform per workgroup
   const int N = q.ncols_dev ? q.ncols_dev[b] : q.N;       // columns to factor

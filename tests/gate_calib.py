@@ -30,6 +30,7 @@ def run(P, Delta, gram):
 
 def report(tag, P, Delta):
     B = P["J"].shape[0]
+    assert B == 1
     s1, k2, st = run(P, Delta, "1")
     s0, _, _ = run(P, Delta, "0")
     for b in range(B):
@@ -42,7 +43,8 @@ def report(tag, P, Delta):
         e0 = np.linalg.norm(s0[b] - So.step) / den
         print("%-28s K2 %.3e  true kappa2(C) %.3e  ratio %6.1f  %s  err(gram-path build) %.1e  err(tree) %.1e"
               % (tag, k2[b], (sv[0] / sv[-1]) ** 2, k2[b] / (sv[0] / sv[-1]) ** 2,
-                 "GRAM" if k2[b] <= 2.5e5 and k2[b] > 0 else "tree", e1, e0))
+                 "GRAM" if st == (1, 0) else "tree", e1, e0)
+              + "  c = err / (eps kappa2) = %.3f" % (e1 / (np.finfo(float).eps * (sv[0] / sv[-1]) ** 2)))
 
 
 def equicorr(B, m, n, rho, seed):

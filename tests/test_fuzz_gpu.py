@@ -151,7 +151,7 @@ def test_fuzz_sweep_of_ill_conditioned_problems():
         recs, bad, paths = run_sweep(70, 2, ctx, budget_s=100, log_kappa=(4.0, 8.0))
         assert not bad, bad
         assert len(recs) >= 40, "time budget cut the sweep too short: %d problems" % len(recs)
-        assert paths[1] >= len(recs) // 3                   # most prescribed-spectrum problems go through the tree
+        assert paths[1] >= 20                               # (bounded problems pass the gate on their augmented system)
         excused = sum(r[7] for r in recs)
         print("fuzz (ill-conditioned): %d problems, paths (Gram, tree) %s, %d beyond 1e-10 and excused by the "
               "oracle's own sensitivity, worst accepted error %.2e"

