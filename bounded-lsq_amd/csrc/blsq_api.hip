@@ -472,6 +472,7 @@ struct blsq_trf_plan {
   const int* path = nullptr;
   bool use_chol = false, use_qr = true;
   DevBuf aug_colinfo;               // [B][2] column-norm summary of R_aug (Gram-path problems)
+  DevBuf aug_mask;                  // [B] launch mask of the stacked QR of [R D; E] (trf_aug_trivial_kernel)
   DevBuf aug_lam;                   // [B] proven bound on lambda_max of the equilibrated H (LmState::lam)
   DevBuf aug_hmax;                  // [B] largest diagonal entry of H (LmState::hmax: which Newton systems of a
                                     // Householder-path problem may be factored from the Gram)
@@ -791,6 +792,7 @@ int trf_alloc_state(blsq_trf_plan* p) {
   ALLOC(p->aug_colinfo, sizeof(double) * (size_t)B * 2);
   ALLOC(p->aug_hmax, sizeof(double) * (size_t)B);
   ALLOC(p->aug_lam, sizeof(double) * (size_t)B);
+  ALLOC(p->aug_mask, sizeof(int) * (size_t)B);
   ALLOC(p->lm_sc, sizeof(double) * (size_t)B * 16);
   ALLOC(p->lm_ph, sizeof(double) * vs);
   HIPCHK(ctx, hipMemsetAsync(p->lm_sa.p, 0, p->lm_sa.bytes, ctx->stream));
@@ -842,8 +844,13 @@ int trf_finish(blsq_trf_plan* p) {
   hipError_t e;
   if (p->use_qr || p->njac != 0 || !p->gate_done) p->x_dirty = true;   // (a stacked QR or a Jacobi launch may follow)
   if (p->use_qr) {
+    // E = 0 (unbounded problems): [R D | c] is the triangle already — written by a copy, masked out of the QR
+    ctx->begin(K_QR_AUG);
+    e = launch_trf_aug_trivial(p->st, p->path, p->aug_mask.as<int>(), nullptr, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_trf_aug_trivial");
     QrArgs q = p->tree.base_args();
-    q.ncols_dev = p->path;                // (nullptr: all problems)
+    q.ncols_dev = p->aug_mask.as<int>();
     // source = R read in place, columns scaled by d on the fly, on top of the VIRTUAL block
     // E = diag(ediag): [R D | c ; E | 0] is never written to memory
     q.A = p->st.Rt; q.strideA = (long)p->ld * p->ld; q.ldA = p->ld;
@@ -1290,7 +1297,7 @@ extern "C" int blsq_trf_plan_destroy(blsq_trf_plan* p) {
   p->o_info.release(); p->in_J.release(); p->in_f.release(); p->in_vec.release();
   p->in_scal.release();
   p->lm_sa.release(); p->lm_Xa.release(); p->lm_ints.release(); p->lm_sc.release();
-  p->lm_ph.release(); p->aug_colinfo.release(); p->aug_hmax.release(); p->aug_lam.release();
+  p->lm_ph.release(); p->aug_colinfo.release(); p->aug_hmax.release(); p->aug_lam.release(); p->aug_mask.release();
   delete p;
   return 0;
 }

@@ -240,6 +240,9 @@ struct TrfStepOut {       // device pointers
                           //         alpha_out, to_bound, qp0, qp1, qp2
   int* info;              // [B][4]: n_iter, branch, choice, status
 };
+// E = 0 problems of the Householder path: the triangle of [R D | c; E | 0] is [R D | c] (written here); mask[b] = n + 1
+// for the problems that still need the stacked QR, 0 for the rest (path / sel as the QR launch would see them)
+hipError_t launch_trf_aug_trivial(const TrfState& st, const int* path, int* mask, const int* sel, hipStream_t s);
 struct LmState;
 hipError_t launch_trf_step(const TrfState& st, const LmState* lm, const double* Delta,
                            const double* alpha_in, double active_rtol,

@@ -97,6 +97,54 @@ hipError_t launch_trf_prep(const TrfState& st, int jac_scaling, int from_gram, c
   return hipGetLastError();
 }
 
+// ------------------------------------------------- trivial augmentation --
+// [R D | c ; E | 0] with E = 0 (no variable has a finite bound in its descent direction: diag_h = 0,
+// trf.py:250 — every unbounded problem) is ALREADY triangular: its triangle is [R D | c] itself, the
+// stacked QR (one workgroup per problem through 17 panels: the latency of one problem, whatever the
+// batch) has nothing to eliminate.  This kernel writes that triangle for such Householder-path problems
+// and builds the launch mask of the QR for the others: mask[b] = n + 1 (QR) or 0 (done here / Gram path).
+__global__ __launch_bounds__(NS_NT) void trf_aug_trivial_kernel(TrfState st, const int* path, int* mask,
+                                                                const int* sel) {
+  __shared__ double red[32];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = st.n, ld = st.ld;
+  const long vo = (long)b * ld;
+  if (path && path[b] == 0) {                            // normal-equations path: no triangle at all
+    if (tid == 0) mask[b] = 0;
+    return;
+  }
+  if (sel && sel[b] <= 1) {                              // (masked factor call: this problem keeps its state)
+    if (tid == 0) mask[b] = 0;
+    return;
+  }
+  int any = 0;
+  for (int j = tid; j < n; j += NS_NT) any |= !(st.ediag[vo + j] == 0.0);   // (NaN counts as non-zero)
+  any = block_or(any, red);
+  if (any) {
+    if (tid == 0) mask[b] = n + 1;
+    return;
+  }
+  if (tid == 0) mask[b] = 0;
+  const double* R = st.Rt + (long)b * ld * ld;
+  double* X = st.X + (long)b * ld * ld;
+  for (int i = tid >> 6; i < ld; i += NS_NW) {           // one wave per row, coalesced
+    for (int j = tid & 63; j < ld; j += WAVE) {
+      double v = 0.0;
+      if (i < n && j >= i) {
+        if (j < n) v = R[(long)i * ld + j] * st.d[vo + j];
+        else if (j == n) v = R[(long)i * ld + n];
+      }
+      X[(long)i * ld + j] = v;
+    }
+  }
+}
+
+hipError_t launch_trf_aug_trivial(const TrfState& st, const int* path, int* mask, const int* sel,
+                                  hipStream_t s) {
+  hipLaunchKernelGGL(trf_aug_trivial_kernel, dim3(st.B), dim3(NS_NT), 0, s, st, path, mask, sel);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ step --
 struct StepCtx {
   int n, ld;

@@ -10,10 +10,13 @@ uses (captured by tests/golden/make_golden.py, which also checks every family he
 reference's own residuals and Jacobians at random points to 1e-11), and what the reference's
 public drivers returned on them.
 
-One family is not restated: CoatingThickness (n = 134, m = 252) is defined by a 252-entry
-measurement table that exists only inside the reference's source file.
+One family is defined by DATA rather than by a formula alone: CoatingThickness (MINPACK-2 "coating
+thickness standardization", n = 134, m = 252) fits two bilinear models to 63 measurements whose 252-entry
+table (abscissae xi [2][63], ordinates y [126], two weights) is captured by make_golden.py into the
+fixture like the start points are (`problems[i]["data"]`); `coating_thickness(data)` restates the model.
 
 FAMILIES: reference factory name -> callable(n_or_m_hint) -> (fun, jac)
+DATA_FAMILIES: ... -> callable(data) -> (fun, jac);  `functions(problem_record)` serves both.
 """
 import numpy as np
 
@@ -398,7 +401,65 @@ FAMILIES = {
     "ChebyshevQuadrature9": lambda: chebyquad(9), "ChebyshevQuadrature10": lambda: chebyquad(10),
     "ChebyshevQuadrature11": lambda: chebyquad(11),
 }
-NOT_RESTATED = {"CoatingThickness": "252-entry measurement table exists only in the reference's source"}
+
+
+def coating_thickness(data):                                  # MINPACK-2 (Averick, Carter, More', Xue 1992)
+    """Errors-in-variables fit of two bilinear response surfaces
+        z_k(u, v) = a_k + b_k u + c_k v + d_k u v,   k = 1, 2,
+    to q = 63 measurements: the abscissae (u_i, v_i) = table + their own corrections (the last 2 q
+    unknowns), x[0:4] = (a, b, c, d)_1, x[4:8] = (a, b, c, d)_2.  Residuals: z_1 - y_1, z_2 - y_2 and the
+    weighted corrections w_1 du, w_2 dv (m = 4 q)."""
+    tab = np.array([[float.fromhex(v) for v in row] for row in data["xi"]])
+    y = np.array([float.fromhex(v) for v in data["y"]])
+    w1, w2 = float.fromhex(data["scale1"]), float.fromhex(data["scale2"])
+    q = tab.shape[1]
+
+    def surfaces(x):
+        u = tab[0] + x[8:8 + q]
+        v = tab[1] + x[8 + q:8 + 2 * q]
+        return u, v
+
+    def fun(x):
+        x = np.asarray(x, float)
+        u, v = surfaces(x)
+        out = np.empty(4 * q)
+        for k in range(2):
+            a, b, c, d = x[4 * k:4 * k + 4]
+            out[k * q:(k + 1) * q] = a + b * u + c * v + d * u * v - y[k * q:(k + 1) * q]
+        out[2 * q:3 * q] = w1 * x[8:8 + q]
+        out[3 * q:] = w2 * x[8 + q:8 + 2 * q]
+        return out
+
+    def jac(x):
+        x = np.asarray(x, float)
+        u, v = surfaces(x)
+        J = np.zeros((4 * q, 8 + 2 * q))
+        i = np.arange(q)
+        for k in range(2):
+            a, b, c, d = x[4 * k:4 * k + 4]
+            rows = k * q + i
+            J[rows, 4 * k] = 1.0
+            J[rows, 4 * k + 1] = u
+            J[rows, 4 * k + 2] = v
+            J[rows, 4 * k + 3] = u * v
+            J[rows, 8 + i] = b + d * v                        # d z_k / d u_i
+            J[rows, 8 + q + i] = c + d * u                    # d z_k / d v_i
+        J[2 * q + i, 8 + i] = w1
+        J[3 * q + i, 8 + q + i] = w2
+        return J
+    return fun, jac
+
+
+DATA_FAMILIES = {"CoatingThickness": coating_thickness}
+NOT_RESTATED = {}
+
+
+def functions(problem):
+    """(fun, jac) of a problem record of tests/golden/suite58.json"""
+    fam = problem["family"]
+    if fam in DATA_FAMILIES:
+        return DATA_FAMILIES[fam](problem["data"])
+    return FAMILIES[fam]()
 
 
 def family_of(problem_name):

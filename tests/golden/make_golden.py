@@ -303,6 +303,29 @@ def make_trf():
     np.savez_compressed(os.path.join(HERE, "trf_large.npz"), **store)
 
 
+def make_trf_gradient_winners():
+    """More tuples in which find_gradient_step (trf.py:159-170) WINS the model comparison of trf.py:300-304
+    (choice 2): one in ~120 seeds of the first hunt.  A wider hunt over seeds, shapes and scalings; the
+    first six winners go to trf_choice2.npz (the other fixtures stay untouched)."""
+    store, names = {}, []
+    for seed in range(520, 6000):
+        m, n = [(24, 6), (40, 8), (64, 16), (96, 24), (30, 5), (200, 40)][seed % 6]
+        P = _synth.trf_problem(seed, m, n)
+        if seed % 2:
+            P["scale"] = np.full(n, (3.0, 0.3, 10.0)[seed % 3])
+        Delta = (10.0, 3.0, 30.0)[(seed // 7) % 3]
+        o = ref_trf_tuple(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"], Delta, 0.0)
+        if o["branch"] == 1 and o["choice"] == 2:
+            name = "grad_%dx%d_s%d" % (m, n, seed)
+            pack(name, dict(P, Delta=Delta, alpha0=0.0), o, store)
+            names.append(name)
+            print("trf", name, "branch", o["branch"], "n_iter", o["n_iter"], "choice", o["choice"])
+            if len(names) == 6:
+                break
+    store["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "trf_choice2.npz"), **store)
+
+
 # ---------------------------------------------------------------- dogbox
 def ref_dog_tuple(J, f, x, lb, ub, scale, on_bound, Delta):
     """Drive the reference's functions as dogbox.py:170-220 does."""
@@ -677,13 +700,32 @@ def make_suite58():
     unb, bnd = ref_problems.extract_lsq_problems()
     rng = np.random.default_rng(58)
     recs, problems, skipped = [], [], []
+    # `only` (names): keep the existing fixture and add just these problems (a family restated later)
+    only = set(sys.argv[2:])
+    if only:
+        with open(os.path.join(HERE, "suite58.json")) as fh:
+            old = json.load(fh)
+        problems = [q for q in old["problems"] if q["name"] not in only]
+        recs = [q for q in old["records"] if q["problem"] not in only]
     for name, rp in unb + bnd:
+        if only and name not in only:
+            continue
         fam = _suite58.family_of(name)
-        if fam not in _suite58.FAMILIES:
+        data = None
+        if fam in _suite58.DATA_FAMILIES:
+            # a family defined by a measurement table: the table is DATA of the reference's problem, captured
+            # from the factory object like the start point is (hex floats), never its code
+            fac = rp.fun.__self__
+            data = dict(xi=[[float(v).hex() for v in row] for row in np.asarray(fac.xi, float)],
+                        y=[float(v).hex() for v in np.asarray(fac.y, float)],
+                        scale1=float(fac.scale1).hex(), scale2=float(fac.scale2).hex())
+            fun, jac = _suite58.DATA_FAMILIES[fam](data)
+        elif fam not in _suite58.FAMILIES:
             skipped.append(name)
             print("suite58", name, "NOT RESTATED:", _suite58.NOT_RESTATED.get(fam, "?"))
             continue
-        fun, jac = _suite58.FAMILIES[fam]()
+        else:
+            fun, jac = _suite58.FAMILIES[fam]()
         x0 = np.asarray(rp.x0, float)
         n = x0.size
         lb = np.full(n, -inf) if rp.bounds[0] is None else np.resize(np.asarray(rp.bounds[0], float), n)
@@ -700,6 +742,8 @@ def make_suite58():
         problems.append(dict(name=name, family=fam, n=n, m=m, bounded=bool("_B" in name),
                              x0=[float(v).hex() for v in x0], lb=[float(v).hex() for v in lb],
                              ub=[float(v).hex() for v in ub]))
+        if data is not None:
+            problems[-1]["data"] = data
 
         def fw(x, fun=fun):
             return np.atleast_1d(fun(x))
@@ -751,6 +795,9 @@ def make_suite58():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dogfb":
         make_dog_fallback()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "choice2":
+        make_trf_gradient_winners()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "suite58":
         make_suite58()

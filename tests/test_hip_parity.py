@@ -34,7 +34,8 @@ def bl():
     return bounded_lsq
 
 
-TRF_CASES = load_npz("trf_small.npz") + load_npz("trf_large.npz")
+TRF_CASES = (load_npz("trf_small.npz") + load_npz("trf_large.npz") +
+             load_npz("trf_choice2.npz"))    # find_gradient_step wins (trf.py:159-170, choice 2)
 
 
 @pytest.fixture(params=["gram_front_end", "qr_tree_only"], autouse=True)

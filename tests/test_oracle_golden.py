@@ -57,7 +57,8 @@ def test_helper_sphere_and_quadratic():
         orc.sphere_intersections(np.array([2.0, 0]), np.ones(2), 1.0)
 
 
-TRF_CASES = load_npz("trf_small.npz") + load_npz("trf_large.npz")
+TRF_CASES = (load_npz("trf_small.npz") + load_npz("trf_large.npz") +
+             load_npz("trf_choice2.npz"))    # find_gradient_step wins (trf.py:159-170, choice 2)
 
 
 @pytest.mark.parametrize("name,ins,out", TRF_CASES, ids=[c[0] for c in TRF_CASES])

@@ -1,9 +1,9 @@
 """Convergence regression on the REFERENCE's OWN benchmark problem set (SURVEY.md 8f-3;
-benchmarks/lsq_problems.py:1003-1018: 58 problems, 57 of them restated in tests/_suite58.py — the one
-left out is defined by a measurement table that exists only in the reference's source).
+benchmarks/lsq_problems.py:1003-1018: 58 problems, all restated in tests/_suite58.py — the one defined by
+a measurement table, CoatingThickness, from the table captured into the fixture as data).
 
 tests/golden/suite58.json holds, per problem, the start point and box of the reference's factory and
-what the reference's public drivers returned (both methods x numeric / 'jac' scaling = 228 records:
+what the reference's public drivers returned (both methods x numeric / 'jac' scaling = 232 records:
 nfev, njev, status, x, objective, optimality, active mask), plus the same runs from start points
 moved by one ulp.  The public front end on the GPU step path must reproduce every record that is
 stable in the reference itself exactly in iteration counts, status and mask; records whose counts
@@ -35,7 +35,7 @@ def unhex(v):
 def solve(rec):
     import bounded_lsq
     p = PROBLEMS[rec["problem"]]
-    fun, jac = _suite58.FAMILIES[p["family"]]()
+    fun, jac = _suite58.functions(p)
     with np.errstate(all="ignore"):
         return bounded_lsq.least_squares(fun, unhex(p["x0"]), jac=jac,
                                          bounds=(unhex(p["lb"]), unhex(p["ub"])),
@@ -45,9 +45,11 @@ def solve(rec):
 
 def test_the_fixture_covers_the_references_problem_set():
     assert S58["reference_problem_count"] == 58
-    assert len(S58["problems"]) == 57 and S58["not_restated"] == ["CoatingThickness"]
+    assert len(S58["problems"]) == 58 and S58["not_restated"] == []
     assert sum(1 for p in S58["problems"] if p["bounded"]) == 26
-    assert len(S58["records"]) == 4 * 57
+    assert len(S58["records"]) == 4 * 58
+    ct = PROBLEMS["CoatingThickness"]
+    assert (ct["n"], ct["m"]) == (134, 252) and len(ct["data"]["y"]) == 126
 
 
 @pytest.mark.parametrize("rec", S58["records"],
@@ -66,7 +68,7 @@ def test_suite58_record(rec):
     if rec["stable"]:
         assert (res.nfev, res.njev, res.status) == (rec["nfev"], rec["njev"], rec["status"])
         obj_ref, x_ref = float.fromhex(rec["obj_value"]), unhex(rec["x"])
-        fun0 = _suite58.FAMILIES[p["family"]]()[0](unhex(p["x0"]))
+        fun0 = _suite58.functions(p)[0](unhex(p["x0"]))
         # (absolute floor relative to the objective at the start: Watson12 ends at 6e-10 from 30,
         #  cond(J) ~ 1e13 — its last digits are not determined by the data)
         np.testing.assert_allclose(res.obj_value, obj_ref, rtol=1e-6,
@@ -77,7 +79,7 @@ def test_suite58_record(rec):
             # the data do not determine x to that accuracy — an ill-conditioned Jacobian at the
             # solution (Watson: cond ~ 1e8 .. 1e13) or a second minimiser of equal value (Biggs
             # EXP6 is symmetric under exchanging its exponential terms)
-            _, jac = _suite58.FAMILIES[p["family"]]()
+            _, jac = _suite58.functions(p)
             with np.errstate(all="ignore"):
                 cond = np.linalg.cond(jac(x_ref))
             twin = abs(res.obj_value - obj_ref) <= 1e-9 * max(1.0, obj_ref) and res.optimality <= 1e-6
