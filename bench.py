@@ -320,6 +320,7 @@ def time_steps(bench, steps, warmup, fence, min_time=0.0, reduce_max=None):
         ctx.timing(True)
         ctx.timing_reset()
         ctx.gram_stats(reset=True)
+        ctx.cqr2_stats(reset=True)
         t0 = time.perf_counter()
         for _ in range(k):
             bench.step()
@@ -615,9 +616,11 @@ def main():
                 km = max(2, min(steps_requested, 20))
                 em, km = time_steps(bm, km, 1, ctx.sync)
                 gsm = ctx.gram_stats()
+                cq2 = ctx.cqr2_stats(reset=True)
                 extras[key] = {
                     "value": B * km / em, "unit": "step-solves/s", "ms_per_step": 1e3 * em / km, "steps": km,
-                    "factorisation_paths": {"normal_equations": gsm[0] // km, "householder_tree": gsm[1] // km},
+                    "factorisation_paths": {"normal_equations": gsm[0] // km, "choleskyqr2": cq2 // km,
+                                            "householder_tree": gsm[1] // km - cq2 // km},
                     "parity": bm.parity(min(16, B)) if args.check > 0 else None,
                     "kernels_ms_per_step": {k: round(v[0] / km, 4) for k, v in ctx.timing_read().items() if v[0] > 0},
                     "note": ("kappa(J) log-uniform over [1, 1e4]; each problem on the path its certificate allows. "

@@ -72,6 +72,7 @@ SIGNATURES = {
     "blsq_tsqr_combine_dev": (C.c_int, [vp] + [vp] * 5 + [C.c_int]),
     "blsq_debug_cqr_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
     "blsq_debug_gram_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
+    "blsq_debug_cqr2_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
     "blsq_debug_probe": (C.c_int, [vp, C.c_int, C.c_int, c_double_p]),
     "blsq_outer_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "blsq_outer_destroy": (C.c_int, [vp]),
@@ -209,6 +210,12 @@ class Context:
         out = (C.c_uint64 * 2)()
         self.check(self.lib.blsq_debug_gram_stats(self.h, out, 1 if reset else 0), "gram_stats")
         return int(out[0]), int(out[1])
+
+    def cqr2_stats(self, reset=False):
+        """-> problems (of those the gate handed on) factored by the CholeskyQR2 middle tier."""
+        out = (C.c_uint64 * 1)()
+        self.check(self.lib.blsq_debug_cqr2_stats(self.h, out, 1 if reset else 0), "cqr2_stats")
+        return int(out[0])
 
     # ---- collective over the ranks of one tall problem (RCCL, blsq_comm_*) ---------------------
     def comm_new_id(self):

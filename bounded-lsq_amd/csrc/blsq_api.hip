@@ -22,10 +22,10 @@ namespace {
 constexpr int RMAX = QR_MAX_TILES * 16;   // rows a workgroup can stage (qr_panel.hip): 1024
 
 enum Slot { K_QR_LEAF = 0, K_QR_MERGE, K_PREP, K_QR_AUG, K_JACOBI, K_STEP, K_LM_GATE, K_LM_QR, K_LM_SOLVE,
-            K_GRAM, K_GRAM_CHOL, K_GRAM_GATE, K_AUG_CHOL, K_LM_CHOL, K_NSLOT };
+            K_GRAM, K_GRAM_CHOL, K_GRAM_GATE, K_AUG_CHOL, K_LM_CHOL, K_CQR2_APPLY, K_CQR2_COMBINE, K_NSLOT };
 const char* kSlotNames[K_NSLOT] = {"qr_leaf", "qr_merge", "prep", "qr_aug", "jacobi_svd", "step",
                                    "lm_gate", "lm_qr", "lm_solve", "gram", "gram_chol", "gram_gate",
-                                   "aug_chol", "lm_chol"};
+                                   "aug_chol", "lm_chol", "cqr2_apply", "cqr2_combine"};
 
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
 // rows of the stacked systems [R D; E] / [R_aug; sqrt(alpha) I]: two blocks of
@@ -53,6 +53,7 @@ struct blsq_ctx {
                                     // ([0..3] one-shot read-backs, [8 + r] Newton-round counters)
   hipEvent_t lm_ev[2] = {nullptr, nullptr};   // read-back of the counter of round r has landed (r & 1)
   long long gram_fast = 0, gram_fallback = 0;   // problems factored by the normal equations / handed to the QR tree
+  unsigned long long* cq_accept_dev = nullptr;  // device counter: rejected problems the CholeskyQR2 tier factored
   // collective over the ranks of one tall problem (RCCL over xGMI; blsq_comm_*)
   ncclComm_t comm = nullptr;
   int comm_ranks = 1, comm_rank = 0;
@@ -206,6 +207,9 @@ struct QrTree {
   DevBuf gram_cert;                        // [B] ints: 1 = proven inside the factor kernel (N <= 80)
   DevBuf gram_cflag, gram_ctau;            // [B] certificate stage 3: problems left to the shifted factorisation, their shifts
   double k2_max = 0.0;                     // the gate for this plan's row count (gram_k2_max)
+  // CholeskyQR2 middle tier (cqr2_kernels.hip): buffers allocated on first use
+  bool cqr2 = false;
+  DevBuf cq_W, cq_Wf, cq_G2, cq_R1, cq_R2, cq_z, cq_ints;
   bool fb_zeroed = false;                  // the gate counters were cleared by pack_vecs_kernel of this factor call
   // per-problem path of the CURRENT triangles: gram_path()[b] = n + 1 (Householder tree) or 0 (Gram).
   // any_gram / any_qr: whether a problem of either kind can exist (host-side upper bounds)
@@ -281,6 +285,10 @@ struct QrTree {
       if (e == hipSuccess) e = hipMemsetAsync(gram_cflag.p, 0, gram_cflag.bytes, ctx->stream);
       if (e != hipSuccess) return ctx->fail(e, "hipMalloc(certificate stage 3)");
       k2_max = gram_k2_max(rows);
+      {
+        const char* ce = getenv("BLSQ_CQR2");
+        cqr2 = cqr2_supported(rows, n) && !(ce && ce[0] == '0');
+      }
       e = hipMemsetAsync(gram_cert.p, 0, gram_cert.bytes, ctx->stream);
       if (e != hipSuccess) return ctx->fail(e, "hipMemsetAsync(Gram certificate flags)");
       e = hipMemsetAsync(gram_k2.p, 0, gram_k2.bytes, ctx->stream);
@@ -300,6 +308,7 @@ struct QrTree {
     gram_part.release(); gram_dsc.release(); gram_ints.release(); gram_keep.release();
     gram_rinv.release(); gram_ywork.release(); gram_k2.release(); gram_cert.release();
     gram_cflag.release(); gram_ctau.release();
+    cq_W.release(); cq_Wf.release(); cq_G2.release(); cq_R1.release(); cq_R2.release(); cq_z.release(); cq_ints.release();
   }
   // [J f] -> triangle by the normal equations where the conditioning gate allows it.
   // Returns the number of problems left for the Householder tree in *nfallback; their indices
@@ -396,6 +405,98 @@ struct QrTree {
       if (e != hipSuccess) return ctx->fail(e, "launch_qr");
     }
     return 0;
+  }
+  // The problems the certificate rejected (fb_list(), nfb of them; fb_mask() = n + 1 for each): a triangle of
+  // [J f] of Householder quality into their Rfinal slots — by CholeskyQR2 where its acceptance test passes
+  // (second pass over J through the MFMA pipe, cqr2_kernels.hip), by the Householder TSQR tree for the rest.
+  int run_fallback(blsq_ctx* ctx, const double* dJ, const double* df, int ldJ, int nfb) {
+    if (!cqr2 || !gram) return run_levels(ctx, dJ, df, ldJ, fb_mask(), fb_list(), nfb);
+    hipError_t e = hipSuccess;
+    if (!cq_W.p) {
+      e = cq_W.alloc(sizeof(double) * (size_t)B * m * n);
+      if (e == hipSuccess) e = cq_Wf.alloc(sizeof(double) * (size_t)B * m);
+      if (e == hipSuccess) e = cq_G2.alloc(sizeof(double) * (size_t)B * NPAD * NPAD);
+      if (e == hipSuccess) e = cq_R2.alloc(sizeof(double) * (size_t)B * NPAD * NPAD);
+      if (e == hipSuccess) e = cq_R1.alloc(sizeof(double) * (size_t)B * NPAD * NPAD);
+      if (e == hipSuccess) e = hipMemsetAsync(cq_R1.p, 0, cq_R1.bytes, ctx->stream);
+      if (e == hipSuccess) e = cq_z.alloc(sizeof(double) * (size_t)B * NPAD);
+      if (e == hipSuccess) e = cq_ints.alloc(sizeof(int) * (4 * (size_t)B + 4));
+      if (e == hipSuccess) e = hipMemsetAsync(cq_G2.p, 0, cq_G2.bytes, ctx->stream);   // (lower tiles are never written)
+      if (e == hipSuccess) e = hipMemsetAsync(cq_R2.p, 0, cq_R2.bytes, ctx->stream);
+      if (e == hipSuccess) e = hipMemsetAsync(cq_ints.p, 0, cq_ints.bytes, ctx->stream);
+      if (e != hipSuccess) {                              // no room for the second pass: the tree does it all
+        cq_W.release(); cq_Wf.release(); cq_G2.release(); cq_R1.release(); cq_R2.release(); cq_z.release(); cq_ints.release();
+        cqr2 = false;
+        (void)hipGetLastError();
+        return run_levels(ctx, dJ, df, ldJ, fb_mask(), fb_list(), nfb);
+      }
+    }
+    int* piv1 = cq_ints.as<int>();
+    int* runm = piv1 + B;
+    int* piv2 = piv1 + 2 * (size_t)B;
+    int* tmask = piv1 + 3 * (size_t)B;
+    int* cnt = piv1 + 4 * (size_t)B;
+    double* Rf = levels.back().R.as<double>();
+    double* R1 = cq_R1.as<double>();
+    // 1. R1 | c = chol of the plain Gram (listed problems) into scratch, its tile inverses and scales
+    GramCholArgs c{};
+    c.Gsrc = gram_keep.as<double>(); c.G = R1; c.NPAD = NPAD; c.n = n; c.skip_zero = 1;
+    c.batch_list = fb_list(); c.fb_mask = piv1; c.fail_count = cnt;
+    c.dsc = gram_dsc.as<double>(); c.rinv = gram_rinv.as<double>(); c.ywork = gram_ywork.as<double>();
+    c.k2_max = 1e300; c.pivot_floor = 1e-14;
+    ctx->begin(K_GRAM_CHOL);
+    e = launch_gram_chol(c, nfb, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(cqr2 first factor)");
+    // 2. Y = R1'^-T by the certificate's kernel, which also bounds kappa_2 of the equilibrated plain Gram: the
+    //    second pass multiplies by the EXPLICIT inverse, whose error enters the triangle as eps kappa(J) (measured:
+    //    step error 2e-18 kappa, tools/cqr2_check.py), so the tier takes a problem only if that PROVEN bound is
+    //    below CQR2_K2_MAX = 1e12 (kappa(J D) <= 1e6: error <= 2e-12); beyond, the Householder tree.
+    GramCholArgs cy = c;
+    cy.batch_list = nullptr; cy.mask = fb_mask(); cy.k2_max = CQR2_K2_MAX;
+    ctx->begin(K_GRAM_GATE);
+    e = launch_gram_gate(cy, B, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_gram_gate(cqr2 inverse)");
+    // 3. z = R^-1 c, launch mask;  4. W = J R^-1, w_f = f - J z
+    Cqr2Args q{};
+    q.J = dJ; q.strideJ = (long)m * ldJ; q.ldJ = ldJ; q.F = df; q.strideF = m;
+    q.m = m; q.n = n; q.NPAD = NPAD; q.list = fb_list(); q.run = runm;
+    q.Y = gram_ywork.as<double>(); q.dsc = gram_dsc.as<double>(); q.R1 = R1; q.z = cq_z.as<double>();
+    q.Wj = cq_W.as<double>(); q.strideW = (long)m * n; q.Wf = cq_Wf.as<double>(); q.strideWf = m;
+    ctx->begin(K_CQR2_APPLY);
+    e = launch_cqr2_prep(q, nfb, piv1, runm, ctx->stream);
+    if (e == hipSuccess) e = launch_cqr2_apply(q, nfb, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_cqr2_apply");
+    // 5. G2 = [W w_f]^T [W w_f]
+    GramArgs g{};
+    g.J = q.Wj; g.strideJ = q.strideW; g.ldJ = n; g.F = q.Wf; g.strideF = m;
+    g.m = m; g.n = n; g.NPAD = NPAD; g.mask = runm; g.list = fb_list();   // (compacted: all XCDs)
+    double* G2 = cq_G2.as<double>();
+    g.G = gram_nchunk > 1 ? gram_part.as<double>() : G2;
+    ctx->begin(K_GRAM);
+    bool fused = false;
+    e = launch_gram(g, gram_nchunk, nfb, ctx->stream, G2, &fused);
+    if (e == hipSuccess && gram_nchunk > 1 && !fused)
+      e = launch_gram_reduce(gram_part.as<double>(), gram_nchunk, NPAD, G2, runm, B, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_gram(cqr2 second pass)");
+    // 6. R2 | c2 = chol(G2)
+    GramCholArgs c2{};
+    c2.Gsrc = G2; c2.G = cq_R2.as<double>(); c2.NPAD = NPAD; c2.n = n;
+    c2.batch_list = fb_list(); c2.mask = runm; c2.fb_mask = piv2; c2.fail_count = cnt + 1;
+    c2.k2_max = 1e300; c2.pivot_floor = 0.25;           // (G2 ~ I: a pivot below 1/2 means the first pass failed)
+    ctx->begin(K_GRAM_CHOL);
+    e = launch_gram_chol(c2, nfb, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(cqr2 second factor)");
+    // 7. acceptance + R~ = R2 [R c; 0 1] into the triangle slot;  8. the tree for what is left
+    ctx->begin(K_CQR2_COMBINE);
+    e = launch_cqr2_combine(q, nfb, runm, piv2, G2, cq_R2.as<double>(), Rf, tmask, ctx->cq_accept_dev, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_cqr2_combine");
+    return run_levels(ctx, dJ, df, ldJ, tmask, fb_list(), nfb);
   }
   int* fb_mask() const { return gram_ints.as<int>(); }
   int* fb_count() const { return gram_ints.as<int>() + B; }
@@ -570,6 +671,8 @@ extern "C" int blsq_ctx_create(int device_id, blsq_ctx** out) {
   e = hipHostMalloc((void**)&c->pinned, 32 * sizeof(int), hipHostMallocDefault);
   if (e != hipSuccess) { hipStreamDestroy(c->stream); delete c; return (int)e; }
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->lm_ev[i], hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->cq_accept_dev, sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemset(c->cq_accept_dev, 0, sizeof(unsigned long long));
   if (e != hipSuccess) { hipHostFree(c->pinned); hipStreamDestroy(c->stream); delete c; return (int)e; }
   *out = c;
   return 0;
@@ -586,6 +689,7 @@ extern "C" int blsq_ctx_destroy(blsq_ctx* ctx) {
   for (auto e : ctx->lm_ev) if (e) hipEventDestroy(e);
   hipStreamDestroy(ctx->stream);
   if (ctx->pinned) hipHostFree(ctx->pinned);
+  if (ctx->cq_accept_dev) hipFree(ctx->cq_accept_dev);
   delete ctx;
   return 0;
 }
@@ -894,7 +998,7 @@ int trf_after_triangle(blsq_trf_plan* p, const double* Rt, int scale_mode, int r
   blsq_ctx* ctx = p->ctx;
   p->st.Rt = Rt; p->st.Gk = nullptr; p->st.path = nullptr;
   p->path = nullptr; p->use_chol = false; p->use_qr = true;
-  p->lm.path = nullptr; p->lm.colinfo = nullptr; p->lm.hmax = nullptr; p->gram_valid = false;
+  p->lm.path = nullptr; p->lm.colinfo = nullptr; p->lm.hmax = nullptr; p->lm.k2 = nullptr; p->gram_valid = false;
   p->tree.path_valid = false; p->tree.any_gram = false; p->tree.any_qr = true;
   p->gate_done = false;
   ctx->begin(K_PREP);
@@ -998,7 +1102,6 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, 
   p->use_chol = t.any_gram;
   p->use_qr = t.any_qr;
   p->lm.path = p->path;
-  p->lm.colinfo = p->use_chol ? p->aug_colinfo.as<double>() : nullptr;
   // Newton systems of Householder-path problems from the Gram where alpha makes them provably well
   // conditioned (LmState::hmax; BLSQ_LM_CHOL_QRPATH = 0: always the stacked QR)
   {
@@ -1007,6 +1110,8 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, 
     p->lm.hmax = on ? p->aug_hmax.as<double>() : nullptr;
     p->lm.lam = p->aug_lam.as<double>();
     p->lm.k2_max = t.k2_max;
+    p->lm.k2 = t.gram_k2.as<double>();
+    p->lm.colinfo = p->aug_colinfo.as<double>();         // (written for every problem the Cholesky kernel looked at)
     p->gram_valid = true;
   }
   return 0;
@@ -1016,7 +1121,7 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, 
 int trf_fallback_stage(blsq_trf_plan* p, const double* dJ, const double* df, int ldJ, int scale_mode,
                        int nfb) {
   blsq_ctx* ctx = p->ctx;
-  int rc = p->tree.run_levels(ctx, dJ, df, ldJ, p->tree.fb_mask(), p->tree.fb_list(), nfb);
+  int rc = p->tree.run_fallback(ctx, dJ, df, ldJ, nfb);
   if (rc) return rc;
   ctx->begin(K_PREP);
   hipError_t e = launch_trf_prep(p->st, scale_mode, 0, p->tree.fb_mask(), 1, ctx->stream);
@@ -1093,7 +1198,7 @@ int trf_resolve(blsq_trf_plan* p, bool* redo) {
   p->njac = p->gate_done ? njac : -1;
   p->use_chol = t.any_gram;
   p->use_qr = t.any_qr;
-  p->lm.colinfo = p->use_chol ? p->aug_colinfo.as<double>() : nullptr;
+  p->lm.colinfo = p->aug_colinfo.as<double>();
   int rc;
   if (nfb > 0 && (rc = trf_fallback_stage(p, p->pend_dJ, p->pend_df, p->pend_ldJ, p->pend_scale_mode, nfb)))
     return rc;
@@ -1140,13 +1245,13 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
       p->lm.fused_gram = 1;
     }
   }
+  int* pin = ctx->pinned + 8;
   if (!p->lm_counts_clean) HIPCHK(ctx, hipMemsetAsync(counts, 0, 16 * sizeof(int), ctx->stream));
   p->lm_counts_clean = false;
   ctx->begin(K_LM_SOLVE);
   e = launch_lm_start(p->lm, dDelta, dalpha_in, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_lm_start");
-  int* pin = ctx->pinned + 8;
   auto read_back = [&](int r) -> hipError_t {            // counter of round r -> pin[r], event r & 1
     hipError_t ee = hipMemcpyAsync(pin + r, counts + r, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     if (ee == hipSuccess) ee = hipEventRecord(ctx->lm_ev[r & 1], ctx->stream);
@@ -1949,7 +2054,7 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
   t.note_paths(ctx, nfb, mask != nullptr);
   if (skip_tail) { p->gate_done = false; return 0; }
   if (nfb > 0) {
-    if ((rc = t.run_levels(ctx, dJ, df, ldJ, t.fb_mask(), t.fb_list(), nfb))) return rc;
+    if ((rc = t.run_fallback(ctx, dJ, df, ldJ, nfb))) return rc;
     ctx->begin(K_PREP);
     e = launch_dog_prep(p->st, scale_mode, 0, t.fb_mask(), 1, ctx->stream);
     ctx->end();
@@ -1991,7 +2096,7 @@ int dog_resolve(blsq_dogbox_plan* p, bool* redo) {
   p->njac = p->gate_done ? njac : -1;
   int rc;
   if (nfb > 0) {
-    if ((rc = t.run_levels(ctx, p->pend_dJ, p->pend_df, p->pend_ldJ, t.fb_mask(), t.fb_list(), nfb))) return rc;
+    if ((rc = t.run_fallback(ctx, p->pend_dJ, p->pend_df, p->pend_ldJ, nfb))) return rc;
     ctx->begin(K_PREP);
     hipError_t e = launch_dog_prep(p->st, p->pend_scale_mode, 0, t.fb_mask(), 1, ctx->stream);
     ctx->end();
@@ -2544,6 +2649,18 @@ extern "C" int blsq_debug_gram_stats(blsq_ctx* ctx, uint64_t* out2, int reset) {
   out2[0] = (uint64_t)ctx->gram_fast;
   out2[1] = (uint64_t)ctx->gram_fallback;
   if (reset) { ctx->gram_fast = 0; ctx->gram_fallback = 0; }
+  return 0;
+}
+
+extern "C" int blsq_debug_cqr2_stats(blsq_ctx* ctx, uint64_t* out1, int reset) {
+  if (!ctx) return -1;
+  if (!out1) return ctx->bad(2, "out is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  unsigned long long v = 0ULL;
+  HIPCHK(ctx, hipMemcpyAsync(&v, ctx->cq_accept_dev, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+  if (reset) HIPCHK(ctx, hipMemsetAsync(ctx->cq_accept_dev, 0, sizeof(v), ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  out1[0] = v;
   return 0;
 }
 

@@ -62,6 +62,9 @@ struct GramArgs {
   int NPAD;               // row stride (and row count) of each G slot
   double* G;              // [B][chunks][NPAD*NPAD] upper tile blocks
   const int* mask;        // optional: problems with mask[b] <= 1 are skipped
+  const int* list;        // optional compacted problem indices: workgroup y works on problem list[y] (the launch
+                          // is then over the list's length; a masked launch whose active workgroups alternate
+                          // with idle ones lands on a fraction of the XCDs)
   int rows_per_chunk;     // set by launch_gram
   int rhs_valu;           // set by launch_gram: J^T f / f^T f accumulated by the vector ALUs
   double* Gscr;           // set by launch_gram (pair mode): the chunk-partials buffer, used as scratch
@@ -182,6 +185,31 @@ hipError_t launch_gram_gate(const GramCholArgs& a, int B, hipStream_t s);
 // same source, scalings and gather as the factor call `a` describes, output into a.ywork
 hipError_t launch_gram_cert_shift(const GramCholArgs& a, int B, hipStream_t s);
 
+// ------------------------------------------------ CholeskyQR2 middle tier (cqr2_kernels.hip) ----
+struct Cqr2Args {
+  const double* J; long strideJ; int ldJ;   // [B][m][ldJ] the Jacobians (read in place)
+  const double* F; long strideF;            // [B][m]
+  int m, n, NPAD;
+  const int* list;        // compacted indices of the problems the certificate rejected
+  const int* run;         // [B] n + 1: second pass for this problem, 0: not (set by cqr2_prep)
+  const double* Y;        // [B][NPAD*NPAD] R1'^-T (lower triangular; gram_cond_kernel's work array)
+  const double* dsc;      // [B][NPAD] the equilibration of the first Cholesky: R1' = R1 diag(dsc)
+  const double* R1;       // [B][NPAD*NPAD] R1 | c as stored by the first Cholesky
+  double* z;              // [B][NPAD] R1^-1 c
+  double* Wj; long strideW;   // [B][m][n]  W = J R1^-1
+  double* Wf; long strideWf;  // [B][m]     f - J R1^-1 c
+  int rows_per_wg;        // set by launch_cqr2_apply
+};
+constexpr double CQR2_K2_MAX = 1.0e12;   // largest proven kappa_2 of the equilibrated J^T J the tier accepts
+bool cqr2_supported(int m, int n);
+hipError_t launch_cqr2_prep(const Cqr2Args& a, int count, const int* pivot_mask, int* run, hipStream_t s);
+hipError_t launch_cqr2_apply(const Cqr2Args& a, int count, hipStream_t s);
+// acceptance (Gershgorin on G2 + the second Cholesky's pivots) and R~ = R2 [R c; 0 1] (a.R1: scratch) into
+// Rout, the problems' triangle slots; tree_mask[b] = 0 (accepted) / n + 1 (Householder tree); *accepted counts
+hipError_t launch_cqr2_combine(const Cqr2Args& a, int count, const int* run, const int* pivot2, const double* G2,
+                               const double* R2, double* Rout, int* tree_mask, unsigned long long* accepted,
+                               hipStream_t s);
+
 // ------------------------------------------------------------- Jacobi -----
 // One-sided Jacobi on the ROWS of the n x (n+1) array [R | c] (row stride ld):
 // U^T [R | c] = [S V^T | U^T c].  In place.
@@ -267,6 +295,9 @@ struct LmState {
   int* active_list;       // [2][B] their indices, compacted (list r & 1 feeds evaluation r)
   const double* colinfo;  // optional [B][2] from the augmented Cholesky (Gram-path problems): min / sum of
                           // the squared column norms of R_aug — a cheap sufficient test for the rank gate
+  const double* k2;       // optional [B]: the certificate's PROVEN bound on kappa_2 of the equilibrated augmented system
+                          // (0: none).  A Householder-path problem with a finite bound needs no estimate of
+                          // s_min either: s_min(R_aug)^2 = lambda_min(H) >= min_j h_jj / K2
   const int* path;        // optional [B]: != 0 -> the problem's Newton systems are factored by QR,
                           // 0 -> by Cholesky of the modified Gram (nullptr: QR for all)
   int round;              // evaluation number of this launch (host-set)

@@ -7,6 +7,7 @@
 //   gram_cond_kernel<NWP>   the conditioning certificate (a PROVEN bound on kappa_2)
 #include "gram_common.h"
 #include "tri_ops.h"
+#include "lm_body.h"
 #include "chol16.h"
 
 namespace blsq {
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
     if (tid == 0 && a.fb_mask) {
       a.fb_mask[b] = a.n + 1; { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }   // (the tree factors ALL n + 1 columns)
       if (a.path_out) a.path_out[b] = a.n + 1;
+      if (a.k2_out && !a.cert_shift) a.k2_out[b] = 0.0;
     }
     return;
   }
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
     a.fb_mask[b] = fail ? a.n + 1 : 0;
     if (a.path_out) a.path_out[b] = fail ? a.n + 1 : 0;
     if (fail) { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
+    if (fail && !a.cert_shift && a.k2_out) a.k2_out[b] = 0.0;      // (no bound for this factorisation)
     if (a.cert_shift) {
       a.cert_flag[b] = 0;
       if (!fail && a.k2_out) a.k2_out[b] = a.k2_max;    // proven: kappa_2 <= Lambda / tau
@@ -361,6 +364,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
     if (tid == 0 && a.fb_mask) {
       a.fb_mask[b] = a.n + 1; { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }   // (the tree factors ALL n + 1 columns)
       if (a.path_out) a.path_out[b] = a.n + 1;
+      if (a.k2_out && !a.cert_shift) a.k2_out[b] = 0.0;
     }
     unsettle();
     return;
@@ -435,6 +439,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
     a.fb_mask[b] = fail ? a.n + 1 : 0;
     if (a.path_out) a.path_out[b] = fail ? a.n + 1 : 0;
     if (fail) { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
+    if (fail && !a.cert_shift && a.k2_out) a.k2_out[b] = 0.0;      // (no bound for this factorisation)
     if (a.cert_shift) {
       a.cert_flag[b] = 0;
       if (!fail && a.k2_out) a.k2_out[b] = kmax;        // proven: kappa_2 <= Lambda / tau
@@ -1009,15 +1014,11 @@ hipError_t launch_lm_rounds_reg(const GramCholArgs& c, const LmState& lm, const 
 // registers (176 VGPRs) the compiler spilled 76 VGPRs to scratch and reloaded / stored them in
 // every row-block step; with eight slots in LDS (112 KB) 28 remain (two Newton rounds of 4096 x 256,
 // 512 problems: 0.404 -> 0.376 ms; same operations in the same order, same bits).
+// The factorisation of ONE problem by the calling workgroup (GR_NT threads): the body of gram_chol_rl_kernel.  sh: the dynamic LDS (launch_gram_chol sizes it),
+// red: 32 doubles, pminsh / flagsh: one double / int of static LDS.  All exits are uniform over the workgroup.
 template <int SL, int KL>
-__global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) {
-  extern __shared__ double sh[];
-  __shared__ double red[32];
-  __shared__ double pminsh;
-  __shared__ int flagsh;                                // last diagonal tile handed to wave 0
-  const int pidx = (int)blockIdx.x;
-  if (a.count_dev && pidx >= *a.count_dev) return;
-  const int b = a.batch_list ? a.batch_list[pidx] : pidx;
+__device__ __forceinline__ void chol_rl_body(const GramCholArgs& a, const int b, double* sh, double* red,
+                                             double& pminsh, int& flagsh) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane >> 4, lc = lane & 15;
@@ -1091,6 +1092,7 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
     if (tid == 0 && a.fb_mask) {
       a.fb_mask[b] = a.n + 1; { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }   // (the tree factors ALL n + 1 columns)
       if (a.path_out) a.path_out[b] = a.n + 1;
+      if (a.k2_out && !a.cert_shift) a.k2_out[b] = 0.0;
     }
     return;
   }
@@ -1254,11 +1256,24 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
     a.fb_mask[b] = fail ? a.n + 1 : 0;
     if (a.path_out) a.path_out[b] = fail ? a.n + 1 : 0;
     if (fail) { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
+    if (fail && !a.cert_shift && a.k2_out) a.k2_out[b] = 0.0;      // (no bound for this factorisation)
     if (a.cert_shift) {
       a.cert_flag[b] = 0;
       if (!fail && a.k2_out) a.k2_out[b] = a.k2_max;    // proven: kappa_2 <= Lambda / tau
     }
   }
+}
+
+template <int SL, int KL>
+__global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) {
+  extern __shared__ double sh[];
+  __shared__ double red[32];
+  __shared__ double pminsh;
+  __shared__ int flagsh;                                // last diagonal tile handed to wave 0
+  const int pidx = (int)blockIdx.x;
+  if (a.count_dev && pidx >= *a.count_dev) return;
+  const int b = a.batch_list ? a.batch_list[pidx] : pidx;
+  chol_rl_body<SL, KL>(a, b, sh, red, pminsh, flagsh);
 }
 
 // ---- conditioning gate: a PROVEN bound on kappa_2 of the equilibrated system -----------------------

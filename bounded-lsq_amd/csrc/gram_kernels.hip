@@ -29,7 +29,7 @@ namespace blsq {
 template <int SLOTS, int NCB>
 __global__ __launch_bounds__(GR_NT, (SLOTS <= 8 ? 4 : 2)) void gram_kernel(GramArgs a) {
   extern __shared__ double lds[];
-  const int b = blockIdx.y;
+  const int b = a.list ? a.list[blockIdx.y] : (int)blockIdx.y;
   if (a.mask && a.mask[b] <= 1) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -234,7 +234,7 @@ __device__ __forceinline__ void gram16_wave(const GramArgs& a, double* lds) {
   constexpr int NF = 16 - W;                            // fragments per k-step: column tiles W .. 15
   constexpr int N0 = 16 - W, N1 = W + 1;                // tiles of tile row W / of tile row 15 - W
   constexpr int A1 = 15 - 2 * W;                        // fragment index of tile row 15 - W
-  const int b = blockIdx.y;
+  const int b = a.list ? a.list[blockIdx.y] : (int)blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63;
   const int lr = lane >> 4, lc = lane & 15;
   const int n = a.n, N = n + 1;
@@ -457,7 +457,7 @@ __device__ __forceinline__ void gram16_wave(const GramArgs& a, double* lds) {
 template <bool RHS, bool PAIR>
 __global__ __launch_bounds__(GR_NT, 2) void gram16_kernel(GramArgs a) {
   extern __shared__ double lds[];
-  if (a.mask && a.mask[blockIdx.y] <= 1) return;
+  if (a.mask && a.mask[a.list ? a.list[blockIdx.y] : (int)blockIdx.y] <= 1) return;
   const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   switch (w) {
     case 0: gram16_wave<0, RHS, PAIR>(a, lds); break;
@@ -489,7 +489,7 @@ __device__ __forceinline__ void gram8_wave(const GramArgs& a, double* lds) {
   constexpr int NF = NTJ - P;                           // fragments per k-step: column tiles P .. 7
   constexpr int N0 = NTJ - P, N1 = P + 1;               // tiles of tile row P / of tile row 7 - P
   constexpr int A1 = NTJ - 1 - 2 * P;                   // fragment index of tile row 7 - P
-  const int b = blockIdx.y;
+  const int b = a.list ? a.list[blockIdx.y] : (int)blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63;
   const int lr = lane >> 4, lc = lane & 15;
   const int n = a.n, N = n + 1;
@@ -656,7 +656,7 @@ __device__ __forceinline__ void gram8_wave(const GramArgs& a, double* lds) {
 template <bool RHS>
 __global__ __launch_bounds__(GR_NT, 2) void gram8_kernel(GramArgs a) {
   extern __shared__ double lds[];
-  if (a.mask && a.mask[blockIdx.y] <= 1) return;
+  if (a.mask && a.mask[a.list ? a.list[blockIdx.y] : (int)blockIdx.y] <= 1) return;
   const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   switch (w) {
     case 0: gram8_wave<0, RHS>(a, lds); break;
@@ -684,7 +684,7 @@ __global__ __launch_bounds__(64 * NWD, (NTT <= 2 ? 4 : 2)) void gram_direct_kern
   constexpr int NTILE = NTT * (NTT + 1) / 2;
   constexpr int KU = 4;                                 // k-steps per round (two rounds in flight per wave)
   extern __shared__ double lds[];                       // [NWD][256]
-  const int b = blockIdx.y;
+  const int b = a.list ? a.list[blockIdx.y] : (int)blockIdx.y;
   if (a.mask && a.mask[b] <= 1) return;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);

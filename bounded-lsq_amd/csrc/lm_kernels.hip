@@ -24,6 +24,7 @@
 #include "blsq_device.h"
 #include "blsq_kernels.h"
 #include "tri_ops.h"
+#include "lm_body.h"
 
 namespace blsq {
 
@@ -63,9 +64,11 @@ __global__ __launch_bounds__(TRI_NT) void lm_gate_kernel(LmState lm, int enable)
   // sigma_min(R') >= GRAM_SMIN_PROVEN (the conditioning certificate), so  s_min >= that x min_j sqrt(h_jj)  and  s_max <= sqrt(sum_j h_jj)
   // (the exact Frobenius norm).  When that already clears the threshold below, the iteration is
   // not needed; otherwise (extreme column scaling near the bounds) the estimate runs as always.
-  if (ok && lm.path && lm.colinfo && lm.path[b] == 0) {
+  // Householder-path problems the certificate saw (finite proven K2 > gate): the same bound with 1 / sqrt(K2)
+  const bool qr_bound = lm.path && lm.path[b] != 0 && lm.k2 && lm.colinfo && lm.k2[b] > 0.0 && is_finite(lm.k2[b]);
+  if (ok && lm.path && lm.colinfo && (lm.path[b] == 0 || qr_bound)) {
     const double mn = lm.colinfo[2 * (long)b], sm = lm.colinfo[2 * (long)b + 1];
-    const double smin_lb = GRAM_SMIN_PROVEN * mn, smax_ub = sqrt(sm);
+    const double smin_lb = (qr_bound ? 1.0 / sqrt(lm.k2[b]) : GRAM_SMIN_PROVEN) * mn, smax_ub = sqrt(sm);
     if (is_finite(sm) && sm > 0.0 && smin_lb > LM_GATE_MARGIN * LM_EPS * lm.m * smax_ub) {
       if (tid == 0) {
         lm.fast[b] = 1;
@@ -143,89 +146,15 @@ hipError_t launch_lm_gate(const LmState& lm, int enable, hipStream_t s) {
   return hipGetLastError();
 }
 
-// which kernel factors the Newton system of problem b at this alpha: the stacked QR (n + 1) or the
-// Cholesky of the modified Gram (0) — LmState::hmax
-__device__ __forceinline__ int lm_qr_cols(const LmState& lm, int b, double alpha, int n) {
-  if (lm.path && lm.path[b] == 0) return 0;                       // normal-equations path: always the Gram
-  if (lm.hmax) {
-    const double hm = lm.hmax[b], L1 = lm.lam[b] + 1.0;
-    if (is_finite(hm) && hm > 0.0 && L1 >= 2.0 && lm.k2_max > L1 && alpha >= 1.01 * hm * L1 / (lm.k2_max - L1)) return 0;
-  }
-  return n + 1;
-}
-
-// restart rule of trust_region.py:128,134
-__device__ __forceinline__ double lm_restart(double lo, double hi) {
-  const double gm = sqrt(lo * hi);
-  return (0.001 * hi > gm) ? 0.001 * hi : gm;
-}
-
 // ------------------------------------------------------------------ start --
-// Gauss-Newton step (alpha = 0) on R_aug, acceptance test, bracket initialisation.
+// Gauss-Newton step (alpha = 0) on R_aug, acceptance test, bracket initialisation (lm_body.h).
 __global__ __launch_bounds__(TRI_NT) void lm_start_kernel(LmState lm, const double* Delta_in,
                                                           const double* alpha_in) {
   extern __shared__ double sh[];
   __shared__ double red[32];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x;
   if (lm.fused_gram && lm.path && lm.path[b] == 0) return;   // (lm_rounds_reg_kernel owns this problem)
-  if (!lm.fast[b]) {
-    if (tid == 0) lm.ncols_lm[b] = 0;
-    return;
-  }
-  const int n = lm.n, ld = lm.ld;
-  const double* R = lm.Raug + (long)b * ld * ld;
-  double* p = sh;
-  double* q = p + ld;
-  double* invd = q + ld;
-  double* pfbuf = invd + ld;                 // 2 x 16 x ld doubles: DMA staging of the solves
-  double* sc = lm.sc + (long)b * 16;
-  int* st = lm.st + (long)b * 4;
-  const double Delta = Delta_in[b];
-  tri_invdiag(R, n, ld, invd);
-  for (int i = tid; i < n; i += TRI_NT) p[i] = R[(long)i * ld + n];     // c_aug
-  __syncthreads();
-  // alpha_upper = ||A^T b|| / Delta
-  double gnorm;
-  if (lm.g_h) {                               // A^T b = D J^T f: known since the prep kernel
-    for (int i = tid; i < n; i += TRI_NT) q[i] = lm.g_h[(long)b * ld + i];
-    __syncthreads();
-    gnorm = sqrt(tri_dot(q, q, n, red));
-  } else {
-    tri_mtv(R, n, ld, p, q);
-    gnorm = sqrt(tri_dot(q, q, n, red));
-  }
-  tri_solve_upper_pf(R, n, ld, invd, p, pfbuf);                           // R^{-1} c
-  const double pn = sqrt(tri_dot(p, p, n, red));
-  for (int i = tid; i < n; i += TRI_NT) {
-    p[i] = -p[i];
-    lm.ph[(long)b * ld + i] = p[i];
-  }
-  __syncthreads();
-  if (pn <= Delta) {                                                      // trust_region.py:116-117
-    if (tid == 0) {
-      sc[SC_ALPHA] = 0.0; st[ST_NITER] = 0; st[ST_PHASE] = LM_IDLE; sc[SC_DELTA] = Delta;
-      lm.ncols_lm[b] = 0;
-    }
-    return;
-  }
-  // phi(0), phi'(0) -> alpha_lower (trust_region.py:121-123)
-  for (int i = tid; i < n; i += TRI_NT) q[i] = p[i];
-  __syncthreads();
-  tri_solve_upper_t_pf(R, n, ld, invd, q, pfbuf);
-  const double qq = tri_dot(q, q, n, red);
-  const double phi = pn - Delta;
-  const double dphi = -qq / pn;
-  double hi = gnorm / Delta;
-  double lo = -phi / dphi;
-  double alpha = alpha_in[b];                                             // :127-130 (full rank)
-  if (alpha < lo || alpha > hi) alpha = lm_restart(lo, hi);               // :133-134, iteration 0
-  if (tid == 0) {
-    sc[SC_ALPHA] = alpha; sc[SC_LO] = lo; sc[SC_HI] = hi; sc[SC_PHI] = phi; sc[SC_DPHI] = dphi;
-    sc[SC_DELTA] = Delta;
-    st[ST_IT] = 0; st[ST_PHASE] = LM_EVAL; st[ST_NITER] = 0;
-    lm.sa[b] = sqrt(alpha); lm.ncols_lm[b] = lm_qr_cols(lm, b, alpha, n);                   // QR launch mask
-    lm.active_list[atomicAdd(lm.active_count, 1)] = b;          // list 0 feeds evaluation 0
-  }
+  lm_start_body<TRI_NT>(lm, b, Delta_in, alpha_in, sh, red, true);
 }
 
 hipError_t launch_lm_start(const LmState& lm, const double* Delta, const double* alpha_in,
@@ -237,82 +166,15 @@ hipError_t launch_lm_start(const LmState& lm, const double* Delta, const double*
 }
 
 // ----------------------------------------------------------------- update --
-// one evaluation of phi / phi' at the current alpha + the Newton update (:132-150)
+// one evaluation of phi / phi' at the current alpha + the Newton update (:132-150; lm_body.h)
 __global__ __launch_bounds__(TRI_NT) void lm_update_kernel(LmState lm) {
   extern __shared__ double sh[];
   __shared__ double red[32];
   // launched over the compacted list of evaluation lm.round; writes the next one
   if ((int)blockIdx.x >= lm.active_count[lm.round]) return;   // (launched over an upper bound)
-  const int b = lm.active_list[(long)(lm.round & 1) * lm.B + blockIdx.x], tid = threadIdx.x;
+  const int b = lm.active_list[(long)(lm.round & 1) * lm.B + blockIdx.x];
   if (!lm.fast[b]) return;
-  int* st = lm.st + (long)b * 4;
-  const int phase = st[ST_PHASE];
-  if (phase == LM_IDLE) return;
-  const int n = lm.n, ld = lm.ld;
-  const double* R = lm.Xa + (long)b * ld * ld;            // R_alpha | c_alpha
-  double* p = sh;
-  double* q = p + ld;
-  double* invd = q + ld;
-  double* pfbuf = invd + ld;                 // 2 x 16 x ld doubles: DMA staging of the solves
-  double* sc = lm.sc + (long)b * 16;
-  const double Delta = sc[SC_DELTA];
-  tri_invdiag(R, n, ld, invd);
-  for (int i = tid; i < n; i += TRI_NT) p[i] = R[(long)i * ld + n];
-  __syncthreads();
-  tri_solve_upper_pf(R, n, ld, invd, p, pfbuf);
-  const double pn = sqrt(tri_dot(p, p, n, red));
-  for (int i = tid; i < n; i += TRI_NT) p[i] = -p[i];
-  __syncthreads();
-  double alpha = sc[SC_ALPHA], lo = sc[SC_LO], hi = sc[SC_HI];
-  double phi = sc[SC_PHI], dphi = sc[SC_DPHI];
-  int it = st[ST_IT];
-  int next_phase = LM_IDLE;
-  int n_iter = st[ST_NITER];
-  bool finished = false;
-  if (phase == LM_FINAL) {
-    // loop exhausted (:132 ran 10 times without break): p at the UPDATED alpha, rescale
-    // test on the STALE phi (:149)
-    finished = true;
-  } else {
-    for (int i = tid; i < n; i += TRI_NT) q[i] = p[i];
-    __syncthreads();
-    tri_solve_upper_t_pf(R, n, ld, invd, q, pfbuf);
-    const double qq = tri_dot(q, q, n, red);
-    phi = pn - Delta;
-    dphi = -qq / pn;
-    if (fabs(phi) < 0.01 * Delta) {                       // :138-139
-      finished = true;
-      n_iter = it + 1;
-    } else {
-      if (phi < 0.0) hi = alpha;                          // :141-142
-      const double ratio = phi / dphi;
-      const double cand = alpha - ratio;
-      lo = (cand > lo) ? cand : lo;                       // :145
-      alpha -= (phi + Delta) * ratio / Delta;             // :146
-      ++it;
-      if (it >= 10) {                                     // max_iter reached: final p at new alpha
-        n_iter = 10;
-        next_phase = LM_FINAL;
-      } else {
-        if (alpha < lo || alpha > hi) alpha = lm_restart(lo, hi);   // :133-134 of the next pass
-        next_phase = LM_EVAL;
-      }
-    }
-  }
-  if (finished) {
-    const double f = (phi > 0.0) ? Delta / pn : 1.0;      // :149-150
-    for (int i = tid; i < n; i += TRI_NT) lm.ph[(long)b * ld + i] = p[i] * f;
-    next_phase = LM_IDLE;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    sc[SC_ALPHA] = alpha; sc[SC_LO] = lo; sc[SC_HI] = hi; sc[SC_PHI] = phi; sc[SC_DPHI] = dphi;
-    st[ST_IT] = it; st[ST_PHASE] = next_phase; st[ST_NITER] = n_iter;
-    lm.sa[b] = sqrt(alpha);
-    lm.ncols_lm[b] = (next_phase != LM_IDLE) ? lm_qr_cols(lm, b, alpha, n) : 0;
-    if (next_phase != LM_IDLE)
-      lm.active_list[(long)((lm.round + 1) & 1) * lm.B + atomicAdd(lm.active_count + lm.round + 1, 1)] = b;
-  }
+  lm_update_body<TRI_NT>(lm, b, sh, red, lm.round + 1);
 }
 
 hipError_t launch_lm_update(const LmState& lm, int active, hipStream_t s) {

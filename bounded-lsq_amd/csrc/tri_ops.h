@@ -8,12 +8,15 @@ namespace blsq {
 
 static constexpr int TRI_NT = 256;
 static constexpr int TRI_NW = TRI_NT / WAVE;
+// Every routine is a template on NT, the thread count of the calling workgroup (default TRI_NT): the fused
+// Newton-round kernel of chol_kernels.hip runs them with its 512 threads.
 
 // u = R s   (one wave per row, lanes stride the columns)
+template <int NT = TRI_NT>
 __device__ __forceinline__ void tri_mv(const double* R, int n, int ld, const double* s, double* u) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   constexpr int RB = 4;                     // rows per wave pass: their loads fly together
-  for (int i0 = w; i0 < n; i0 += TRI_NW * RB) {
+  for (int i0 = w; i0 < n; i0 += (NT / WAVE) * RB) {
     double acc[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) acc[r] = 0.0;
@@ -21,21 +24,21 @@ __device__ __forceinline__ void tri_mv(const double* R, int n, int ld, const dou
       double rv[RB];
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
-        const int i = i0 + r * TRI_NW;
+        const int i = i0 + r * (NT / WAVE);
         const int ic = (i < n) ? i : n - 1;
         const int j = ic + lane + jj;
         rv[r] = R[(long)ic * ld + ((j < n) ? j : n - 1)];
       }
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
-        const int i = i0 + r * TRI_NW;
+        const int i = i0 + r * (NT / WAVE);
         const int j = i + lane + jj;
         if (i < n && j < n) acc[r] = fma(rv[r], s[j], acc[r]);
       }
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
-      const int i = i0 + r * TRI_NW;
+      const int i = i0 + r * (NT / WAVE);
       const double t = wave_sum(acc[r]);
       if (lane == 0 && i < n) u[i] = t;
     }
@@ -44,9 +47,10 @@ __device__ __forceinline__ void tri_mv(const double* R, int n, int ld, const dou
 }
 
 // u = R^T s  (thread per column j: sum_{i<=j} R[i][j] s_i; coalesced across threads)
+template <int NT = TRI_NT>
 __device__ __forceinline__ void tri_mtv(const double* R, int n, int ld, const double* s,
                                         double* u) {
-  for (int j = threadIdx.x; j < n; j += TRI_NT) {
+  for (int j = threadIdx.x; j < n; j += NT) {
     double acc = 0.0;
     // 32 rows per pass, unconditional (clamped) loads in flight together: the passes are serialised by
     // their waits, and the longest column has n rows (8 per pass: 32 round trips at n = 256)
@@ -64,14 +68,16 @@ __device__ __forceinline__ void tri_mtv(const double* R, int n, int ld, const do
 }
 
 // invd[i] = 1 / R[i][i]
+template <int NT = TRI_NT>
 __device__ __forceinline__ void tri_invdiag(const double* R, int n, int ld, double* invd) {
-  for (int i = threadIdx.x; i < n; i += TRI_NT) invd[i] = 1.0 / R[(long)i * ld + i];
+  for (int i = threadIdx.x; i < n; i += NT) invd[i] = 1.0 / R[(long)i * ld + i];
   __syncthreads();
 }
 
 // In place: x <- R^{-1} x.  Blocked back substitution, 16-wide blocks: the diagonal
 // block is solved by lanes 0..15 of wave 0 (lane i owns row i, x_s broadcast with
 // v_readlane), the part above it is updated by all threads (one row each).
+template <int NT = TRI_NT>
 __device__ __forceinline__ void tri_solve_upper(const double* R, int n, int ld,
                                                 const double* invd, double* x) {
   const int tid = threadIdx.x;
@@ -97,7 +103,7 @@ __device__ __forceinline__ void tri_solve_upper(const double* R, int n, int ld,
       if (tid < bs) x[c0 + tid] = r * iv;
     }
     __syncthreads();
-    for (int i = tid; i < c0; i += TRI_NT) {           // rows above the block
+    for (int i = tid; i < c0; i += NT) {           // rows above the block
       const double* row = R + (long)i * ld + c0;
       double rv[16], acc = 0.0;             // unconditional (clamped) loads: a guarded load would
 #pragma unroll                              // serialise into branch + load + wait per element
@@ -111,6 +117,7 @@ __device__ __forceinline__ void tri_solve_upper(const double* R, int n, int ld,
 }
 
 // In place: y <- R^{-T} y.  Blocked forward substitution.
+template <int NT = TRI_NT>
 __device__ __forceinline__ void tri_solve_upper_t(const double* R, int n, int ld,
                                                   const double* invd, double* y) {
   const int tid = threadIdx.x;
@@ -136,7 +143,7 @@ __device__ __forceinline__ void tri_solve_upper_t(const double* R, int n, int ld
       if (tid < bs) y[c0 + tid] = r * iv;
     }
     __syncthreads();
-    for (int j = c0 + 16 + tid; j < n; j += TRI_NT) {   // columns to the right of the block
+    for (int j = c0 + 16 + tid; j < n; j += NT) {   // columns to the right of the block
       double rv[16], acc = 0.0;             // 16 rows = 16 cache lines: all loads in flight together
 #pragma unroll
       for (int s = 0; s < 16; ++s) rv[s] = R[(long)(c0 + ((s < bs) ? s : bs - 1)) * ld + j];
@@ -156,29 +163,32 @@ __device__ __forceinline__ void tri_solve_upper_t(const double* R, int n, int ld
 // buf: 2 * 16 * ld doubles of LDS.  R rows must be 16-byte aligned (ld % 2 == 0).
 
 // rows 0 .. c0+15, columns c0 .. c0+15  ->  dst[row * 16 + col - c0]
+template <int NT = TRI_NT>
 __device__ __forceinline__ void tri_pf_issue_upper(const double* R, int ld, int c0, double* dst) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nrow = c0 + 16;                              // multiple of 16: whole 8-row DMA pieces
-  for (int r0 = w * 8; r0 < nrow; r0 += TRI_NW * 8) {
+  for (int r0 = w * 8; r0 < nrow; r0 += (NT / WAVE) * 8) {
     const int row = r0 + (lane >> 3);
     glds16(R + c0, (unsigned)(row * ld + 2 * (lane & 7)) * 8u, dst + r0 * 16);
   }
 }
 // rows c0 .. c0+15, columns c0 .. ld-1  ->  dst[s * (ld - c0) + col - c0]
+template <int NT = TRI_NT>
 __device__ __forceinline__ void tri_pf_issue_lower(const double* R, int ld, int c0, double* dst) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int L = ld - c0;                                 // multiple of 16
   const int half = L >> 1;                               // 16-byte pieces per row
   const int total = 16 * half;                           // multiple of 64
-  for (int i0 = w * 64; i0 < total; i0 += TRI_NW * 64) {
+  for (int i0 = w * 64; i0 < total; i0 += (NT / WAVE) * 64) {
     const int idx = i0 + lane;
     const int srow = idx / half, off = idx - srow * half;
     glds16(R + c0, (unsigned)((c0 + srow) * ld + 2 * off) * 8u, dst + i0 * 2);
   }
 }
 
+template <int NT = TRI_NT>
 __device__ __forceinline__ void tri_solve_upper_pf(const double* R, int n, int ld,
                                                    const double* invd, double* x, double* buf) {
   const int tid = threadIdx.x;
@@ -186,14 +196,14 @@ __device__ __forceinline__ void tri_solve_upper_pf(const double* R, int n, int l
   const int bsz = 16 * ld;
   int cur = 0;
   __builtin_amdgcn_s_waitcnt(0x0F70);
-  tri_pf_issue_upper(R, ld, (nblk - 1) * 16, buf);
+  tri_pf_issue_upper<NT>(R, ld, (nblk - 1) * 16, buf);
   for (int kb = nblk - 1; kb >= 0; --kb) {
     const int c0 = kb * 16;
     const int bs = (n - c0 < 16) ? n - c0 : 16;
     const double* b = buf + cur * bsz;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();                                       // every wave's pieces have landed
-    if (kb > 0) tri_pf_issue_upper(R, ld, c0 - 16, buf + (cur ^ 1) * bsz);
+    if (kb > 0) tri_pf_issue_upper<NT>(R, ld, c0 - 16, buf + (cur ^ 1) * bsz);
     if (tid < 64) {                                      // wave 0 (lanes >= 16 are idle copies)
       const int i = tid & 15;
       double D[16];
@@ -212,7 +222,7 @@ __device__ __forceinline__ void tri_solve_upper_pf(const double* R, int n, int l
       if (tid < bs) x[c0 + tid] = r * iv;
     }
     lds_barrier();
-    for (int i = tid; i < c0; i += TRI_NT) {             // rows above the block
+    for (int i = tid; i < c0; i += NT) {             // rows above the block
       const double* row = b + i * 16;
       double acc = 0.0;
 #pragma unroll
@@ -224,6 +234,7 @@ __device__ __forceinline__ void tri_solve_upper_pf(const double* R, int n, int l
   }
 }
 
+template <int NT = TRI_NT>
 __device__ __forceinline__ void tri_solve_upper_t_pf(const double* R, int n, int ld,
                                                      const double* invd, double* y, double* buf) {
   const int tid = threadIdx.x;
@@ -231,7 +242,7 @@ __device__ __forceinline__ void tri_solve_upper_t_pf(const double* R, int n, int
   const int bsz = 16 * ld;
   int cur = 0;
   __builtin_amdgcn_s_waitcnt(0x0F70);
-  tri_pf_issue_lower(R, ld, 0, buf);
+  tri_pf_issue_lower<NT>(R, ld, 0, buf);
   for (int kb = 0; kb < nblk; ++kb) {
     const int c0 = kb * 16;
     const int bs = (n - c0 < 16) ? n - c0 : 16;
@@ -239,7 +250,7 @@ __device__ __forceinline__ void tri_solve_upper_t_pf(const double* R, int n, int
     const double* b = buf + cur * bsz;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
-    if (kb + 1 < nblk) tri_pf_issue_lower(R, ld, c0 + 16, buf + (cur ^ 1) * bsz);
+    if (kb + 1 < nblk) tri_pf_issue_lower<NT>(R, ld, c0 + 16, buf + (cur ^ 1) * bsz);
     if (tid < 64) {
       const int i = tid & 15;               // row i of the lower-triangular block = column i of R's block
       double D[16];
@@ -258,7 +269,7 @@ __device__ __forceinline__ void tri_solve_upper_t_pf(const double* R, int n, int
       if (tid < bs) y[c0 + tid] = r * iv;
     }
     lds_barrier();
-    for (int j = c0 + 16 + tid; j < n; j += TRI_NT) {    // columns to the right of the block
+    for (int j = c0 + 16 + tid; j < n; j += NT) {    // columns to the right of the block
       double acc = 0.0;
 #pragma unroll
       for (int s = 0; s < 16; ++s) acc = fma(b[s * L + (j - c0)], (s < bs) ? y[c0 + s] : 0.0, acc);
@@ -269,9 +280,10 @@ __device__ __forceinline__ void tri_solve_upper_t_pf(const double* R, int n, int
   }
 }
 
+template <int NT = TRI_NT>
 __device__ __forceinline__ double tri_dot(const double* a, const double* b, int n, double* red) {
   double acc = 0.0;
-  for (int j = threadIdx.x; j < n; j += TRI_NT) acc = fma(a[j], b[j], acc);
+  for (int j = threadIdx.x; j < n; j += NT) acc = fma(a[j], b[j], acc);
   return block_sum(acc, red);
 }
 

@@ -226,6 +226,10 @@ int blsq_tsqr_combine_dev(blsq_trf_plan* plan, const double* dtri_stack /*nranks
  * reconstruction fast path (out[0]) and by the exact Householder column loop (out[1]: partial
  * last panels and panels whose scaled Gram has a small pivot) since the last reset. */
 int blsq_debug_cqr_stats(blsq_ctx* ctx, uint64_t out[2], int reset);
+/* Diagnostics: of the problems the gate handed on (out[1] of blsq_debug_gram_stats), how many the CholeskyQR2
+ * middle tier factored (second pass over J through the MFMA pipe, proven acceptance test)
+ * instead of the Householder tree, since the last reset.  Synchronises the ctx stream. */
+int blsq_debug_cqr2_stats(blsq_ctx* ctx, uint64_t* out1, int reset);
 /* Diagnostics of the factorisation front end: out[0] = problems factored by the
  * normal-equations fast path (Gram + equilibrated Cholesky, conditioning-gated), out[1] =
  * problems the gate handed to the Householder TSQR tree, since the last reset. */
