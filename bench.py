@@ -611,7 +611,22 @@ def main():
                 mixed(P)
                 P["lb"][:] = -np.inf
                 P["ub"][:] = np.inf
-            for key, mut in (("mixed_conditioning", mixed), ("mixed_conditioning_unbounded", mixed_unbounded)):
+            def all_rejected(P):
+                # every problem beyond the gate: kappa(J) = 3e3, no bounds — what a batch gets whose problems ALL
+                # fail the certificate (the CholeskyQR2 tier; `householder_only` above is the tree alone)
+                rng = np.random.default_rng(4243)
+                nn = P["J"].shape[2]
+                V, _ = np.linalg.qr(rng.standard_normal((nn, nn)))
+                K = min(64, P["J"].shape[0])
+                sv = np.logspace(0.0, -np.log10(3e3), nn)
+                for b in range(K):
+                    P["J"][b] = (P["J"][b] @ (V * sv)) @ V.T
+                for b in range(K, P["J"].shape[0]):
+                    P["J"][b] = P["J"][b % K]
+                P["lb"][:] = -np.inf
+                P["ub"][:] = np.inf
+            for key, mut in (("mixed_conditioning", mixed), ("mixed_conditioning_unbounded", mixed_unbounded),
+                             ("certificate_rejected", all_rejected)):
                 bm = Bench(name, ctx, 0, 1, batch=args.batch, mutate=mut)
                 km = max(2, min(steps_requested, 20))
                 em, km = time_steps(bm, km, 1, ctx.sync)
@@ -623,7 +638,9 @@ def main():
                                             "householder_tree": gsm[1] // km - cq2 // km},
                     "parity": bm.parity(min(16, B)) if args.check > 0 else None,
                     "kernels_ms_per_step": {k: round(v[0] / km, 4) for k, v in ctx.timing_read().items() if v[0] > 0},
-                    "note": ("kappa(J) log-uniform over [1, 1e4]; each problem on the path its certificate allows. "
+                    "note": ("kappa(J) = 3e3 for every problem, no bounds: all of them beyond the gate"
+                             if key == "certificate_rejected" else
+                             "kappa(J) log-uniform over [1, 1e4]; each problem on the path its certificate allows. "
                              + ("Bounds as in the headline workload: the Coleman-Li block E^2 of the augmented "
                                 "system [J D; E] (trf.py:264-270) keeps the SOLVED system well conditioned."
                                 if key == "mixed_conditioning" else
@@ -704,7 +721,8 @@ def main():
                 digest[k] = [round(v["value"], 1), round(v["ms_per_step"], 4), round(v["roofline"]["frac"], 3)]
             else:
                 digest[k] = v
-        for k in ("householder_only", "mixed_conditioning", "mixed_conditioning_unbounded", "h2d_inclusive"):
+        for k in ("householder_only", "certificate_rejected", "mixed_conditioning", "mixed_conditioning_unbounded",
+                  "h2d_inclusive"):
             if k in extras:
                 digest[k] = [round(extras[k]["value"], 1), round(extras[k]["ms_per_step"], 4), None]
         if "c5_tsqr" in extras and isinstance(extras["c5_tsqr"], dict) and "value" in extras["c5_tsqr"]:

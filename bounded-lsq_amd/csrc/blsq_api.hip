@@ -454,6 +454,9 @@ struct QrTree {
     //    below CQR2_K2_MAX = 1e12 (kappa(J D) <= 1e6: error <= 2e-12); beyond, the Householder tree.
     GramCholArgs cy = c;
     cy.batch_list = nullptr; cy.mask = fb_mask(); cy.k2_max = CQR2_K2_MAX;
+    // (the bound on the PLAIN equilibrated Gram also bounds the augmented system's — its spectrum lies inside,
+    //  chol_kernels.hip — so it replaces the missing / larger bound of a rejected problem: the rank gate uses it)
+    cy.k2_out = gram_k2.as<double>();
     ctx->begin(K_GRAM_GATE);
     e = launch_gram_gate(cy, B, ctx->stream);
     ctx->end();
@@ -1032,7 +1035,7 @@ GramCholArgs trf_chol_args(blsq_trf_plan* p, const int* mask) {
 
 // the second half of the certificate + the rank gate of the trust-region solver (counters:
 // fb_count()[0] problems that leave the path, [1] problems for the SVD)
-int trf_gate_tail(blsq_trf_plan* p, const GramCholArgs& c) {
+int trf_gate_tail(blsq_trf_plan* p, const GramCholArgs& c, bool full = true) {
   blsq_ctx* ctx = p->ctx;
   QrTree& t = p->tree;
   ctx->begin(K_GRAM_GATE);
@@ -1045,8 +1048,13 @@ int trf_gate_tail(blsq_trf_plan* p, const GramCholArgs& c) {
   p->lm.path = t.path_rw();
   p->lm.colinfo = p->aug_colinfo.as<double>();
   p->lm.jac_count = t.fb_count() + 1;
+  // (normal-equations-path problems only: a problem the certificate has just rejected gets its triangle first and
+  //  is gated by trf_finish afterwards — estimating the rank of its abandoned factor here cost the latency of one
+  //  problem's inverse iteration for nothing; such a problem counts as "needs the SVD" until then, which the verdict
+  //  logic ignores whenever a problem left the path)
   ctx->begin(K_LM_GATE);
-  e = launch_lm_gate(p->lm, p->lm_gate_mask, ctx->stream);
+  //  (`full`: every problem is refreshed by this call — a masked call keeps the others' state as it is)
+  e = launch_lm_gate(p->lm, full ? (p->lm_gate_mask & 2) : p->lm_gate_mask, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_lm_gate");
   return 0;
@@ -1079,7 +1087,7 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, 
   if (skip_tail) {
     p->lm.path = t.path_rw();
     p->lm.colinfo = p->aug_colinfo.as<double>();
-  } else if ((rc = trf_gate_tail(p, c))) return rc;
+  } else if ((rc = trf_gate_tail(p, c, mask == nullptr))) return rc;
   if (defer) {                              // the counters travel; the verdict is read by trf_resolve
     HIPCHK(ctx, hipMemcpyAsync(p->pend_pin, t.fb_count(), 3 * sizeof(int), hipMemcpyDeviceToHost,
                                ctx->stream));
