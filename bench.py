@@ -658,7 +658,65 @@ def main():
             extras["h2d_inclusive"] = {
                 "value": B * kh / eh, "unit": "step-solves/s", "ms_per_step": 1e3 * eh / kh, "steps": kh,
                 "host_to_device_GBps": 8.0 * B * m * (n + 1) * kh / eh / 1e9,
-                "note": "host-pointer API (pageable numpy buffers); the link bounds this mode, never `value`"}
+                "note": "host-pointer API (pageable numpy buffers; copies in sub-batches overlapped with the Grams); "
+                        "the link bounds this mode, never `value`"}
+            try:
+                # the same with J / f in page-locked memory (Context.pinned_empty -> blsq_host_alloc): straight DMA
+                Jp = ctx.pinned_empty(bench.P["J"].shape)
+                fp = ctx.pinned_empty(bench.P["f"].shape)
+                Jp[...] = bench.P["J"]
+                fp[...] = bench.P["f"]
+                keep = bench.P["J"], bench.P["f"]
+                bench.P["J"], bench.P["f"] = Jp, fp
+                bench.step_host()
+                t0 = time.perf_counter()
+                for _ in range(kh):
+                    bench.step_host()
+                ep = time.perf_counter() - t0
+                bench.P["J"], bench.P["f"] = keep
+                ctx.pinned_free(Jp)
+                ctx.pinned_free(fp)
+                extras["h2d_inclusive"]["pinned"] = {
+                    "value": B * kh / ep, "ms_per_step": 1e3 * ep / kh,
+                    "host_to_device_GBps": 8.0 * B * m * (n + 1) * kh / ep / 1e9}
+            except Exception as exc:                           # noqa: BLE001
+                extras["h2d_inclusive"]["pinned"] = {"error": str(exc)[:200]}
+            try:
+                # per-iteration cost of the drop-in front end on ONE 4096 x 256 problem with host callbacks
+                # (least_squares.py:351-371: fun and jac return numpy arrays every iteration)
+                import bounded_lsq
+                P1 = bench.P
+                J1, x1 = np.ascontiguousarray(P1["J"][0]), P1["x"][0].copy()
+                y1 = J1 @ x1 + 0.1 * P1["f"][0]
+
+                def fun1(xx):
+                    return np.tanh(J1 @ xx - y1)
+
+                def jac1(xx):
+                    return (1.0 - np.tanh(J1 @ xx - y1) ** 2)[:, None] * J1
+                kw1 = dict(jac=jac1, bounds=(P1["lb"][0] - 1.0, P1["ub"][0] + 1.0), method="trf", max_nfev=12)
+                bounded_lsq.least_squares(fun1, x1 + 0.01, **kw1)          # (warm: code objects, allocator)
+                t0 = time.perf_counter()
+                sol1 = bounded_lsq.TrfStepSolver(1, m, n)                  # what every solve pays once: its plan
+                sol1.close()
+                eplan = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                r1 = bounded_lsq.least_squares(fun1, x1 + 0.01, **kw1)
+                e1 = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                for _ in range(r1.njev):
+                    jac1(r1.x)
+                for _ in range(r1.nfev):
+                    fun1(r1.x)
+                ecb = time.perf_counter() - t0
+                extras["least_squares_single_4096x256"] = {
+                    "nfev": int(r1.nfev), "njev": int(r1.njev), "status": int(r1.status), "total_ms": 1e3 * e1,
+                    "callbacks_ms": 1e3 * ecb, "plan_create_ms": 1e3 * eplan,
+                    "ms_per_iteration_excluding_callbacks_and_plan": 1e3 * (e1 - ecb - eplan) / max(1, int(r1.njev)),
+                    "note": "bounded_lsq.least_squares (sequential host driver, numpy callbacks): wall time per outer "
+                            "iteration = H2D of the 8 MiB Jacobian + factor + inner steps + result fetches"}
+            except Exception as exc:                           # noqa: BLE001
+                extras["least_squares_single_4096x256"] = {"error": str(exc)[:200]}
         if not args.no_side:
             side = {}
             for sn, ks in (("c2-single", 100), ("c3", 40), ("c4", 40), ("c5", 100)):

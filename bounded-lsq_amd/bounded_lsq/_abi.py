@@ -31,6 +31,8 @@ SIGNATURES = {
     "blsq_dev_malloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
     "blsq_dev_free": (C.c_int, [vp, vp]),
     "blsq_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "blsq_host_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+    "blsq_host_free": (C.c_int, [vp, vp]),
     "blsq_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "blsq_timing_enable": (C.c_int, [vp, C.c_int]),
     "blsq_timing_reset": (C.c_int, [vp]),
@@ -187,6 +189,25 @@ class Context:
 
     def free(self, p):
         self.check(self.lib.blsq_dev_free(self.h, p), "blsq_dev_free")
+
+    def pinned_empty(self, shape, dtype=np.float64):
+        """A numpy array in page-locked host memory (blsq_host_alloc): hand it to factor() / let `jac` fill it and
+        the Jacobian crosses PCIe by DMA at link speed.  Keep the context alive as long as the array; release with
+        ``ctx.pinned_free(arr)`` (or leave it to the process)."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        p = vp()
+        self.check(self.lib.blsq_host_alloc(self.h, nbytes, C.byref(p)), "blsq_host_alloc")
+        buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.__array_interface__["data"][0]] = p
+        return arr
+
+    def pinned_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.__array_interface__["data"][0], None)
+        if p is not None:
+            self.check(self.lib.blsq_host_free(self.h, p), "blsq_host_free")
 
     def to_device(self, arr):
         arr = np.ascontiguousarray(arr)

@@ -42,6 +42,8 @@ inline bool merge_fits(int n) { return 2 * ((n + 15) / 16) <= QR_MAX_TILES; }
 struct blsq_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;              // host-pointer API: H2D of the next problems while the Gram of the last runs
+  std::vector<hipEvent_t> copy_ev;
   std::string err;
   bool timing = false;
   double t_ms[K_NSLOT] = {0};
@@ -359,22 +361,27 @@ struct QrTree {
     return 0;
   }
   // Gram front end ONLY: G = [J f]^T [J f] into gram_keep (+ the cross-rank sum); nothing is factored.
+  // (k0, nb): problems k0 .. k0 + nb - 1 only (the host-pointer API feeds the Grams in sub-batches behind
+  // the copies; the result does not depend on the split — a problem's chunks and their order are functions of m)
   int run_gram_only(blsq_ctx* ctx, const double* dJ, const double* df, int ldJ, const int* mask,
-                    bool collective) {
+                    bool collective, int k0 = 0, int nb = -1) {
+    if (nb < 0) nb = B;
+    const size_t tri = (size_t)NPAD * NPAD;
     GramArgs g{};
-    g.J = dJ; g.strideJ = (long)m * ldJ; g.ldJ = ldJ; g.F = df; g.strideF = m;
-    g.m = m; g.n = n; g.NPAD = NPAD; g.mask = mask;
-    double* Gk = gram_keep.as<double>();
-    g.G = gram_nchunk > 1 ? gram_part.as<double>() : Gk;
+    g.J = dJ + (size_t)k0 * m * ldJ; g.strideJ = (long)m * ldJ; g.ldJ = ldJ; g.F = df + (size_t)k0 * m; g.strideF = m;
+    g.m = m; g.n = n; g.NPAD = NPAD; g.mask = mask ? mask + k0 : nullptr;
+    double* Gk = gram_keep.as<double>() + (size_t)k0 * tri;
+    double* Gp = gram_nchunk > 1 ? gram_part.as<double>() + (size_t)k0 * gram_nchunk * tri : nullptr;
+    g.G = gram_nchunk > 1 ? Gp : Gk;
     ctx->begin(K_GRAM);
     bool fused = false;
-    hipError_t e = launch_gram(g, gram_nchunk, B, ctx->stream, Gk, &fused);
+    hipError_t e = launch_gram(g, gram_nchunk, nb, ctx->stream, Gk, &fused);
     if (e == hipSuccess && gram_nchunk > 1 && !fused)
-      e = launch_gram_reduce(gram_part.as<double>(), gram_nchunk, NPAD, Gk, mask, B, ctx->stream);
+      e = launch_gram_reduce(Gp, gram_nchunk, NPAD, Gk, g.mask, nb, ctx->stream);
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_gram");
     if (collective && ctx->comm && ctx->comm_ranks > 1)
-      RCCLCHK(ctx, g_rccl.AllReduce(Gk, Gk, (size_t)B * NPAD * NPAD, ncclDouble, ncclSum, ctx->comm,
+      RCCLCHK(ctx, g_rccl.AllReduce(Gk, Gk, (size_t)nb * NPAD * NPAD, ncclDouble, ncclSum, ctx->comm,
                                     ctx->stream));
     return 0;
   }
@@ -671,6 +678,8 @@ extern "C" int blsq_ctx_create(int device_id, blsq_ctx** out) {
   c->device = device_id;
   e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e != hipSuccess) { delete c; return (int)e; }
+  e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) { hipStreamDestroy(c->stream); delete c; return (int)e; }
   e = hipHostMalloc((void**)&c->pinned, 32 * sizeof(int), hipHostMallocDefault);
   if (e != hipSuccess) { hipStreamDestroy(c->stream); delete c; return (int)e; }
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->lm_ev[i], hipEventDisableTiming);
@@ -690,6 +699,8 @@ extern "C" int blsq_ctx_destroy(blsq_ctx* ctx) {
   ctx->comm = nullptr;
   for (auto e : ctx->pool) hipEventDestroy(e);
   for (auto e : ctx->lm_ev) if (e) hipEventDestroy(e);
+  for (auto e : ctx->copy_ev) hipEventDestroy(e);
+  if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
   hipStreamDestroy(ctx->stream);
   if (ctx->pinned) hipHostFree(ctx->pinned);
   if (ctx->cq_accept_dev) hipFree(ctx->cq_accept_dev);
@@ -799,6 +810,20 @@ extern "C" int blsq_dev_free(blsq_ctx* ctx, void* dptr) {
   if (!ctx) return -1;
   { int rc_ = ctx_resolve_pending(ctx); if (rc_) return rc_; }   // (it may be the J of a pending verdict)
   HIPCHK(ctx, hipFree(dptr));
+  return 0;
+}
+extern "C" int blsq_host_alloc(blsq_ctx* ctx, size_t bytes, void** hptr) {
+  if (!ctx) return -1;
+  if (!hptr) return ctx->bad(3, "hptr is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipHostMalloc(hptr, bytes ? bytes : 8, hipHostMallocDefault));
+  return 0;
+}
+extern "C" int blsq_host_free(blsq_ctx* ctx, void* hptr) {
+  if (!ctx) return -1;
+  { int rc_ = ctx_resolve_pending(ctx); if (rc_) return rc_; }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipHostFree(hptr));
   return 0;
 }
 extern "C" int blsq_memcpy_h2d(blsq_ctx* ctx, void* dst, const void* src, size_t bytes) {
@@ -1140,7 +1165,7 @@ int trf_fallback_stage(blsq_trf_plan* p, const double* dJ, const double* df, int
 
 // the whole factor call from device-resident [J f] (mask: outer driver, fresh Jacobians only)
 int trf_factor_core(blsq_trf_plan* p, const double* dJ, const double* df, int ldJ, int scale_mode,
-                    const int* mask, bool may_defer = false) {
+                    const int* mask, bool may_defer = false, bool gram_done = false) {
   blsq_ctx* ctx = p->ctx;
   int rc;
   if (p->pending) {
@@ -1159,7 +1184,7 @@ int trf_factor_core(blsq_trf_plan* p, const double* dJ, const double* df, int ld
     if ((rc = p->tree.run_levels(ctx, dJ, df, ldJ, mask))) return rc;
     return trf_after_triangle(p, p->tree.Rfinal(), scale_mode);
   }
-  if ((rc = p->tree.run_gram_only(ctx, dJ, df, ldJ, mask, false))) return rc;
+  if (!gram_done && (rc = p->tree.run_gram_only(ctx, dJ, df, ldJ, mask, false))) return rc;
   int nfb = 0;
   // (never in the n-band that always takes the SVD, nor right after a wrong guess)
   const bool defer = may_defer && p->optimistic && p->guess_ok && p->lm_enable && !mask && p->pend_pin &&
@@ -1591,11 +1616,43 @@ extern "C" int blsq_trf_factor(blsq_trf_plan* p, const double* J, const double* 
     e = p->in_f.p ? hipSuccess : p->in_f.alloc(fb);
     if (e != hipSuccess) return ctx->fail(e, "hipMalloc(f staging)");
   }
-  HIPCHK(ctx, hipMemcpyAsync(p->in_J.p, J, jb, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(p->in_f.p, f, fb, hipMemcpyHostToDevice, ctx->stream));
   int rc = trf_put_bounds(p, x, lb, ub, scale_io, hipMemcpyHostToDevice);
   if (rc) return rc;
-  if ((rc = trf_factor_core(p, p->in_J.as<double>(), p->in_f.as<double>(), p->n, scale_mode, nullptr)))
+  // [J f] crosses PCIe in sub-batches of problems on a copy stream; the Gram of sub-batch k runs while sub-batch
+  // k + 1 is in flight (pinned caller buffers — blsq_host_alloc — are DMA'd straight; pageable ones are staged by the
+  // runtime, the host thread then runs one copy ahead of the GPU).  BLSQ_H2D_PIPE = 0: one copy, then everything.
+  bool piped = false;
+  {
+    const char* pe = getenv("BLSQ_H2D_PIPE");
+    const size_t per = sizeof(double) * (size_t)p->m * (p->n + 1);
+    const int sub = (int)std::max<size_t>(1, std::min<size_t>((size_t)p->B, ((size_t)96 << 20) / std::max<size_t>(per, 1)));
+    if (p->tree.gram && p->B >= 2 * sub && !(pe && pe[0] == '0')) {
+      piped = true;
+      const int nsub = (p->B + sub - 1) / sub;
+      while ((int)ctx->copy_ev.size() < nsub) {
+        hipEvent_t ev = nullptr;
+        HIPCHK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ctx->copy_ev.push_back(ev);
+      }
+      for (int k = 0, k0 = 0; k0 < p->B; ++k, k0 += sub) {
+        const int nb = std::min(sub, p->B - k0);
+        const size_t jo = (size_t)k0 * p->m * p->n, fo = (size_t)k0 * p->m;
+        HIPCHK(ctx, hipMemcpyAsync(p->in_J.as<double>() + jo, J + jo, sizeof(double) * (size_t)nb * p->m * p->n,
+                                   hipMemcpyHostToDevice, ctx->copy_stream));
+        HIPCHK(ctx, hipMemcpyAsync(p->in_f.as<double>() + fo, f + fo, sizeof(double) * (size_t)nb * p->m,
+                                   hipMemcpyHostToDevice, ctx->copy_stream));
+        HIPCHK(ctx, hipEventRecord(ctx->copy_ev[k], ctx->copy_stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->copy_ev[k], 0));
+        if ((rc = p->tree.run_gram_only(ctx, p->in_J.as<double>(), p->in_f.as<double>(), p->n, nullptr, false, k0, nb)))
+          return rc;
+      }
+    }
+  }
+  if (!piped) {
+    HIPCHK(ctx, hipMemcpyAsync(p->in_J.p, J, jb, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(p->in_f.p, f, fb, hipMemcpyHostToDevice, ctx->stream));
+  }
+  if ((rc = trf_factor_core(p, p->in_J.as<double>(), p->in_f.as<double>(), p->n, scale_mode, nullptr, false, piped)))
     return rc;
   return blsq_trf_fetch_factor(p, g, g_norm, theta,
                                scale_mode != BLSQ_SCALE_GIVEN ? scale_io : nullptr, nullptr);

@@ -56,6 +56,12 @@ int blsq_sync(blsq_ctx* ctx);
 int blsq_dev_malloc(blsq_ctx* ctx, size_t bytes, void** dptr);
 int blsq_dev_free(blsq_ctx* ctx, void* dptr);
 int blsq_memcpy_h2d(blsq_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* Page-locked host memory for the buffers handed to the host-pointer calls (blsq_trf_factor, blsq_dogbox_factor):
+ * a `jac` callback (least_squares.py:367-371) that writes J into such a buffer has it DMA'd to the GPU at link
+ * speed, in sub-batches of problems overlapped with the Gram of the previous sub-batch; pageable buffers work too
+ * (the runtime stages them). */
+int blsq_host_alloc(blsq_ctx* ctx, size_t bytes, void** hptr);
+int blsq_host_free(blsq_ctx* ctx, void* hptr);
 int blsq_memcpy_d2h(blsq_ctx* ctx, void* dst, const void* src, size_t bytes);
 
 /* per-kernel device timing (HIP events on the ctx stream, for bench.py) */
