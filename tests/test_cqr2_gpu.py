@@ -159,3 +159,94 @@ def test_device_api_with_a_rejected_problem_in_a_large_batch():
     for v in list(d.values()) + [dD, dA]:
         ctx.free(v)
     ctx.close()
+
+
+def _mixed_unbounded(seed, B, m, n, kappas):
+    from bounded_lsq import _synth
+    rng = np.random.default_rng(seed)
+    P = _synth.trf_batch(seed, B, m, n, unbounded=True)
+    V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    for b, kap in enumerate(kappas):
+        if kap > 1:
+            P["J"][b] = (P["J"][b] @ (V * np.logspace(0.0, -np.log10(kap), n))) @ V.T
+    return P
+
+
+def test_newton_systems_of_rejected_problems_from_the_gram(monkeypatch):
+    """A problem off the normal-equations path still has its Newton systems H + alpha I factored by Cholesky of
+    the modified Gram wherever alpha makes them PROVABLY well conditioned ((Lambda + 1)(h_max + alpha) / alpha
+    below the gate, LmState::hmax) — the stacked QR of [R_aug; sqrt(alpha) I] only below that alpha.  Same
+    iteration counts, alpha and step (to far below the bar) as with the QR for every round
+    (BLSQ_LM_CHOL_QRPATH = 0), and both match the oracle."""
+    from oracle import blsq_oracle as orc
+    B, m, n = 6, 2048, 144
+    P = _mixed_unbounded(3, B, m, n, [1, 800, 3e3, 1e4, 4e4, 1])
+    Delta = np.array([0.5, 0.5, 10.0, 0.2, 3.0, 0.05])
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("BLSQ_LM_CHOL_QRPATH", flag)
+        outs[flag] = run_trf(P, Delta)
+    (s1, S1), (s0, S0) = outs["1"], outs["0"]
+    assert s1 == s0 and s1[1] >= 3
+    assert np.array_equal(S1.n_iter, S0.n_iter) and max(S1.n_iter) >= 2
+    for b in range(B):
+        _, So = orc.trf_step_solve(P["J"][b], P["f"][b], P["x"][b], P["lb"][b], P["ub"][b], P["scale"][b],
+                                   Delta[b], 0.0)
+        assert rel(S1.step[b], So.step) < RTOL and rel(S0.step[b], So.step) < RTOL
+        assert int(S1.n_iter[b]) == So.n_iter
+        assert rel(S1.step[b], S0.step[b]) < 2e-11
+        assert abs(S1.alpha[b] - S0.alpha[b]) <= 1e-9 * abs(S0.alpha[b])
+
+
+def test_unbounded_problems_skip_the_stacked_qr_of_the_augmentation(monkeypatch):
+    """E = 0 (no finite bound in any descent direction): [R D | c] IS the triangle of [R D | c; E | 0]
+    (trf.py:264-270) — written by a copy instead of a QR; a half-bounded problem in the same batch still
+    takes the QR.  Both against the oracle, front end off so that every problem has a triangle."""
+    from bounded_lsq import _synth
+    from oracle import blsq_oracle as orc
+    monkeypatch.setenv("BLSQ_GRAM", "0")
+    B, m, n = 4, 900, 100
+    P = _synth.trf_batch(12, B, m, n)
+    for b in (0, 2):
+        P["lb"][b] = -np.inf; P["ub"][b] = np.inf
+    P["ub"][3][::2] = np.inf
+    P["scale"] = np.tile(np.linspace(0.5, 2.0, n), (B, 1))
+    Delta = np.array([10.0, 0.5, 0.3, 2.0])
+    _, S = run_trf(P, Delta)
+    for b in range(B):
+        _, So = orc.trf_step_solve(P["J"][b], P["f"][b], P["x"][b], P["lb"][b], P["ub"][b], P["scale"][b],
+                                   Delta[b], 0.0)
+        assert rel(S.step[b], So.step) < RTOL, (b, rel(S.step[b], So.step))
+        np.testing.assert_array_equal(S.hits[b], So.hits)
+        assert int(S.n_iter[b]) == So.n_iter
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_pointer_api_sub_batches_and_pinned_buffers(pinned, monkeypatch):
+    """blsq_trf_factor copies [J f] in sub-batches of problems on a copy stream, the Gram of one sub-batch under
+    the copy of the next (BLSQ_H2D_PIPE = 0: one copy first); from pageable numpy arrays or from page-locked
+    buffers of blsq_host_alloc.  Every variant gives the same bits."""
+    import bounded_lsq as bl
+    from bounded_lsq import _synth, _abi
+    B, m, n = 40, 4096, 200                                  # 6.6 MB per problem: 14 per sub-batch
+    P = _synth.trf_batch(55, B, m, n)
+    Delta = np.where(np.arange(B) % 2 == 0, 10.0, 0.5)
+    outs = []
+    for pipe in ("1", "0"):
+        monkeypatch.setenv("BLSQ_H2D_PIPE", pipe)
+        ctx = _abi.Context(0)
+        sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
+        J, f = P["J"], P["f"]
+        if pinned:
+            J = ctx.pinned_empty(P["J"].shape); f = ctx.pinned_empty(P["f"].shape)
+            J[...] = P["J"]; f[...] = P["f"]
+        F = sol.factor(J, f, P["x"], P["lb"], P["ub"], P["scale"])
+        S = sol.step(Delta, np.zeros(B))
+        outs.append((F.g.copy(), S.step.copy(), S.hits.copy()))
+        sol.close()
+        if pinned:
+            ctx.pinned_free(J); ctx.pinned_free(f)
+        ctx.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert np.allclose(outs[0][0], np.einsum("bmn,bm->bn", P["J"], P["f"]), rtol=1e-12, atol=1e-9)
