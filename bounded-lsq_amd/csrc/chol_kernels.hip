@@ -1536,7 +1536,9 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_cond_kernel(GramCholArgs a) {
     if (a.k2_out) a.k2_out[b] = k2;
     if (a.lam_out && lam >= 1.0) a.lam_out[b] = lam;
     if (!(k2 <= kmax)) {                                 // (NaN fails)
-      if (a.cert_flag && is_finite(k2) && lam >= 1.0) {
+      // (a bound 64x above the gate is beyond what its overestimate — 3.5 ... 13 measured, 30 at the worst — can
+      //  explain: such a problem is rejected here, without the third stage's factorisation)
+      if (a.cert_flag && is_finite(k2) && lam >= 1.0 && k2 <= 64.0 * kmax) {
         // The norm bounds overestimate kappa_2 by 3.5 ... 13 where they decide: leave the verdict to the third
         // stage, a Cholesky factorisation of C - tau I with tau = Lambda / k2_max (launch_gram_cert_shift) —
         // it succeeds iff lambda_min(C) > tau, which proves kappa_2(C) <= Lambda / tau = k2_max.

@@ -264,11 +264,13 @@ __global__ __launch_bounds__(256) void cqr2_accept_kernel(Cqr2Args a, const int*
 }
 
 // ---- combine: R~ | c~ = R2 [R c; 0 1] ------------------------------------------------------------------
-// grid = (tile rows, listed problems), one wave per output tile (i, j): sum_{k = i..j} R2(i, k) R1'(k, j) by MFMA,
-// R1' = [R c; 0 1] read from the scratch the first Cholesky wrote, the result into the problem's triangle slot
-// (out of place: no ordering between the tiles).
-__global__ __launch_bounds__(GR_NT) void cqr2_combine_kernel(Cqr2Args a, const int* tree_mask, const double* R2,
-                                                            double* Rout) {
+// grid = (tile groups, listed problems), ONE WAVE PER OUTPUT TILE (i, j) of the full NT x NT image (tiles left of
+// the diagonal: zeros): sum_{k = i..j} R2(i, k) R1'(k, j) by MFMA, R1' = [R c; 0 1] read from the scratch the
+// first Cholesky wrote, the result into the problem's triangle slot (out of place: no ordering between tiles;
+// the kernel is all latency, so the tiles are spread over as many waves as there are).
+constexpr int CQ_CW = 4;                                // waves (tiles) per workgroup
+__global__ __launch_bounds__(64 * CQ_CW) void cqr2_combine_kernel(Cqr2Args a, const int* tree_mask, const double* R2,
+                                                                 double* Rout) {
   const int b = a.list[blockIdx.y];
   if (tree_mask[b] != 0) return;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -276,34 +278,33 @@ __global__ __launch_bounds__(GR_NT) void cqr2_combine_kernel(Cqr2Args a, const i
   const int lr = lane >> 4, lc = lane & 15;
   const int n = a.n, N = n + 1, NPAD = a.NPAD;
   const int NT = (N + 15) / 16;
-  const int ti = blockIdx.x;
-  if (ti >= NT) return;
+  const int q = (int)blockIdx.x * CQ_CW + w;            // tile index, row-major over the full image
+  if (q >= NT * NT) return;
+  const int ti = q / NT, tj = q - ti * NT;
   const double* S = R2 + (long)b * NPAD * NPAD;         // R2 | c2 (rows < n)
   const double* T = a.R1 + (long)b * NPAD * NPAD;       // R | c (rows < n)
   double* O = Rout + (long)b * NPAD * NPAD;
-  for (int tj = w; tj < NT; tj += GR_NW) {              // (tiles left of the diagonal: zeros — the slot is a full image)
-    v4d out = v4d{0.0, 0.0, 0.0, 0.0};
-    for (int k = ti; k <= tj; ++k) {
-      double av[4], bv[4];
+  v4d out = v4d{0.0, 0.0, 0.0, 0.0};
+  for (int k = ti; k <= tj; ++k) {
+    double av[4], bv[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int kk = 16 * k + 4 * s + lr;             // inner index
-        const int ar = 16 * ti + lc;                    // A[m = lc][kk]: R2[row ar][col kk]
-        av[s] = (ar < n && kk < N) ? S[(long)ar * NPAD + kk] : 0.0;
-        const int bc = 16 * tj + lc;                    // B[kk][nn = lc]: R1'[row kk][col bc]
-        double t = 0.0;
-        if (kk < n && bc < N) t = T[(long)kk * NPAD + bc];
-        else if (kk == n && bc == n) t = 1.0;
-        bv[s] = t;
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) out = gmfma(av[s], bv[s], out);
+    for (int s = 0; s < 4; ++s) {
+      const int kk = 16 * k + 4 * s + lr;               // inner index
+      const int ar = 16 * ti + lc;                      // A[m = lc][kk]: R2[row ar][col kk]
+      av[s] = (ar < n && kk < N) ? S[(long)ar * NPAD + kk] : 0.0;
+      const int bc = 16 * tj + lc;                      // B[kk][nn = lc]: R1'[row kk][col bc]
+      double t = 0.0;
+      if (kk < n && bc < N) t = T[(long)kk * NPAD + bc];
+      else if (kk == n && bc == n) t = 1.0;
+      bv[s] = t;
     }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int row = 16 * ti + lr + 4 * g, col = 16 * tj + lc;
-      O[(long)row * NPAD + col] = (row < n && col < N && col >= row) ? out[g] : 0.0;
-    }
+    for (int s = 0; s < 4; ++s) out = gmfma(av[s], bv[s], out);
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int row = 16 * ti + lr + 4 * g, col = 16 * tj + lc;
+    O[(long)row * NPAD + col] = (row < n && col < N && col >= row) ? out[g] : 0.0;
   }
 }
 
@@ -343,7 +344,8 @@ hipError_t launch_cqr2_combine(const Cqr2Args& a, int count, const int* run, con
   if (count <= 0) return hipSuccess;
   hipLaunchKernelGGL(cqr2_accept_kernel, dim3(count), dim3(256), 0, s, a, run, pivot2, G2, tree_mask, accepted);
   const int NT = (a.n + 1 + 15) / 16;
-  hipLaunchKernelGGL(cqr2_combine_kernel, dim3(NT, count), dim3(GR_NT), 0, s, a, tree_mask, R2, Rout);
+  hipLaunchKernelGGL(cqr2_combine_kernel, dim3((NT * NT + CQ_CW - 1) / CQ_CW, count), dim3(64 * CQ_CW), 0, s, a,
+                     tree_mask, R2, Rout);
   return hipGetLastError();
 }
 
