@@ -658,8 +658,9 @@ def main():
             extras["h2d_inclusive"] = {
                 "value": B * kh / eh, "unit": "step-solves/s", "ms_per_step": 1e3 * eh / kh, "steps": kh,
                 "host_to_device_GBps": 8.0 * B * m * (n + 1) * kh / eh / 1e9,
-                "note": "host-pointer API (pageable numpy buffers; copies in sub-batches overlapped with the Grams); "
-                        "the link bounds this mode, never `value`"}
+                "note": "host-pointer API, pageable numpy buffers (one copy, the runtime pins on the fly); `pinned`: the "
+                        "same from page-locked buffers (blsq_host_alloc), copied in sub-batches under the Grams of the "
+                        "previous ones; the PCIe link bounds both, never `value`"}
             try:
                 # the same with J / f in page-locked memory (Context.pinned_empty -> blsq_host_alloc): straight DMA
                 Jp = ctx.pinned_empty(bench.P["J"].shape)

@@ -1619,14 +1619,23 @@ extern "C" int blsq_trf_factor(blsq_trf_plan* p, const double* J, const double* 
   int rc = trf_put_bounds(p, x, lb, ub, scale_io, hipMemcpyHostToDevice);
   if (rc) return rc;
   // [J f] crosses PCIe in sub-batches of problems on a copy stream; the Gram of sub-batch k runs while sub-batch
-  // k + 1 is in flight (pinned caller buffers — blsq_host_alloc — are DMA'd straight; pageable ones are staged by the
-  // runtime, the host thread then runs one copy ahead of the GPU).  BLSQ_H2D_PIPE = 0: one copy, then everything.
+  // k + 1 is in flight — for caller buffers in page-locked memory (blsq_host_alloc), which are DMA'd straight.
+  // BLSQ_H2D_PIPE = 0 / 1: never / always (pageable memory too).
   bool piped = false;
   {
     const char* pe = getenv("BLSQ_H2D_PIPE");
     const size_t per = sizeof(double) * (size_t)p->m * (p->n + 1);
     const int sub = (int)std::max<size_t>(1, std::min<size_t>((size_t)p->B, ((size_t)96 << 20) / std::max<size_t>(per, 1)));
-    if (p->tree.gram && p->B >= 2 * sub && !(pe && pe[0] == '0')) {
+    // (page-locked source only — BLSQ_H2D_PIPE = 1 forces it for pageable memory too: there the runtime's own
+    //  pin-on-the-fly path for ONE large copy reached 52-53 GB/s, sub-batches of it as little as 27)
+    bool pinned_src = false;
+    {
+      hipPointerAttribute_t at{};
+      if (hipPointerGetAttributes(&at, J) == hipSuccess) pinned_src = (at.type == hipMemoryTypeHost);
+      else (void)hipGetLastError();                       // (plain malloc memory: "invalid value", not an error here)
+    }
+    const bool want = pe ? pe[0] == '1' : pinned_src;
+    if (p->tree.gram && p->B >= 2 * sub && want) {
       piped = true;
       const int nsub = (p->B + sub - 1) / sub;
       while ((int)ctx->copy_ev.size() < nsub) {

@@ -224,8 +224,8 @@ def test_unbounded_problems_skip_the_stacked_qr_of_the_augmentation(monkeypatch)
 @pytest.mark.parametrize("pinned", [False, True])
 def test_host_pointer_api_sub_batches_and_pinned_buffers(pinned, monkeypatch):
     """blsq_trf_factor copies [J f] in sub-batches of problems on a copy stream, the Gram of one sub-batch under
-    the copy of the next (BLSQ_H2D_PIPE = 0: one copy first); from pageable numpy arrays or from page-locked
-    buffers of blsq_host_alloc.  Every variant gives the same bits."""
+    the copy of the next (by default for page-locked buffers of blsq_host_alloc; BLSQ_H2D_PIPE = 1 / 0 forces it
+    on / off, pageable numpy arrays included).  Every variant gives the same bits."""
     import bounded_lsq as bl
     from bounded_lsq import _synth, _abi
     B, m, n = 40, 4096, 200                                  # 6.6 MB per problem: 14 per sub-batch
