@@ -45,22 +45,32 @@ __global__ __launch_bounds__(256) void cqr2_prep_kernel(Cqr2Args a, const int* p
   }
 }
 
+// first k-tile of the second half of a wave's MFMA stream: the smallest ks with at least half of the 8 (T0 + T1)
+// MFMAs of a chunk's row tile pair in the k-tiles below it
+constexpr int cqr2_split(int T0, int T1) {
+  int sum = 0, ks = 0;
+  while (ks < T1 && 2 * sum < 8 * (T0 + T1)) { sum += (ks < T0) ? 16 : 8; ++ks; }
+  return ks;
+}
+
 // ---- W = (J D) Y^T, w_f = f - J z -------------------------------------------------------------------
 // One workgroup per (row block, listed problem): the rows stream through LDS 32 at a time exactly as in the
 // Gram kernels (double buffered, the next rows prefetched into registers behind the MFMA stream).  Wave W
 // owns the column tiles W and NTJ - 1 - W of W: its B operands — the tiles (k, j), k <= j, of the upper
 // triangular P = D Y^T, at most 17 of them — are loaded ONCE and stay in registers for all rows of the
 // block; the A operands X[row][16 k + 4 s + lr] come from LDS, each fragment feeding both column tiles.
-template <int W, int NCB>
+// FULL: sixteen column tiles (n = 241 .. 256) — every wave has two column tiles with W + 1 and 16 - W B tiles, no
+// guard is left in the MFMA stream (the generic form spent ~2500 instructions per chunk around its 136 MFMAs).
+template <int W, int NCB, bool FULL>
 __device__ __forceinline__ void cqr2_wave(const Cqr2Args& a, double* lds, int b) {
   constexpr int T0 = W + 1, T1 = 16 - W;                // B tiles of column tile W / of column tile NTJ - 1 - W (at most)
   const int tid = threadIdx.x, lane = tid & 63;
   const int lr = lane >> 4, lc = lane & 15;
   const int n = a.n, N = n + 1, NPAD = a.NPAD;
-  const int NTJ = (n + 15) / 16;
+  const int NTJ = FULL ? 16 : (n + 15) / 16;
   const int LDX = cqr2_ldx(N);
   const int c0 = W, c1 = NTJ - 1 - W;                   // (wave-uniform) c0 <= c1: two tiles; c0 == c1: one; else idle
-  const bool has0 = c0 < c1, has1 = c0 <= c1;           // tile c0 only when distinct from c1
+  const bool has0 = FULL || c0 < c1, has1 = FULL || c0 <= c1;   // tile c0 only when distinct from c1
   const int r_lo = blockIdx.x * a.rows_per_wg;
   int r_hi = r_lo + a.rows_per_wg;
   if (r_hi > a.m) r_hi = a.m;
@@ -78,6 +88,9 @@ __device__ __forceinline__ void cqr2_wave(const Cqr2Args& a, double* lds, int b)
       const int row = 16 * k + 4 * s + lr, col = 16 * j + lc;
       double v = 0.0;
       if (row < n && col < n && row <= col) v = dl[row] * Y[(long)col * NPAD + row];
+      // (opaque to the compiler from here on: it otherwise REMATERIALISES the tile — load, scale and guards — in
+      //  every chunk of the row loop instead of keeping it in its register: 177 global loads per 136 MFMAs)
+      asm volatile("" : "+v"(v));
       dst[s] = v;
     }
   };
@@ -131,13 +144,32 @@ __device__ __forceinline__ void cqr2_wave(const Cqr2Args& a, double* lds, int b)
   __syncthreads();
   double* Wjb = a.Wj + (long)b * a.strideW;
   double* Wfb = a.Wf + (long)b * a.strideWf;
+  constexpr bool LATE = W >= 4;
+  v4d acc[2][2];
+  // lane holds W[row0 + 16 rt + lr + 4 g][16 j + lc]
+  auto store_tiles = [&](int row0_) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = row0_ + 16 * rt + lr + 4 * g;
+        if (row < m) {
+          if (has0 && 16 * c0 + lc < n) Wjb[(long)row * n + 16 * c0 + lc] = acc[rt][0][g];
+          if (has1 && 16 * c1 + lc < n) Wjb[(long)row * n + 16 * c1 + lc] = acc[rt][1][g];
+        }
+      }
+    }
+  };
   int cidx = 0;
   for (int row0 = r_lo; row0 < m; row0 += GR_RC, ++cidx) {
     const bool more = row0 + GR_RC < m;
     const double* X = (cidx & 1) ? X1 : X0;
     double* Xn = (cidx & 1) ? X0 : X1;
     if (more) issue(row0 + GR_RC, 0);
-    v4d acc[2][2];
+    // Waves 4 .. 7 (the SIMDs' second waves) store the tiles of the PREVIOUS chunk first and compute after, waves
+    // 0 .. 3 compute first and store after: the two waves of a SIMD are out of phase, the stores (and w_f) of one
+    // run under the MFMAs of the other instead of all eight waves leaving the pipe idle together.
+    if (LATE && cidx > 0) store_tiles(row0 - GR_RC);
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) { acc[rt][0] = v4d{0.0, 0.0, 0.0, 0.0}; acc[rt][1] = v4d{0.0, 0.0, 0.0, 0.0}; }
     const double* Xa = X + lc * LDX + lr;               // A[m = lc][kk = lr] of row tile 0
@@ -154,14 +186,14 @@ __device__ __forceinline__ void cqr2_wave(const Cqr2Args& a, double* lds, int b)
     };
     auto ktile = [&](auto kc) {
       constexpr int k = decltype(kc)::value;
-      if (has1 && k <= c1) {                            // (wave-uniform)
-        if (k + 1 < T1 && k + 1 <= c1) fetch(k + 1, fa[(k + 1) & 1]);
+      if (FULL || (has1 && k <= c1)) {                  // (wave-uniform)
+        if (k + 1 < T1 && (FULL || k + 1 <= c1)) fetch(k + 1, fa[(k + 1) & 1]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const double a0 = fa[k & 1][2 * s], a1 = fa[k & 1][2 * s + 1];
           if constexpr (k < T0) {
-            if (has0) {
+            if (FULL || has0) {
               acc[0][0] = gmfma(a0, B0[k][s], acc[0][0]);
               acc[1][0] = gmfma(a1, B0[k][s], acc[1][0]);
             }
@@ -173,49 +205,46 @@ __device__ __forceinline__ void cqr2_wave(const Cqr2Args& a, double* lds, int b)
       }
     };
     if (has1) fetch(0, fa[0]);
-    static_for<0, (T1 < 8 ? T1 : 8)>(ktile);
+    // the second half of the next rows is requested in the MIDDLE of this wave's MFMAs (k-tiles below T0 carry
+    // 16 of them, the others 8): with the split at k = 8 wave 7 had 128 MFMAs before and 8 behind it, and waited
+    // for those loads at the end of every chunk
+    constexpr int KS = cqr2_split(T0, T1);
+    static_for<0, KS>(ktile);
     if (more) { commit(row0 + GR_RC, 0, Xn); issue(row0 + GR_RC, 1); }
-    if constexpr (T1 > 8) static_for<8, T1>(ktile);
-    // store the tiles: lane holds W[row0 + 16 rt + lr + 4 g][16 j + lc]
+    if constexpr (T1 > KS) static_for<KS, T1>(ktile);
+    if (!LATE) store_tiles(row0);
+    // w_f = f - x^T z for the 32 rows of the chunk: waves 0 .. 3, eight rows each, 16 lanes per row
+    if (!LATE) {
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int row = row0 + 16 * rt + lr + 4 * g;
-        if (row < m) {
-          if (has0 && 16 * c0 + lc < n) Wjb[(long)row * n + 16 * c0 + lc] = acc[rt][0][g];
-          if (has1 && 16 * c1 + lc < n) Wjb[(long)row * n + 16 * c1 + lc] = acc[rt][1][g];
-        }
+      for (int pp = 0; pp < 2; ++pp) {
+        const int row = W * 8 + pp * 4 + lr, cg = lc;
+        double sum = 0.0;
+        for (int c = cg; c < n; c += 16) sum = fma(X[row * LDX + c], zs[c], sum);
+        sum = row16_sum(sum);
+        if (cg == 0 && row0 + row < m) Wfb[row0 + row] = X[row * LDX + n] - sum;
       }
-    }
-    // w_f = f - x^T z for the 32 rows of the chunk: 16 threads per row
-    {
-      const int row = tid >> 4, cg = tid & 15;
-      double sum = 0.0;
-      for (int c = cg; c < n; c += 16) sum = fma(X[row * LDX + c], zs[c], sum);
-      sum = row16_sum(sum);
-      if (cg == 0 && row0 + row < m) Wfb[row0 + row] = X[row * LDX + n] - sum;
     }
     if (more) commit(row0 + GR_RC, 1, Xn);
     __syncthreads();
   }
+  if (LATE && cidx > 0) store_tiles(r_lo + (cidx - 1) * GR_RC);
 }
 
-template <int NCB>
+template <int NCB, bool FULL>
 __global__ __launch_bounds__(GR_NT, 2) void cqr2_apply_kernel(Cqr2Args a) {
   extern __shared__ double lds[];
   const int b = a.list[blockIdx.y];
   if (a.run[b] <= 1) return;
   const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   switch (w) {
-    case 0: cqr2_wave<0, NCB>(a, lds, b); break;
-    case 1: cqr2_wave<1, NCB>(a, lds, b); break;
-    case 2: cqr2_wave<2, NCB>(a, lds, b); break;
-    case 3: cqr2_wave<3, NCB>(a, lds, b); break;
-    case 4: cqr2_wave<4, NCB>(a, lds, b); break;
-    case 5: cqr2_wave<5, NCB>(a, lds, b); break;
-    case 6: cqr2_wave<6, NCB>(a, lds, b); break;
-    default: cqr2_wave<7, NCB>(a, lds, b); break;
+    case 0: cqr2_wave<0, NCB, FULL>(a, lds, b); break;
+    case 1: cqr2_wave<1, NCB, FULL>(a, lds, b); break;
+    case 2: cqr2_wave<2, NCB, FULL>(a, lds, b); break;
+    case 3: cqr2_wave<3, NCB, FULL>(a, lds, b); break;
+    case 4: cqr2_wave<4, NCB, FULL>(a, lds, b); break;
+    case 5: cqr2_wave<5, NCB, FULL>(a, lds, b); break;
+    case 6: cqr2_wave<6, NCB, FULL>(a, lds, b); break;
+    default: cqr2_wave<7, NCB, FULL>(a, lds, b); break;
   }
 }
 
@@ -324,16 +353,17 @@ hipError_t launch_cqr2_apply(const Cqr2Args& a_in, int count, hipStream_t s) {
   const size_t lds = sizeof(double) * (2 * GR_RC * (size_t)cqr2_ldx(N) + (size_t)a.NPAD);
   const dim3 grid((a.m + a.rows_per_wg - 1) / a.rows_per_wg, count, 1);
   const int ncb = (a.n + 63) / 64;
-#define BLSQ_CQR2_LAUNCH(CB)                                                             \
+#define BLSQ_CQR2_LAUNCH(CB, FL)                                                         \
   do {                                                                                   \
     static std::atomic<size_t> granted[64];                                              \
-    hipError_t ge = gram_grant_lds(cqr2_apply_kernel<CB>, lds, granted);                 \
+    hipError_t ge = gram_grant_lds(cqr2_apply_kernel<CB, FL>, lds, granted);             \
     if (ge != hipSuccess) return ge;                                                     \
-    hipLaunchKernelGGL((cqr2_apply_kernel<CB>), grid, dim3(GR_NT), lds, s, a);           \
+    hipLaunchKernelGGL((cqr2_apply_kernel<CB, FL>), grid, dim3(GR_NT), lds, s, a);       \
   } while (0)
-  if (ncb <= 2) BLSQ_CQR2_LAUNCH(2);
-  else if (ncb <= 3) BLSQ_CQR2_LAUNCH(3);
-  else BLSQ_CQR2_LAUNCH(4);
+  if (ncb <= 2) BLSQ_CQR2_LAUNCH(2, false);
+  else if (ncb <= 3) BLSQ_CQR2_LAUNCH(3, false);
+  else if ((a.n + 15) / 16 == 16) BLSQ_CQR2_LAUNCH(4, true);
+  else BLSQ_CQR2_LAUNCH(4, false);
 #undef BLSQ_CQR2_LAUNCH
   return hipGetLastError();
 }
