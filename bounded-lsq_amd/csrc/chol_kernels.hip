@@ -1276,6 +1276,104 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
   chol_rl_body<SL, KL>(a, b, sh, red, pminsh, flagsh);
 }
 
+// ---- certificate, stage 0: the comparison-matrix bound (two triangular solves instead of an inverse) ----
+// For triangular T, |T^-1| <= M(T)^-1 entrywise, M(T) the comparison matrix (diagonal |t_ii|, off-diagonal
+// -|t_ij|; Higham, ASNA 8.2), so  ||R'^-1||_inf <= max_i (M(R')^-1 e)_i  and  ||R'^-1||_1 <= max_j (M(R')^-T e)_j :
+// an O(n^2) PROVEN bound on the pair ||Y||_1 ||Y||_inf of the stage below, which needs the O(n^3) explicit
+// inverse.  It grows like exp(sum of the off-diagonal mass), so it settles what is well conditioned by a margin
+// (Gaussian 4096 x 256: 1600 against the inverse's 430; the bench's bounded problems) and leaves everything else
+// to gram_cond_kernel, which then finds the problem flagged (cert_done) and leaves at once.  With R' = T diag(dl):
+// M(R') z = e  <=>  M(T) w = e, z = w / dl;   M(R')^T y = e  <=>  M(T)^T y = 1 / dl.  All terms are non-negative
+// (no cancellation; the result is inflated by 1e-9 for the rounding of <= 2 n additions per entry).
+__global__ __launch_bounds__(TRI_NT) void gram_cert0_kernel(GramCholArgs a) {
+  extern __shared__ double sh[];
+  __shared__ double red[32];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (a.mask && a.mask[b] <= 1) return;
+  if (a.fb_mask[b] != 0) return;                        // already failed on a pivot
+  const int NPAD = a.NPAD;
+  const int n = a.ncols_dev ? a.ncols_dev[b] - 1 : a.n;
+  if (n <= 0) return;
+  const double* T = a.G + (long)b * NPAD * NPAD;
+  double* x = sh;                        // [NPAD] M(T)^-1 e
+  double* y = x + NPAD;                  // [NPAD] M(T)^-T (1 / dl)
+  double* invd = y + NPAD;               // [NPAD]
+  double* dl = invd + NPAD;              // [NPAD]
+  double* pfbuf = dl + NPAD;             // [2 * 16 * NPAD] DMA staging of the solves
+  double* rowsR = pfbuf;                 // [NPAD] row sums (before the solves: two workgroups per CU need <= 80 KB each)
+  for (int j = tid; j < NPAD; j += TRI_NT) dl[j] = a.dsc[(long)b * NPAD + j];
+  __syncthreads();
+  // the two comparison solves FIRST: ||R'||_1 ||R'||_inf >= lambda_max(C) >= 1, so a product of the two maxima
+  // beyond the gate already decides "not settled here" and the norm passes are skipped
+  tri_invdiag(T, n, NPAD, invd);
+  for (int i = tid; i < n; i += TRI_NT) { x[i] = 1.0; y[i] = 1.0 / dl[i]; }
+  __syncthreads();
+  tri_solve_upper_pf<TRI_NT, true>(T, n, NPAD, invd, x, pfbuf);
+  tri_solve_upper_t_pf<TRI_NT, true>(T, n, NPAD, invd, y, pfbuf);
+  double zm = 0.0, ym = 0.0;
+  for (int i = tid; i < n; i += TRI_NT) { zm = nanmax2(zm, x[i] / dl[i]); ym = nanmax2(ym, y[i]); }
+  zm = block_max(zm, red);
+  ym = block_max(ym, red);
+  const double kmax = a.k2_max > 0.0 ? a.k2_max : GRAM_K2_MAX;
+  if (!(zm * ym <= kmax)) {                             // (uniform; NaN / inf included)
+    if (tid == 0) a.cert_done[b] = 0;
+    return;
+  }
+  __syncthreads();                                      // (rowsR aliases the solves' staging)
+  // ||R'||_1 (thread per column) and ||R'||_inf (wave per row), as gram_cond_kernel
+  double r1 = 0.0;
+  for (int j = tid; j < n; j += TRI_NT) {
+    double sum = 0.0;
+    for (int i0 = 0; i0 <= j; i0 += 32) {
+      double rv[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) rv[u] = T[(long)((i0 + u <= j) ? i0 + u : j) * NPAD + j];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) if (i0 + u <= j) sum += fabs(rv[u]);
+    }
+    r1 = fmax(r1, sum * dl[j]);
+  }
+  r1 = block_max(r1, red);
+  for (int i0 = w; i0 < n; i0 += 4 * TRI_NW) {
+    double rv[4][4], dv[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = (i0 + TRI_NW * q < n) ? i0 + TRI_NW * q : n - 1;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int j = i + lane + WAVE * c;
+        const int jc = j < n ? j : n - 1;
+        rv[q][c] = T[(long)i * NPAD + jc];
+        dv[q][c] = dl[jc];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = i0 + TRI_NW * q;
+      double sum = 0.0;
+      for (int c = 0; c < 4; ++c)
+        if (i < n && i + lane + WAVE * c < n) sum += fabs(rv[q][c]) * dv[q][c];
+      // (n <= 256 per pass of four 64-lane chunks; wider rows: the remaining chunks)
+      for (int j = i + lane + WAVE * 4; i < n && j < n; j += WAVE) sum += fabs(T[(long)i * NPAD + j]) * dl[j];
+      sum = wave_sum(sum);
+      if (lane == 0 && i < n) rowsR[i] = sum;
+    }
+  }
+  __syncthreads();
+  double rinf = 0.0;
+  for (int i = tid; i < n; i += TRI_NT) rinf = fmax(rinf, rowsR[i]);
+  rinf = block_max(rinf, red);
+  const double k2 = (r1 * rinf) * (zm * ym) * (1.0 + 1.0e-9);
+  const bool passed = k2 <= kmax;                       // (NaN / inf fail)
+  if (tid == 0) {
+    a.cert_done[b] = passed ? 1 : 0;
+    if (passed) {
+      if (a.k2_out) a.k2_out[b] = k2;
+      if (a.lam_out) a.lam_out[b] = fmin(r1 * rinf, (double)n);
+    }
+  }
+}
+
 // ---- conditioning gate: a PROVEN bound on kappa_2 of the equilibrated system -----------------------
 // The normal-equations path loses kappa_2(C) eps where C = R'^T R' is the equilibrated system matrix
 // (unit diagonal) the step is solved from.  An estimate of sigma_min(R') by inverse iteration is a
@@ -1638,6 +1736,21 @@ hipError_t launch_gram_cert_shift(const GramCholArgs& a_in, int B, hipStream_t s
 hipError_t launch_gram_gate(const GramCholArgs& a_in, int B, hipStream_t s) {
   GramCholArgs a = a_in;
   a.count = B;
+  // stage 0 (N > 80; the register-resident factor kernel of the small shapes carries its own first bound):
+  // BLSQ_CERT0 = 0 switches it off
+  if (a.NPAD > 80 && a.cert_done && a.dsc) {
+    const char* ce = getenv("BLSQ_CERT0");
+    if (!(ce && ce[0] == '0')) {
+      const size_t lds0 = sizeof(double) * (4 + 32) * (size_t)a.NPAD;
+      static std::atomic<size_t> granted[64];
+      hipError_t ge = gram_grant_lds(gram_cert0_kernel, lds0, granted);
+      if (ge != hipSuccess) return ge;
+      hipLaunchKernelGGL(gram_cert0_kernel, dim3(B), dim3(TRI_NT), lds0, s, a);
+    } else {
+      hipError_t me = hipMemsetAsync(a.cert_done, 0, sizeof(int) * (size_t)B, s);
+      if (me != hipSuccess) return me;
+    }
+  }
   const size_t per1 = sizeof(double) * (6 * (size_t)a.NPAD + 16 * 1 + 64);
   const size_t per8 = sizeof(double) * (6 * (size_t)a.NPAD + 16 * 8 + 64);
   if (a.NPAD <= 80) {                                   // one wave per problem, eight per workgroup

@@ -188,7 +188,9 @@ __device__ __forceinline__ void tri_pf_issue_lower(const double* R, int ld, int 
   }
 }
 
-template <int NT = TRI_NT>
+// CMP: the COMPARISON matrix M(R) instead of R (diagonal as it is, off-diagonal entries -|r_ij|): for a non-negative
+// right-hand side the solution is entrywise >= |R^-1| rhs (Higham, ASNA 8.2) — the certificate's stage 0.
+template <int NT = TRI_NT, bool CMP = false>
 __device__ __forceinline__ void tri_solve_upper_pf(const double* R, int n, int ld,
                                                    const double* invd, double* x, double* buf) {
   const int tid = threadIdx.x;
@@ -209,7 +211,7 @@ __device__ __forceinline__ void tri_solve_upper_pf(const double* R, int n, int l
       double D[16];
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        const double val = b[(c0 + i) * 16 + s];
+        const double val = CMP ? -fabs(b[(c0 + i) * 16 + s]) : b[(c0 + i) * 16 + s];
         D[s] = (i < bs && s < bs && s > i) ? val : 0.0;
       }
       double r = (i < bs) ? x[c0 + i] : 0.0;
@@ -226,7 +228,7 @@ __device__ __forceinline__ void tri_solve_upper_pf(const double* R, int n, int l
       const double* row = b + i * 16;
       double acc = 0.0;
 #pragma unroll
-      for (int s = 0; s < 16; ++s) acc = fma(row[s], (s < bs) ? x[c0 + s] : 0.0, acc);
+      for (int s = 0; s < 16; ++s) acc = fma(CMP ? -fabs(row[s]) : row[s], (s < bs) ? x[c0 + s] : 0.0, acc);
       x[i] -= acc;
     }
     lds_barrier();
@@ -234,7 +236,7 @@ __device__ __forceinline__ void tri_solve_upper_pf(const double* R, int n, int l
   }
 }
 
-template <int NT = TRI_NT>
+template <int NT = TRI_NT, bool CMP = false>
 __device__ __forceinline__ void tri_solve_upper_t_pf(const double* R, int n, int ld,
                                                      const double* invd, double* y, double* buf) {
   const int tid = threadIdx.x;
@@ -256,7 +258,7 @@ __device__ __forceinline__ void tri_solve_upper_t_pf(const double* R, int n, int
       double D[16];
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        const double val = b[s * L + i];
+        const double val = CMP ? -fabs(b[s * L + i]) : b[s * L + i];
         D[s] = (i < bs && s < bs && s < i) ? val : 0.0;
       }
       double r = (i < bs) ? y[c0 + i] : 0.0;
@@ -272,7 +274,8 @@ __device__ __forceinline__ void tri_solve_upper_t_pf(const double* R, int n, int
     for (int j = c0 + 16 + tid; j < n; j += NT) {    // columns to the right of the block
       double acc = 0.0;
 #pragma unroll
-      for (int s = 0; s < 16; ++s) acc = fma(b[s * L + (j - c0)], (s < bs) ? y[c0 + s] : 0.0, acc);
+      for (int s = 0; s < 16; ++s)
+        acc = fma(CMP ? -fabs(b[s * L + (j - c0)]) : b[s * L + (j - c0)], (s < bs) ? y[c0 + s] : 0.0, acc);
       y[j] -= acc;
     }
     lds_barrier();

@@ -882,3 +882,36 @@ def test_bounded_problems_are_gated_on_the_augmented_system(bl, rho):
     stats, worst = _check(bl, P, np.array([10.0, 0.5, 2.0]))
     assert stats == (B, 0), stats
     assert worst < 1e-11
+
+
+def test_stage_zero_of_the_certificate_changes_no_verdict(bl, monkeypatch):
+    """Stage 0 (comparison-matrix bound: two triangular solves instead of the explicit inverse) only SETTLES
+    well-conditioned problems early; with it switched off (BLSQ_CERT0 = 0) the later stages reach the same
+    verdicts, and every step comes out bit for bit the same.  Its bound is a bound: K2 >= the true kappa_2."""
+    from bounded_lsq import _synth, _abi
+    B, m, n = 8, 2048, 160
+    P = _synth.trf_batch(91, B, m, n, unbounded=True)
+    rho = np.array([0.0, 0.0, 0.3, 0.9, 0.99, 0.9995, 0.0, 1 - 1e-9])
+    Jc = _equicorrelated(B, m, n, rho, 13)
+    for b in range(B):
+        if rho[b] > 0:
+            P["J"][b] = Jc[b]
+    Delta = np.full(B, 0.7)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("BLSQ_CERT0", flag)
+        ctx = _abi.Context(0)
+        sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
+        ctx.gram_stats(reset=True)
+        sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+        stats = ctx.gram_stats()
+        k2 = sol.debug_cond()
+        S = sol.step(Delta, np.zeros(B))
+        outs.append((stats, k2.copy(), S.step.copy(), np.asarray(S.n_iter).copy()))
+        sol.close(); ctx.close()
+    (s1, k1, st1, it1), (s0, k0, st0, it0) = outs
+    assert s1 == s0 and s1[1] >= 1 and s1[0] >= 5
+    assert np.array_equal(st1, st0) and np.array_equal(it1, it0)
+    assert np.any(k1 != k0)                                   # (stage 0 settled some problems with its own bound)
+    _certificate_holds(P, k1, s1)
+    _certificate_holds(P, k0, s0)
