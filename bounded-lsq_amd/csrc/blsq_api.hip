@@ -1523,6 +1523,10 @@ extern "C" int blsq_trf_fetch_factor(blsq_trf_plan* p, double* g, double* g_norm
   return blsq_sync(ctx);
 }
 
+#ifdef BLSQ_CHOL_STAMPS
+namespace blsq { int chol_debug_stamps(long long* host); }
+extern "C" int blsq_debug_chol_stamps(long long* host) { return blsq::chol_debug_stamps(host); }
+#endif
 extern "C" int blsq_debug_qr_stamps(void* dbuf) {
   set_qr_debug_buffer(reinterpret_cast<double*>(dbuf));
   return 0;

@@ -12,6 +12,30 @@
 
 namespace blsq {
 
+// Diagnostic build only (-DBLSQ_CHOL_STAMPS): wall-clock stamps (100 MHz) of the phases of every row block, taken
+// by lane 0 of two waves of ONE problem (launch index CHOL_STAMP_PIDX).  Never enabled in the product.
+#ifdef BLSQ_CHOL_STAMPS
+__device__ long long g_chol_st[4][20][8];
+#define CST(cond, p, kb, i) do { if ((cond) && lane == 0) g_chol_st[p][kb][i] = (long long)wall_clock64(); } while (0)
+#else
+#define CST(cond, p, kb, i) do { } while (0)
+#endif
+
+// column-norm summary of the first n columns by ONE wave: min / max of sqrt(h_jj) and the sum of h_jj in a FIXED
+// order (lane-strided partial sums, then a butterfly) — the same bits in every kernel that factors N > 80
+__device__ __forceinline__ void colinfo_wave(const double* sq, int n, int lane, double& mn, double& mx, double& sm) {
+  mn = __builtin_inf(); mx = 0.0; sm = 0.0;
+  for (int j = lane; j < n; j += WAVE) {
+    const double v = sq[j];
+    mn = v < mn ? v : mn; mx = v > mx ? v : mx; sm = fma(v, v, sm);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const double omn = __shfl_xor(mn, o, WAVE), omx = __shfl_xor(mx, o, WAVE), osm = __shfl_xor(sm, o, WAVE);
+    mn = omn < mn ? omn : mn; mx = omx > mx ? omx : mx; sm = sm + osm;
+  }
+}
+
 // ---- equilibrated blocked Cholesky, in place in the triangle slot -------------------------------
 // Row block kb of R' :  S_j = C_{kb,j} - sum_{k<kb} R'_{k,kb}^T R'_{k,j}   (MFMA, operands from the
 // rows already written),  R'_{kb,kb} = chol(S_kb) and its inverse on wave 0 (lane j owns column
@@ -105,10 +129,13 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
   }
   if (a.colinfo) {                                      // (uniform) column-norm summary for the rank gate
     psync();
-    if (tid == 0) {
-      double mn = __builtin_inf(), sm = 0.0;
-      double mx = 0.0;
+    double mn = __builtin_inf(), sm = 0.0, mx = 0.0;
+    if (NWP == 8) {
+      if (w == 0) colinfo_wave(sq, n, lane, mn, mx, sm);
+    } else if (tid == 0) {
       for (int j = 0; j < n; ++j) { const double v = sq[j]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; sm = fma(v, v, sm); }
+    }
+    if (tid == 0) {
       a.colinfo[2 * (long)b] = mn; a.colinfo[2 * (long)b + 1] = sm;
       if (a.hmax) a.hmax[b] = mx * mx;
       if (a.lam_out) a.lam_out[b] = (double)n;
@@ -131,7 +158,10 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
     return;
   }
 
+  const bool stp = (NWP == 8) && pidx == (a.count > 300 ? 300 : 0) && !a.cert_shift;   // (diagnostic stamps)
+  (void)stp;
   for (int kb = 0; kb < NT; ++kb) {
+    CST(stp && w == 0, 0, kb, 0); CST(stp && w == 3, 1, kb, 0);
     // ---- A. Schur complements of this row block (tile j = kb + w + 8 u) ----
     v4d S[UMAX];
     const double dk = dl[16 * kb + lc];
@@ -170,11 +200,14 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
     }
     // ---- B. wave 0: Cholesky of the diagonal tile and its inverse (chol16.h), straight from the
     // accumulators of its Schur complement ----
+    CST(stp && w == 0, 0, kb, 1); CST(stp && w == 3, 1, kb, 1);
     if (w == 0) {
       const double pm = chol16_blocked3(S[0], Dt, Ri, n - 16 * kb, pminsh);
       if (lane == 0) pminsh = pm;
     }
+    CST(stp && w == 0, 0, kb, 2);
     psync();
+    CST(stp && w == 0, 0, kb, 3); CST(stp && w == 3, 1, kb, 3);
     if (a.rinv && w == NWP - 1) {                       // kept for the conditioning certificate (off the chain)
       double* ro = a.rinv + ((long)b * (NPAD / 16) + kb) * 256;
 #pragma unroll
@@ -204,7 +237,9 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
         }
       }
     }
+    CST(stp && w == 0, 0, kb, 4); CST(stp && w == 3, 1, kb, 4);
     psync();
+    CST(stp && w == 0, 0, kb, 5); CST(stp && w == 3, 1, kb, 5);
   }
   if (16 * NT < NPAD && !a.skip_zero) {                  // sub-matrix: the rest of the slot is zero
     for (int r = w; r < NPAD; r += NWP) {
@@ -1023,6 +1058,8 @@ __device__ __forceinline__ void chol_rl_body(const GramCholArgs& a, const int b,
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane >> 4, lc = lane & 15;
   const int NPAD = a.NPAD;
+  const bool stp0 = (int)blockIdx.x == 100 && !a.cert_shift; (void)stp0;
+  CST(stp0 && (w == 0 || w == 2), w == 0 ? 2 : 3, 17, 0);
   if (a.mask && a.mask[b] <= 1) {
     if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
     return;
@@ -1076,10 +1113,9 @@ __device__ __forceinline__ void chol_rl_body(const GramCholArgs& a, const int b,
   }
   if (a.colinfo) {
     __syncthreads();
+    double mn = __builtin_inf(), sm = 0.0, mx = 0.0;
+    if (w == 0) colinfo_wave(sq, n, lane, mn, mx, sm);
     if (tid == 0) {
-      double mn = __builtin_inf(), sm = 0.0;
-      double mx = 0.0;
-      for (int j = 0; j < n; ++j) { const double v = sq[j]; mn = v < mn ? v : mn; mx = v > mx ? v : mx; sm = fma(v, v, sm); }
       a.colinfo[2 * (long)b] = mn; a.colinfo[2 * (long)b + 1] = sm;
       if (a.hmax) a.hmax[b] = mx * mx;
       if (a.lam_out) a.lam_out[b] = (double)n;
@@ -1096,6 +1132,7 @@ __device__ __forceinline__ void chol_rl_body(const GramCholArgs& a, const int b,
     }
     return;
   }
+  CST(stp0 && (w == 0 || w == 2), w == 0 ? 2 : 3, 17, 1);
   // ROLES: wave 0 only runs the 16x16 chains (its registers hold the column / inverse vectors, no
   // tiles); waves 1..7 own the tiles.  LOOKAHEAD: in the trailing update of row block kb the owner
   // of the next diagonal tile updates it first, puts it into LDS and raises a flag; wave 0 starts
@@ -1103,6 +1140,8 @@ __device__ __forceinline__ void chol_rl_body(const GramCholArgs& a, const int b,
   // loops pass the same two barriers per row block.
   constexpr int NWK = GR_NW - 1;                        // worker waves
   const int ntile = NT * (NT + 1) / 2;
+  const bool stp = (int)blockIdx.x == 100 && !a.cert_shift;   // (diagnostic stamps)
+  (void)stp;
   // zeros outside the factor: strictly lower tiles, and everything beyond 16 NT (sub-matrix use)
   auto zero_fill = [&]() {
     for (int r = w; r < (a.skip_zero ? 0 : NPAD); r += GR_NW) {
@@ -1114,7 +1153,9 @@ __device__ __forceinline__ void chol_rl_body(const GramCholArgs& a, const int b,
   };
   if (w == 0) {
     __syncthreads();                                    // X: workers have read the source, Dt holds tile (0, 0)
+    CST(stp, 2, 17, 3);
     zero_fill();
+    CST(stp, 2, 17, 4);
     double pmin = 1.0;
     for (int kb = 0; kb < NT; ++kb) {
       if (kb > 0) {                                     // wait for the updated diagonal tile kb
@@ -1122,14 +1163,18 @@ __device__ __forceinline__ void chol_rl_body(const GramCholArgs& a, const int b,
           __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
       }
+      CST(stp, 2, kb, 0);
       pmin = chol16_blocked3(Dt, Ri, n - 16 * kb, pmin);   // (chol16.h)
+      CST(stp, 2, kb, 1);
       if (a.rinv) {                                     // kept for the conditioning certificate
         double* ro = a.rinv + ((long)b * (NPAD / 16) + kb) * 256;
 #pragma unroll
         for (int q = 0; q < 4; ++q) ro[q * 64 + lane] = Ri[q * 64 + lane];
       }
       __syncthreads();                                  // B: R'_kk and its inverse are in LDS
+      CST(stp, 2, kb, 2);
       __syncthreads();                                  // C: (workers published the row block)
+      CST(stp, 2, kb, 3);
     }
     if (lane == 0) pminsh = pmin;
   } else {
@@ -1183,10 +1228,15 @@ __device__ __forceinline__ void chol_rl_body(const GramCholArgs& a, const int b,
       }
       RL_ACC_PUT(t, a0);
     }
+    CST(stp && w == 2, 3, 17, 2);
     __syncthreads();                                    // X: all source reads done before the first store
+    CST(stp && w == 2, 3, 17, 3);
     zero_fill();
+    CST(stp && w == 2, 3, 17, 4);
     for (int kb = 0; kb < NT; ++kb) {
+      CST(stp && w == 2, 3, kb, 5);
       __syncthreads();                                  // B: wave 0 finished the chain of block kb
+      CST(stp && w == 2, 3, kb, 0);
       // c. the row block: R'_{kb,j} = R'_{kb,kb}^-T S_j -> LDS row buffer and (unscaled) to memory
 #pragma unroll
       for (int t = 0; t < SL; ++t) {
@@ -1217,7 +1267,9 @@ __device__ __forceinline__ void chol_rl_body(const GramCholArgs& a, const int b,
           }
         }
       }
+      CST(stp && w == 2, 3, kb, 1);
       __syncthreads();                                  // C: the row block is in the LDS buffer
+      CST(stp && w == 2, 3, kb, 2);
       // d. trailing update: the next diagonal tile first (-> LDS, flag for wave 0), then the rest
 #pragma unroll
       for (int t = 0; t < SL; ++t) {
@@ -1234,6 +1286,7 @@ __device__ __forceinline__ void chol_rl_body(const GramCholArgs& a, const int b,
           if (lane == 0) __hip_atomic_store(&flagsh, kb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
+      CST(stp && w == 2, 3, kb, 3);
 #pragma unroll
       for (int t = 0; t < SL; ++t) {
         if (ti[t] > kb && !(ti[t] == kb + 1 && tj[t] == kb + 1)) {
@@ -1246,11 +1299,14 @@ __device__ __forceinline__ void chol_rl_body(const GramCholArgs& a, const int b,
           RL_ACC_PUT(t, S);
         }
       }
+      CST(stp && w == 2, 3, kb, 4);
     }
 #undef RL_ACC_GET
 #undef RL_ACC_PUT
   }
+  CST(stp && (w == 0 || w == 2), w == 0 ? 2 : 3, 18, 0);
   __syncthreads();
+  CST(stp && (w == 0 || w == 2), w == 0 ? 2 : 3, 18, 1);
   if (tid == 0 && a.fb_mask) {
     const bool fail = !(pminsh >= (a.pivot_floor > 0.0 ? a.pivot_floor : 1.0 / GRAM_K2_MAX));
     a.fb_mask[b] = fail ? a.n + 1 : 0;
@@ -1274,6 +1330,347 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl_kernel(GramCholArgs a) 
   if (a.count_dev && pidx >= *a.count_dev) return;
   const int b = a.batch_list ? a.batch_list[pidx] : pidx;
   chol_rl_body<SL, KL>(a, b, sh, red, pminsh, flagsh);
+}
+
+// ---- right-looking, flag-driven: no workgroup barrier inside the factorisation -------------------
+// The arithmetic of gram_chol_rl_kernel (same tiles, same operands, same order: the same bits), scheduled along its
+// critical path  chain(kb) -> R'_{kb,kb+1} -> S_{kb+1,kb+1} -> chain(kb + 1):
+//   * wave 0 only runs the 16x16 chains: it waits for the flag "diagonal tile kb is in Dt", factors, raises "R'_kk
+//     and its inverse are in LDS" — it never meets a barrier, nor the stores of the workers;
+//   * the owner of tile (kb, kb+1) solves it first and raises a flag; the owner of (kb+1, kb+1) waits for exactly
+//     that tile, updates the diagonal tile and hands it to wave 0; only then come the other tiles of the row;
+//   * the trailing update of a worker starts when a COUNTER says that all seven workers have published their
+//     tiles of the row block — LDS flags and lgkmcnt waits only, so nobody waits for the acknowledgement of the
+//     global stores of the factor (a __syncthreads does: vmcnt counts stores on gfx9);
+//   * Dt, Ri and the row buffer are double-buffered by the parity of kb.  Buffer kb & 1 is written again at row block
+//     kb + 2, whose chain needs S_{kb+2,kb+2}, i.e. its owner's trailing update with row kb, which waited for the
+//     counter of row kb — every worker had then read Ri / Dt of kb and finished its trailing update of kb - 1.
+//   * the source tiles are requested ALL AT ONCE at kernel entry (the old preamble paid one memory round trip per
+//     tile slot: 37 us) and the column summary is a wave reduction (14 -> 3 us).
+// SL tile slots per worker wave, the first KL in LDS (top rows: dead after three row blocks).
+__device__ __forceinline__ void spin_ge(const int* f, int v) {
+  while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void raise_flag(int* f, int v, int lane) {      // (after this wave's LDS writes)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+enum { FL_DIAG = 0, FL_RINV = 1, FL_ROW1 = 2, FL_PUB = 3, FL_BAD = 4 };
+
+template <int SL, int KL>
+__device__ __forceinline__ void chol_rl2_body(const GramCholArgs& a, const int b, double* sh, int* fl, double& pminsh) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane >> 4, lc = lane & 15;
+  const int NPAD = a.NPAD;
+  const bool stp = (int)blockIdx.x == 100 && !a.cert_shift; (void)stp;
+  CST(stp && (w == 0 || w == 2), w == 0 ? 2 : 3, 17, 0);
+  if (a.mask && a.mask[b] <= 1) {
+    if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
+    return;
+  }
+  if (a.skip_path && a.skip_path[b] != 0 && !(a.qr_mask && a.qr_mask[b] == 0)) return;
+  double tau = 0.0;                                     // certificate stage 3: factor C - tau I
+  if (a.cert_shift) {
+    if (!a.cert_flag[b]) return;                        // (uniform)
+    tau = a.cert_tau[b];
+  }
+  const int N = a.ncols_dev ? a.ncols_dev[b] : a.n + 1;
+  if (N <= 1) {                                         // (dogbox: every variable active — nothing to factor)
+    if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
+    return;
+  }
+  const int n = N - 1;
+  const int NT = (N + 15) / 16;
+  const int NTP = NPAD / 16;
+  const int* gidx = a.gather ? a.gather + (long)b * a.stride_vec : nullptr;
+  const double* Gs = a.Gsrc + (long)b * NPAD * NPAD;
+  double* Gb = a.G + (long)b * NPAD * NPAD;
+  double* dl = sh;                 // [NPAD]
+  double* sq = dl + NPAD;          // [NPAD]
+  double* sc = sq + NPAD;          // [NPAD]
+  double* td = sc + NPAD;          // [NPAD]
+  double* Dt = td + NPAD;          // [2][256]
+  double* Ri = Dt + 512;           // [2][256]
+  double* Rrow = Ri + 512;         // [2][NTP][256] finished tiles of a row block (operands of the trailing updates)
+  double* accL = Rrow + 2 * (size_t)NTP * 256;          // [KL][7][256] the LDS-resident tile slots
+  int* gl = reinterpret_cast<int*>(accL + (size_t)KL * (GR_NW - 1) * 256);   // [NPAD] gathered source indices
+  const double* csv = a.colscale ? a.colscale + (long)b * a.stride_vec : nullptr;
+  const double* edv = a.diag_vec ? a.diag_vec + (long)b * a.stride_vec : nullptr;
+  const double sa = a.diag_sqrt ? a.diag_sqrt[b] : 0.0;
+  if (tid < 8) fl[tid] = 0;
+  if (tid == 0) pminsh = 1.0;
+  if (gidx) {                                           // (uniform) the index map of a gathered sub-matrix -> LDS
+    for (int j = tid; j < NPAD; j += GR_NT) gl[j] = j < n ? gidx[j] : a.n;
+  }
+  __syncthreads();
+  auto src = [&](int i) -> int { return gidx ? gl[i] : i; };     // (i < N)
+
+  constexpr int NWK = GR_NW - 1;                        // worker waves
+  const int ww = w - 1;
+  // tile q (row-major over the upper tiles) -> worker q % 7, slot q / 7; packed (i | j << 8) per slot
+  int tij[SL];
+  v4d acc[SL];                                          // (slots < KL leave for LDS after the scaling)
+  if (w > 0) {
+    int i = 0, off = ww;                                // slot 0: q = ww
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+      while (i < NT && off >= NT - i) { off -= NT - i; ++i; }
+      const bool valid = i < NT;
+      tij[t] = valid ? (i | ((i + off) << 8)) : -1;
+      acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
+      if (valid) {
+        const int j = i + off;
+        const int col = 16 * j + lc;
+        const int scol = col < N ? src(col) : 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * i + lr + 4 * g;
+          int sr_ = row < N ? src(row) : 0, sc_ = scol;
+          if (sr_ > sc_) { const int t_ = sr_; sr_ = sc_; sc_ = t_; }       // symmetric: stay in the upper tiles
+          acc[t][g] = Gs[(unsigned)(sr_ * NPAD + sc_)];                     // (raw; selected and scaled below)
+        }
+      }
+      off += NWK;
+    }
+  }
+  // column scales from the diagonal of H
+  int bad = 0;
+  for (int j = tid; j < NPAD; j += GR_NT) {
+    const double cs = (csv && j < n) ? csv[j] : 1.0;
+    const double ej = (edv && j < n) ? edv[j] : 0.0;
+    const double add = (j < n) ? fma(ej, ej, sa * sa) : 0.0;
+    const int sj_ = (j < N) ? src(j) : j;
+    const double g = (j < N) ? fma(Gs[(long)sj_ * NPAD + sj_] * cs, cs, add) : 0.0;
+    const bool okc = (g > 0.0) && is_finite(g);
+    if (j < n && !okc) bad = 1;
+    double d = 1.0, s_ = 1.0;
+    if (j < N && okc) {
+      d = __builtin_amdgcn_rsq(g);
+      d = d * fma(-0.5 * g * d, d, 1.5);
+      d = d * fma(-0.5 * g * d, d, 1.5);
+      s_ = g * d;
+    }
+    dl[j] = d; sq[j] = s_; sc[j] = cs * d; td[j] = add * d * d - ((j < n) ? tau : 0.0);
+    if (a.dsc) a.dsc[(long)b * NPAD + j] = d;
+  }
+  if (__any(bad) && lane == 0) __hip_atomic_store(&fl[FL_BAD], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  CST(stp && (w == 0 || w == 2), w == 0 ? 2 : 3, 17, 1);
+  __syncthreads();                                      // S: the scales are in LDS
+  auto slot = [&](int t) -> double* { return accL + ((size_t)t * NWK + ww) * 256 + lane; };   // [g * 64]
+#define RL2_GET(t, dst)                                                           \
+    do {                                                                          \
+      if ((t) < KL) { const double* p_ = slot(t);                                 \
+        dst = v4d{p_[0], p_[64], p_[128], p_[192]}; }                             \
+      else dst = acc[t];                                                          \
+    } while (0)
+#define RL2_PUT(t, srcv)                                                          \
+    do {                                                                          \
+      if ((t) < KL) { double* p_ = slot(t);                                       \
+        p_[0] = (srcv)[0]; p_[64] = (srcv)[1]; p_[128] = (srcv)[2]; p_[192] = (srcv)[3]; } \
+      else acc[t] = srcv;                                                         \
+    } while (0)
+  if (w == 0) {
+    if (a.colinfo) {                                    // column-norm summary for the rank gate
+      double mn, mx, sm;
+      colinfo_wave(sq, n, lane, mn, mx, sm);
+      if (lane == 0) {
+        a.colinfo[2 * (long)b] = mn; a.colinfo[2 * (long)b + 1] = sm;
+        if (a.hmax) a.hmax[b] = mx * mx;
+        if (a.lam_out) a.lam_out[b] = (double)n;
+      }
+    }
+  } else {
+    // the scaled source tiles (the source may alias the output: everything is read before anything is written)
+#pragma unroll
+    for (int t = 0; t < SL; ++t) {
+      if (tij[t] >= 0) {
+        const int i = tij[t] & 255, j = tij[t] >> 8;
+        const double scj = sc[16 * j + lc];
+        v4d a0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * i + lr + 4 * g, col = 16 * j + lc;
+          double v = 0.0;
+          if (row < N && col < N) v = acc[t][g] * sc[row] * scj;
+          if (j == i && lr + 4 * g == lc) v += td[row];
+          a0[g] = v;
+        }
+        if (i == 0 && j == 0) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) Dt[(lr + 4 * g) * 16 + lc] = a0[g];
+        }
+        RL2_PUT(t, a0);
+      }
+    }
+  }
+  CST(stp && w == 2, 3, 17, 2);
+  __syncthreads();                                      // X: all source reads done before the first store
+  CST(stp && (w == 0 || w == 2), w == 0 ? 2 : 3, 17, 3);
+  if (__hip_atomic_load(&fl[FL_BAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {   // uniform: to the QR tree
+    if (tid == 0 && a.fb_mask) {
+      a.fb_mask[b] = a.n + 1; { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }   // (the tree factors ALL n + 1 columns)
+      if (a.path_out) a.path_out[b] = a.n + 1;
+      if (a.k2_out && !a.cert_shift) a.k2_out[b] = 0.0;
+    }
+    return;
+  }
+  // zeros outside the factor: strictly lower tiles, and everything beyond 16 NT (sub-matrix use)
+  for (int r = w; r < (a.skip_zero ? 0 : NPAD); r += GR_NW) {
+    const int cend = (r < 16 * NT) ? (r & ~15) : NPAD;
+    for (int c = lane; c < cend; c += WAVE) Gb[(unsigned)(r * NPAD + c)] = 0.0;
+    if (r < 16 * NT)
+      for (int c = 16 * NT + lane; c < NPAD; c += WAVE) Gb[(unsigned)(r * NPAD + c)] = 0.0;
+  }
+  CST(stp && (w == 0 || w == 2), w == 0 ? 2 : 3, 17, 4);
+  if (w == 0) {
+    double pmin = 1.0;
+    for (int kb = 0; kb < NT; ++kb) {
+      double* DtC = Dt + (kb & 1) * 256;
+      double* RiC = Ri + (kb & 1) * 256;
+      if (kb > 0) spin_ge(&fl[FL_DIAG], kb);            // the updated diagonal tile kb is in DtC
+      CST(stp, 2, kb, 0);
+      pmin = chol16_blocked3(DtC, RiC, n - 16 * kb, pmin);   // (chol16.h; ends with lgkmcnt(0))
+      if (lane == 0) __hip_atomic_store(&fl[FL_RINV], kb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      CST(stp, 2, kb, 1);
+      if (a.rinv) {                                     // kept for the conditioning certificate
+        double* ro = a.rinv + ((long)b * NTP + kb) * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ro[q * 64 + lane] = RiC[q * 64 + lane];
+      }
+    }
+    if (lane == 0) pminsh = pmin;
+  } else {
+    for (int kb = 0; kb < NT; ++kb) {
+      const double* DtC = Dt + (kb & 1) * 256;
+      const double* RiC = Ri + (kb & 1) * 256;
+      double* RrowC = Rrow + (size_t)(kb & 1) * NTP * 256;
+      // this wave's slots of row block kb: tiles q0 .. q0 + NT - kb - 1
+      const int q0 = kb * NT - kb * (kb - 1) / 2;
+      const int t_lo = (q0 - ww + NWK - 1 + NWK) / NWK - 1;          // ceil((q0 - ww) / 7), q0 - ww >= -6
+      const int t_hi = (q0 + NT - kb - 1 - ww + NWK) / NWK - 1;      // floor(.. / 7)
+      const int t_one = ((q0 + 1 - ww) % NWK == 0 && kb + 1 < NT) ? (q0 + 1 - ww) / NWK : -1;   // slot of (kb, kb+1)
+      const int q1 = q0 + NT - kb;                                     // tile (kb+1, kb+1)
+      const int t_dia = ((q1 - ww) % NWK == 0 && kb + 1 < NT) ? (q1 - ww) / NWK : -1;
+      CST(stp && w == 2, 3, kb, 5);
+      spin_ge(&fl[FL_RINV], kb + 1);                    // R'_kk and its inverse are in LDS
+      CST(stp && w == 2, 3, kb, 0);
+      double rf[4];
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) rf[s_] = RiC[(4 * s_ + lr) * 16 + lc];
+      // R'_{kb,j} = R'_{kb,kb}^-T S_j -> memory (as R = R' D^-1) and the LDS row buffer
+      auto solve_tile = [&](int t, const v4d& S) {
+        const int j = kb + (ww + NWK * t - q0);
+        v4d X = {0.0, 0.0, 0.0, 0.0};
+        if (j == kb) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) X[g] = DtC[(lr + 4 * g) * 16 + lc];
+        } else {
+#pragma unroll
+          for (int s_ = 0; s_ < 4; ++s_) X = gmfma(rf[s_], S[s_], X);
+        }
+        const double sj = sq[16 * j + lc];
+        const double dj = dl[16 * j + lc];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * kb + lr + 4 * g;
+          const int colg = 16 * j + lc;
+          double val = X[g] * sj;
+          if (row >= n || row > colg || colg > n) val = 0.0;
+          Gb[(unsigned)(row * NPAD + colg)] = val;
+          // the operand of the trailing updates is what the left-looking kernel reads back: the STORED
+          // entry times its column's equilibration — all factor kernels agree bit for bit
+          if (j != kb) RrowC[j * 256 + (lr + 4 * g) * 16 + lc] = val * dj;
+        }
+      };
+      // 1. the critical tile (kb, kb + 1) first
+      if (t_one >= 0) {
+        CST(stp, 1, kb, 0);
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+          if (t == t_one) { v4d S; RL2_GET(t, S); solve_tile(t, S); }
+        }
+        raise_flag(&fl[FL_ROW1], kb + 1, lane);
+        CST(stp, 1, kb, 1);
+      }
+      // 2. the next diagonal tile: S_{kb+1,kb+1} -= R'_{kb,kb+1}^T R'_{kb,kb+1} -> Dt of the other parity
+      if (t_dia >= 0) {
+        spin_ge(&fl[FL_ROW1], kb + 1);
+        CST(stp, 1, kb, 2);
+        const double* Ra = RrowC + (kb + 1) * 256 + lr * 16 + lc;
+        double* DtN = Dt + ((kb + 1) & 1) * 256;
+#pragma unroll
+        for (int t = 0; t < SL; ++t) {
+          if (t == t_dia) {
+            v4d S;
+            RL2_GET(t, S);
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) S = gmfma(-Ra[64 * s_], Ra[64 * s_], S);
+            RL2_PUT(t, S);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) DtN[(lr + 4 * g) * 16 + lc] = S[g];
+          }
+        }
+        raise_flag(&fl[FL_DIAG], kb + 1, lane);
+        CST(stp, 1, kb, 3);
+      }
+      CST(stp && w == 2, 3, kb, 1);
+      // 3. the other tiles of the row block
+#pragma unroll
+      for (int t = 0; t < SL; ++t) {
+        if (t >= t_lo && t <= t_hi && t != t_one) { v4d S; RL2_GET(t, S); solve_tile(t, S); }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(&fl[FL_PUB], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      CST(stp && w == 2, 3, kb, 2);
+      if (kb + 1 >= NT) break;
+      spin_ge(&fl[FL_PUB], NWK * (kb + 1));             // every worker's tiles of the row block are in RrowC
+      CST(stp && w == 2, 3, kb, 3);
+      // 4. trailing update of this wave's tiles (ascending rows; the next diagonal tile is done)
+#pragma unroll
+      for (int t = 0; t < SL; ++t) {
+        if (t > t_hi && t != t_dia && tij[t] >= 0) {
+          const int i = tij[t] & 255, j = tij[t] >> 8;
+          const double* Ra = RrowC + i * 256 + lr * 16 + lc;
+          const double* Rb = RrowC + j * 256 + lr * 16 + lc;
+          v4d S;
+          RL2_GET(t, S);
+#pragma unroll
+          for (int s_ = 0; s_ < 4; ++s_) S = gmfma(-Ra[64 * s_], Rb[64 * s_], S);
+          RL2_PUT(t, S);
+        }
+      }
+      CST(stp && w == 2, 3, kb, 4);
+    }
+  }
+#undef RL2_GET
+#undef RL2_PUT
+  CST(stp && (w == 0 || w == 2), w == 0 ? 2 : 3, 18, 0);
+  __syncthreads();
+  CST(stp && (w == 0 || w == 2), w == 0 ? 2 : 3, 18, 1);
+  if (tid == 0 && a.fb_mask) {
+    const bool fail = !(pminsh >= (a.pivot_floor > 0.0 ? a.pivot_floor : 1.0 / GRAM_K2_MAX));
+    a.fb_mask[b] = fail ? a.n + 1 : 0;
+    if (a.path_out) a.path_out[b] = fail ? a.n + 1 : 0;
+    if (fail) { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
+    if (fail && !a.cert_shift && a.k2_out) a.k2_out[b] = 0.0;      // (no bound for this factorisation)
+    if (a.cert_shift) {
+      a.cert_flag[b] = 0;
+      if (!fail && a.k2_out) a.k2_out[b] = a.k2_max;    // proven: kappa_2 <= Lambda / tau
+    }
+  }
+}
+
+template <int SL, int KL>
+__global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl2_kernel(GramCholArgs a) {
+  extern __shared__ double sh[];
+  __shared__ double pminsh;
+  __shared__ int fl[8];                                 // FL_*: hand-over flags and the publication counter
+  const int pidx = (int)blockIdx.x;
+  if (a.count_dev && pidx >= *a.count_dev) return;
+  const int b = a.batch_list ? a.batch_list[pidx] : pidx;
+  chol_rl2_body<SL, KL>(a, b, sh, fl, pminsh);
 }
 
 // ---- certificate, stage 0: the comparison-matrix bound (two triangular solves instead of an inverse) ----
@@ -1705,7 +2102,16 @@ hipError_t launch_gram_chol(const GramCholArgs& a_in, int B, hipStream_t s) {
     const int rl_env = rle ? (rle[0] == '0' ? 0 : 1) : -1;
     constexpr int ncu = 256;                           // MI355X: 8 XCDs x 32 CUs
     const bool rl = rl_env >= 0 ? rl_env != 0 : (a.expect > 0 ? a.expect : B) <= ncu;
-    if (rl) {
+    const char* r2e = getenv("BLSQ_CHOL_RL2");         // 0: the barrier-synchronous right-looking kernel
+    if (rl && !(r2e && r2e[0] == '0')) {
+      constexpr int R2_KL = 5;
+      const size_t lds = sizeof(double) * (4 * (size_t)a.NPAD + 1024 + 2 * (size_t)(a.NPAD / 16) * 256 +
+                                           (size_t)R2_KL * (GR_NW - 1) * 256) + sizeof(int) * (size_t)a.NPAD;
+      static std::atomic<size_t> granted[64];
+      hipError_t ge = gram_grant_lds(gram_chol_rl2_kernel<22, R2_KL>, lds, granted);
+      if (ge != hipSuccess) return ge;
+      hipLaunchKernelGGL((gram_chol_rl2_kernel<22, R2_KL>), dim3(B), dim3(GR_NT), lds, s, a);
+    } else if (rl) {
       constexpr int RL_KL = 8;                          // tile slots per worker wave kept in LDS
       const size_t lds = per + sizeof(double) * 256 * ((size_t)(a.NPAD / 16) + (size_t)RL_KL * (GR_NW - 1));
       static std::atomic<size_t> granted[64];
@@ -1761,4 +2167,9 @@ hipError_t launch_gram_gate(const GramCholArgs& a_in, int B, hipStream_t s) {
   return hipGetLastError();
 }
 
+#ifdef BLSQ_CHOL_STAMPS
+int chol_debug_stamps(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_chol_st), sizeof(g_chol_st));
+}
+#endif
 }  // namespace blsq

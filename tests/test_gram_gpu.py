@@ -802,8 +802,9 @@ def test_chunk_pairs_summed_in_the_kernel_match_the_reduction_pass(bl, monkeypat
 
 
 def test_both_cholesky_kernels_agree_bit_for_bit(bl, monkeypatch):
-    """N > 80: launches of at most 256 problems use the right-looking register kernel, larger ones the
-    left-looking one (BLSQ_CHOL_RL forces either).  Both apply the same operands in the same order —
+    """N > 80: launches of at most 256 problems use the right-looking register kernel (flag-driven schedule;
+    BLSQ_CHOL_RL2 = 0: the barrier-synchronous one), larger ones the
+    left-looking one (BLSQ_CHOL_RL forces either).  All apply the same operands in the same order —
     the right-looking kernel publishes the STORED entry times its equilibration, exactly what the
     left-looking one reads back — so which one ran (i.e. how many problems shared the launch, or were
     still active in a Newton round) never shows in the results."""
@@ -812,8 +813,9 @@ def test_both_cholesky_kernels_agree_bit_for_bit(bl, monkeypatch):
                             (4, 600, 100, "trf"), (4, 900, 120, "dogbox")]:
         P = _synth.trf_batch(70 + n, B, m, n) if kind == "trf" else _synth.dogbox_batch(70 + n, B, m, n)
         outs = []
-        for rl in ("0", "1"):
+        for rl, rl2 in (("0", "1"), ("1", "1"), ("1", "0")):       # left-looking, flag-driven, barrier-synchronous
             monkeypatch.setenv("BLSQ_CHOL_RL", rl)
+            monkeypatch.setenv("BLSQ_CHOL_RL2", rl2)
             ctx = _abi.Context(0)
             got = []
             if kind == "trf":
@@ -830,8 +832,8 @@ def test_both_cholesky_kernels_agree_bit_for_bit(bl, monkeypatch):
                     got += [S.step.copy(), S.predicted_reduction.copy()]
             sol.close(); ctx.close()
             outs.append(got)
-        for x0, x1 in zip(*outs):
-            assert np.array_equal(x0, x1)
+        for x0, x1, x2 in zip(*outs):
+            assert np.array_equal(x0, x1) and np.array_equal(x0, x2)
 
 
 def test_k_split_kernel_for_eight_column_tiles(bl, monkeypatch):
