@@ -2093,15 +2093,15 @@ hipError_t launch_gram_chol(const GramCholArgs& a_in, int B, hipStream_t s) {
                          s, a);
     }
   } else {
-    // Right-looking register variant: 0.22 ms per problem on a CU of its own against 0.27 ms for
-    // the left-looking kernel, but one workgroup per CU instead of two — so it serves the launches
-    // that cannot fill the CUs twice anyway (the Newton rounds), the left-looking one the rest.
-    // BLSQ_CHOL_RL = 0 / 1 forces either.
-    // The two kernels agree bit for bit (same operands, same order), so the choice is speed only.
-    const char* rle = getenv("BLSQ_CHOL_RL");          // (read per launch: tests compare the two)
+    // Right-looking register kernel, flag-driven: 0.12 ms per problem on a CU of its own (one workgroup per
+    // CU) against 0.27 ms for a PAIR of problems on a CU through the left-looking kernel (its Schur-complement
+    // phase waits for L2: 190 of its 275 us, tools/chol_stamps.py) — the right-looking one serves every launch
+    // (512 problems: two generations, 0.241 against 0.262 ms).  BLSQ_CHOL_RL = 0 / 1 forces either;
+    // BLSQ_CHOL_RL2 = 0 selects the barrier-synchronous right-looking kernel (<= 256 problems: 0.187 ms).
+    // All three agree bit for bit (same operands, same order), so the choice is speed only.
+    const char* rle = getenv("BLSQ_CHOL_RL");          // (read per launch: tests compare the kernels)
     const int rl_env = rle ? (rle[0] == '0' ? 0 : 1) : -1;
-    constexpr int ncu = 256;                           // MI355X: 8 XCDs x 32 CUs
-    const bool rl = rl_env >= 0 ? rl_env != 0 : (a.expect > 0 ? a.expect : B) <= ncu;
+    const bool rl = rl_env >= 0 ? rl_env != 0 : true;
     const char* r2e = getenv("BLSQ_CHOL_RL2");         // 0: the barrier-synchronous right-looking kernel
     if (rl && !(r2e && r2e[0] == '0')) {
       constexpr int R2_KL = 5;
