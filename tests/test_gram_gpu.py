@@ -917,3 +917,33 @@ def test_stage_zero_of_the_certificate_changes_no_verdict(bl, monkeypatch):
     assert np.any(k1 != k0)                                   # (stage 0 settled some problems with its own bound)
     _certificate_holds(P, k1, s1)
     _certificate_holds(P, k0, s0)
+
+
+def test_flag_driven_cholesky_is_race_free_under_repetition(bl, monkeypatch):
+    """The right-looking Cholesky kernel hands tiles between its waves through LDS flags and counters, without
+    workgroup barriers.  A missed hand-over would show as different bits: every shape (6 ... 17 tile columns, one
+    problem ... more problems than CUs, gathered sub-matrices of dogbox) is factored 25 times and must reproduce
+    the left-looking kernel's result bit for bit every time."""
+    from bounded_lsq import _synth, _abi
+    for (B, m, n, kind) in [(1, 300, 81, "trf"), (300, 300, 96, "trf"), (7, 500, 150, "trf"), (520, 260, 256, "trf"),
+                            (3, 400, 271, "trf"), (40, 400, 130, "dogbox")]:
+        P = _synth.trf_batch(170 + n, B, m, n) if kind == "trf" else _synth.dogbox_batch(170 + n, B, m, n)
+        ref = None
+        for rep, rl in enumerate(["0"] + ["1"] * 25):
+            monkeypatch.setenv("BLSQ_CHOL_RL", rl)
+            ctx = _abi.Context(0)
+            if kind == "trf":
+                sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
+                sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+                S = sol.step(np.full(B, 0.3), np.zeros(B))
+                got = (S.step.copy(), np.asarray(S.alpha).copy())
+            else:
+                sol = bl.DogboxStepSolver(B, m, n, ctx=ctx)
+                sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"], P["on_bound"])
+                S = sol.step(np.full(B, 0.3))
+                got = (S.step.copy(), S.predicted_reduction.copy())
+            sol.close(); ctx.close()
+            if ref is None:
+                ref = got
+            else:
+                assert all(np.array_equal(a, b) for a, b in zip(ref, got)), (B, m, n, kind, rep)
