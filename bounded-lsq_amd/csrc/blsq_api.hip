@@ -1526,6 +1526,8 @@ extern "C" int blsq_trf_fetch_factor(blsq_trf_plan* p, double* g, double* g_norm
 #ifdef BLSQ_CHOL_STAMPS
 namespace blsq { int chol_debug_stamps(long long* host); }
 extern "C" int blsq_debug_chol_stamps(long long* host) { return blsq::chol_debug_stamps(host); }
+namespace blsq { int gram_debug_stamps(long long* host); }
+extern "C" int blsq_debug_gram_stamps(long long* host) { return blsq::gram_debug_stamps(host); }
 #endif
 extern "C" int blsq_debug_qr_stamps(void* dbuf) {
   set_qr_debug_buffer(reinterpret_cast<double*>(dbuf));

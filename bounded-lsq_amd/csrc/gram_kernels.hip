@@ -228,6 +228,12 @@ __global__ __launch_bounds__(GR_NT, (SLOTS <= 8 ? 4 : 2)) void gram_kernel(GramA
 // chunk boundary the accumulators go to the output slot and restart from zero, at the end the first
 // chunk's tiles are read back and added — (0 + P0) + P1, exactly what gram_reduce_kernel computes
 // from two partial Grams, without writing the second one, reading both and a launch in between.
+#ifdef BLSQ_CHOL_STAMPS
+__device__ long long g_gram_st[8][130][4];             // [wave][chunk][phase] of ONE workgroup (diagnostic build)
+#define GST(c, i) do { if (stp && lane == 0 && (c) < 130) g_gram_st[W][c][i] = (long long)wall_clock64(); } while (0)
+#else
+#define GST(c, i) do { } while (0)
+#endif
 template <int W, bool RHS, bool PAIR>
 __device__ __forceinline__ void gram16_wave(const GramArgs& a, double* lds) {
   constexpr int LDX = 272, NCB = 4;
@@ -237,6 +243,7 @@ __device__ __forceinline__ void gram16_wave(const GramArgs& a, double* lds) {
   const int b = a.list ? a.list[blockIdx.y] : (int)blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63;
   const int lr = lane >> 4, lc = lane & 15;
+  const bool stp = blockIdx.y == 300 && blockIdx.x == 0; (void)stp;
   const int n = a.n, N = n + 1;
   const int r_lo = PAIR ? 0 : blockIdx.x * a.rows_per_chunk;
   int r_hi = PAIR ? a.m : r_lo + a.rows_per_chunk;
@@ -365,6 +372,7 @@ __device__ __forceinline__ void gram16_wave(const GramArgs& a, double* lds) {
     const double* X = (cidx & 1) ? X1 : X0;
     double* Xn = (cidx & 1) ? X0 : X1;
     const unsigned xb = lds_addr(X) + 8u * (unsigned)(lr * LDX + lc);
+    GST(cidx, 0);
     // fragments of the chunk's first k-step (its latency is exposed once per chunk)
     static_for<0, NF>([&](auto ic) {
       constexpr int c = decltype(ic)::value;
@@ -389,11 +397,14 @@ __device__ __forceinline__ void gram16_wave(const GramArgs& a, double* lds) {
             lds_read64_off<8 * (4 * (s + 1) * LDX + 16 * (W + 2 * t + 1))>(fr[nxt][2 * t + 1], xb);
         }
       });
+      if constexpr (s == 3) GST(cidx, 1);
       if constexpr (s == 3 || s == 7) {
         if (more) commit(row0 + GR_RC, s / 4, Xn);
       }
     });
+    GST(cidx, 2);
     __syncthreads();
+    GST(cidx, 3);
   }
 
   const bool two = PAIR && m > boundary;                // (a second chunk was accumulated)
@@ -1029,4 +1040,9 @@ hipError_t launch_gram_reduce(const double* Gpart, int chunks, int NPAD, double*
                        Gpart, chunks, NPAD, Gout, mask);
   return hipGetLastError();
 }
+#ifdef BLSQ_CHOL_STAMPS
+int gram_debug_stamps(long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gram_st), sizeof(g_gram_st));
+}
+#endif
 }  // namespace blsq
