@@ -120,6 +120,9 @@ struct GramCholArgs {
                           // rejecting it); the shifted launch works on exactly those and clears the flag
   double* cert_tau;       // [B] the shift tau of such a problem (written by gram_cond_kernel)
   int cert_shift;         // 1: THIS launch is the shifted factorisation (G = scratch; verdict -> fb_mask etc.)
+  double* cert_ym;        // optional [B] out (N > 80, right-looking factor kernel) / in (stage 0 of the certificate):
+  double* cert_r1;        //   max_j (M(R')^-T e)_j and ||R'||_1, accumulated row block by row block while the factor
+                          //   is produced (0: not computed — stage 0 then makes its own two passes for them)
   int* cert_done;         // optional [B]: 1 = the factor kernel itself proved K2 <= GRAM_K2_MAX (N <= 80: the
                           // register-resident kernel has R' at hand); launch_gram_gate then skips the problem
   // dogbox, N <= 80 (optional; g == nullptr: off): the register-resident kernel also does what

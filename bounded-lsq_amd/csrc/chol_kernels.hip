@@ -1356,9 +1356,9 @@ __device__ __forceinline__ void raise_flag(int* f, int v, int lane) {      // (a
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if (lane == 0) __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-enum { FL_DIAG = 0, FL_RINV = 1, FL_ROW1 = 2, FL_PUB = 3, FL_BAD = 4 };
+enum { FL_DIAG = 0, FL_RINV = 1, FL_ROW1 = 2, FL_PUB = 3, FL_BAD = 4, FL_YB = 5, FL_YPUB = 6 };
 
-template <int SL, int KL>
+template <int SL, int KL, bool CERT>
 __device__ __forceinline__ void chol_rl2_body(const GramCholArgs& a, const int b, double* sh, int* fl, double& pminsh) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1396,6 +1396,12 @@ __device__ __forceinline__ void chol_rl2_body(const GramCholArgs& a, const int b
   double* Rrow = Ri + 512;         // [2][NTP][256] finished tiles of a row block (operands of the trailing updates)
   double* accL = Rrow + 2 * (size_t)NTP * 256;          // [KL][7][256] the LDS-resident tile slots
   int* gl = reinterpret_cast<int*>(accL + (size_t)KL * (GR_NW - 1) * 256);   // [NPAD] gathered source indices
+  // The factor kernel's share of the certificate's stage 0 (GramCholArgs::cert_ym): the solve M(R')^T y = e and
+  // the column sums of |R'| advance row block by row block as R' is produced — stage 0 then needs ONE pass over
+  // the factor (the backward solve, with the row sums on the way) instead of four.  Fixed order: reproducible.
+  double* yv = reinterpret_cast<double*>(gl + NPAD);     // [NPAD] y (final for the finished row blocks)
+  double* csum = yv + NPAD;                              // [NPAD] sum_i |R'_ij| over the finished row blocks
+  constexpr bool cert = CERT;                            // (a launch with cert_ym set, never the shifted one)
   const double* csv = a.colscale ? a.colscale + (long)b * a.stride_vec : nullptr;
   const double* edv = a.diag_vec ? a.diag_vec + (long)b * a.stride_vec : nullptr;
   const double sa = a.diag_sqrt ? a.diag_sqrt[b] : 0.0;
@@ -1454,6 +1460,7 @@ __device__ __forceinline__ void chol_rl2_body(const GramCholArgs& a, const int b
     }
     dl[j] = d; sq[j] = s_; sc[j] = cs * d; td[j] = add * d * d - ((j < n) ? tau : 0.0);
     if (a.dsc) a.dsc[(long)b * NPAD + j] = d;
+    if (cert) { yv[j] = 1.0; csum[j] = 0.0; }
   }
   if (__any(bad) && lane == 0) __hip_atomic_store(&fl[FL_BAD], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   CST(stp && (w == 0 || w == 2), w == 0 ? 2 : 3, 17, 1);
@@ -1615,6 +1622,30 @@ __device__ __forceinline__ void chol_rl2_body(const GramCholArgs& a, const int b
         raise_flag(&fl[FL_DIAG], kb + 1, lane);
         CST(stp, 1, kb, 3);
       }
+      if (cert && (q0 - ww) % NWK == 0) {
+        // this wave owns the diagonal tile: y of the block by forward substitution with |R'_kk| — once every worker
+        // has added its share of the row block before (FL_YPUB) — and the tile's column sums
+        spin_ge(&fl[FL_YPUB], NWK * kb);
+        const int i_ = lane & 15, gi = 16 * kb + i_;
+        double Dc[16], cs_ = 0.0;
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) {
+          const double v_ = fabs(DtC[s_ * 16 + i_]);
+          Dc[s_] = s_ < i_ ? v_ : 0.0;
+          if (s_ <= i_) cs_ += v_;
+        }
+        const double dg_ = DtC[i_ * 16 + i_];
+        const bool live_ = gi < n && dg_ > 0.0;
+        const double iv_ = live_ ? 1.0 / dg_ : 0.0;
+        double r_ = live_ ? yv[gi] : 0.0;
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) {
+          const double ys_ = read_lane(r_ * iv_, s_);
+          if (i_ > s_) r_ = fma(Dc[s_], ys_, r_);
+        }
+        if (lane < 16 && gi < n) { yv[gi] = r_ * iv_; csum[gi] += cs_; }
+        raise_flag(&fl[FL_YB], kb + 1, lane);
+      }
       CST(stp && w == 2, 3, kb, 1);
       // 3. the other tiles of the row block
 #pragma unroll
@@ -1623,6 +1654,27 @@ __device__ __forceinline__ void chol_rl2_body(const GramCholArgs& a, const int b
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_fetch_add(&fl[FL_PUB], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (cert) {                                       // (behind the counter: nobody's trailing update waits for this)
+        // y_j += sum_s |R'_{kb,j}[s][.]| y_s and the column sums, for this wave's tiles of the row block (from the
+        // row buffer; lane (lr, lc) holds rows lr + 4 g of column lc, the four lane rows are added in a fixed tree)
+        if (kb + 1 < NT) spin_ge(&fl[FL_YB], kb + 1);
+        for (int t = t_lo; t <= t_hi && kb + 1 < NT; ++t) {
+          const int j = kb + (ww + NWK * t - q0);
+          if (j == kb) continue;
+          double p_ = 0.0, q_ = 0.0;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const double a_ = fabs(RrowC[j * 256 + (lr + 4 * g) * 16 + lc]);
+            p_ = fma(a_, yv[16 * kb + lr + 4 * g], p_);
+            q_ += a_;
+          }
+          p_ += __shfl_xor(p_, 16, WAVE); q_ += __shfl_xor(q_, 16, WAVE);
+          p_ += __shfl_xor(p_, 32, WAVE); q_ += __shfl_xor(q_, 32, WAVE);
+          if (lr == 0 && 16 * j + lc < n) { yv[16 * j + lc] += p_; csum[16 * j + lc] += q_; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(&fl[FL_YPUB], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
       CST(stp && w == 2, 3, kb, 2);
       if (kb + 1 >= NT) break;
       spin_ge(&fl[FL_PUB], NWK * (kb + 1));             // every worker's tiles of the row block are in RrowC
@@ -1649,6 +1701,19 @@ __device__ __forceinline__ void chol_rl2_body(const GramCholArgs& a, const int b
   CST(stp && (w == 0 || w == 2), w == 0 ? 2 : 3, 18, 0);
   __syncthreads();
   CST(stp && (w == 0 || w == 2), w == 0 ? 2 : 3, 18, 1);
+  if (cert && w == 0) {
+    double ym_ = 0.0, r1_ = 0.0;
+    for (int j = lane; j < n; j += WAVE) {
+      ym_ = yv[j] > ym_ ? yv[j] : ym_;
+      r1_ = csum[j] > r1_ ? csum[j] : r1_;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double oy = __shfl_xor(ym_, o, WAVE), orr = __shfl_xor(r1_, o, WAVE);
+      ym_ = oy > ym_ ? oy : ym_; r1_ = orr > r1_ ? orr : r1_;
+    }
+    if (lane == 0) { a.cert_ym[b] = ym_; a.cert_r1[b] = r1_; }
+  }
   if (tid == 0 && a.fb_mask) {
     const bool fail = !(pminsh >= (a.pivot_floor > 0.0 ? a.pivot_floor : 1.0 / GRAM_K2_MAX));
     a.fb_mask[b] = fail ? a.n + 1 : 0;
@@ -1662,7 +1727,7 @@ __device__ __forceinline__ void chol_rl2_body(const GramCholArgs& a, const int b
   }
 }
 
-template <int SL, int KL>
+template <int SL, int KL, bool CERT>
 __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl2_kernel(GramCholArgs a) {
   extern __shared__ double sh[];
   __shared__ double pminsh;
@@ -1670,7 +1735,7 @@ __global__ __launch_bounds__(GR_NT, 2) void gram_chol_rl2_kernel(GramCholArgs a)
   const int pidx = (int)blockIdx.x;
   if (a.count_dev && pidx >= *a.count_dev) return;
   const int b = a.batch_list ? a.batch_list[pidx] : pidx;
-  chol_rl2_body<SL, KL>(a, b, sh, fl, pminsh);
+  chol_rl2_body<SL, KL, CERT>(a, b, sh, fl, pminsh);
 }
 
 // ---- certificate, stage 0: the comparison-matrix bound (two triangular solves instead of an inverse) ----
@@ -1697,9 +1762,82 @@ __global__ __launch_bounds__(TRI_NT) void gram_cert0_kernel(GramCholArgs a) {
   double* invd = y + NPAD;               // [NPAD]
   double* dl = invd + NPAD;              // [NPAD]
   double* pfbuf = dl + NPAD;             // [2 * 16 * NPAD] DMA staging of the solves
-  double* rowsR = pfbuf;                 // [NPAD] row sums (before the solves: two workgroups per CU need <= 80 KB each)
+  double* rowsR = pfbuf;                 // [NPAD] row sums (after the solves: two workgroups per CU need <= 80 KB each)
+  double* rowsB = pfbuf + 32 * NPAD;     // [NPAD] row sums gathered DURING the backward solve
   for (int j = tid; j < NPAD; j += TRI_NT) dl[j] = a.dsc[(long)b * NPAD + j];
   __syncthreads();
+  if (a.cert_ym && a.cert_ym[b] > 0.0) {
+    // The factor kernel has done the transposed solve and the column sums on its way (GramCholArgs::cert_ym):
+    // what is left is ONE pass over the factor — the backward solve M(T) x = e by column panels, each thread adding
+    // the panel's share of its row's |T_ij| / ||J_j|| sum while the panel is in LDS.
+    const double ym = a.cert_ym[b], r1 = a.cert_r1[b];
+    tri_invdiag(T, n, NPAD, invd);
+    for (int i = tid; i < NPAD; i += TRI_NT) { x[i] = 1.0; rowsB[i] = 0.0; }
+    __syncthreads();
+    {
+      const int nblk = (n + 15) / 16;
+      const int bsz = 16 * NPAD;
+      int cur = 0;
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      tri_pf_issue_upper<TRI_NT>(T, NPAD, (nblk - 1) * 16, pfbuf);
+      for (int kb = nblk - 1; kb >= 0; --kb) {
+        const int c0 = kb * 16;
+        const int bs = (n - c0 < 16) ? n - c0 : 16;
+        const double* bq = pfbuf + cur * bsz;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();                                   // every wave's pieces have landed
+        if (kb > 0) tri_pf_issue_upper<TRI_NT>(T, NPAD, c0 - 16, pfbuf + (cur ^ 1) * bsz);
+        if (tid < 64) {                                  // wave 0 (lanes >= 16 are idle copies)
+          const int i = tid & 15;
+          double D[16], rs = 0.0;
+#pragma unroll
+          for (int s_ = 0; s_ < 16; ++s_) {
+            const double av = fabs(bq[(c0 + i) * 16 + s_]);
+            D[s_] = (i < bs && s_ < bs && s_ > i) ? -av : 0.0;
+            if (i < bs && s_ < bs && s_ >= i) rs = fma(av, dl[c0 + s_], rs);
+          }
+          double r = (i < bs) ? x[c0 + i] : 0.0;
+          const double iv = (i < bs) ? invd[c0 + i] : 0.0;
+#pragma unroll
+          for (int s_ = 15; s_ >= 0; --s_) {
+            const double xs = read_lane(r * iv, s_);
+            if (i < s_) r = fma(-D[s_], xs, r);
+          }
+          if (tid < bs) { x[c0 + tid] = r * iv; rowsB[c0 + tid] += rs; }
+        }
+        lds_barrier();
+        for (int i = tid; i < c0; i += TRI_NT) {         // rows above the block
+          const double* row = bq + i * 16;
+          double acc = 0.0, rs = 0.0;
+#pragma unroll
+          for (int s_ = 0; s_ < 16; ++s_) {
+            const double av = fabs(row[s_]);
+            acc = fma(-av, (s_ < bs) ? x[c0 + s_] : 0.0, acc);
+            if (s_ < bs) rs = fma(av, dl[c0 + s_], rs);
+          }
+          x[i] -= acc;
+          rowsB[i] += rs;
+        }
+        lds_barrier();
+        cur ^= 1;
+      }
+    }
+    double zm = 0.0, rinf = 0.0;
+    for (int i = tid; i < n; i += TRI_NT) { zm = nanmax2(zm, x[i] / dl[i]); rinf = fmax(rinf, rowsB[i]); }
+    zm = block_max(zm, red);
+    rinf = block_max(rinf, red);
+    const double kmax = a.k2_max > 0.0 ? a.k2_max : GRAM_K2_MAX;
+    const double k2 = (r1 * rinf) * (zm * ym) * (1.0 + 1.0e-9);
+    const bool passed = k2 <= kmax;                     // (NaN / inf fail)
+    if (tid == 0) {
+      a.cert_done[b] = passed ? 1 : 0;
+      if (passed) {
+        if (a.k2_out) a.k2_out[b] = k2;
+        if (a.lam_out) a.lam_out[b] = fmin(r1 * rinf, (double)n);
+      }
+    }
+    return;
+  }
   // the two comparison solves FIRST: ||R'||_1 ||R'||_inf >= lambda_max(C) >= 1, so a product of the two maxima
   // beyond the gate already decides "not settled here" and the norm passes are skipped
   tri_invdiag(T, n, NPAD, invd);
@@ -2103,14 +2241,27 @@ hipError_t launch_gram_chol(const GramCholArgs& a_in, int B, hipStream_t s) {
     const int rl_env = rle ? (rle[0] == '0' ? 0 : 1) : -1;
     const bool rl = rl_env >= 0 ? rl_env != 0 : true;
     const char* r2e = getenv("BLSQ_CHOL_RL2");         // 0: the barrier-synchronous right-looking kernel
-    if (rl && !(r2e && r2e[0] == '0')) {
+    const bool rl2 = rl && !(r2e && r2e[0] == '0');
+    if (a.cert_ym && !rl2) {                            // (only the flag-driven kernel has a share in stage 0)
+      hipError_t me = hipMemsetAsync(a.cert_ym, 0, sizeof(double) * (size_t)B, s);
+      if (me != hipSuccess) return me;
+    }
+    if (rl2) {
       constexpr int R2_KL = 5;
       const size_t lds = sizeof(double) * (4 * (size_t)a.NPAD + 1024 + 2 * (size_t)(a.NPAD / 16) * 256 +
-                                           (size_t)R2_KL * (GR_NW - 1) * 256) + sizeof(int) * (size_t)a.NPAD;
-      static std::atomic<size_t> granted[64];
-      hipError_t ge = gram_grant_lds(gram_chol_rl2_kernel<22, R2_KL>, lds, granted);
-      if (ge != hipSuccess) return ge;
-      hipLaunchKernelGGL((gram_chol_rl2_kernel<22, R2_KL>), dim3(B), dim3(GR_NT), lds, s, a);
+                                           (size_t)R2_KL * (GR_NW - 1) * 256 + 2 * (size_t)a.NPAD) +
+                         sizeof(int) * (size_t)a.NPAD;
+      if (a.cert_ym && !a.cert_shift) {
+        static std::atomic<size_t> granted[64];
+        hipError_t ge = gram_grant_lds(gram_chol_rl2_kernel<22, R2_KL, true>, lds, granted);
+        if (ge != hipSuccess) return ge;
+        hipLaunchKernelGGL((gram_chol_rl2_kernel<22, R2_KL, true>), dim3(B), dim3(GR_NT), lds, s, a);
+      } else {
+        static std::atomic<size_t> granted[64];
+        hipError_t ge = gram_grant_lds(gram_chol_rl2_kernel<22, R2_KL, false>, lds, granted);
+        if (ge != hipSuccess) return ge;
+        hipLaunchKernelGGL((gram_chol_rl2_kernel<22, R2_KL, false>), dim3(B), dim3(GR_NT), lds, s, a);
+      }
     } else if (rl) {
       constexpr int RL_KL = 8;                          // tile slots per worker wave kept in LDS
       const size_t lds = per + sizeof(double) * 256 * ((size_t)(a.NPAD / 16) + (size_t)RL_KL * (GR_NW - 1));
@@ -2147,7 +2298,7 @@ hipError_t launch_gram_gate(const GramCholArgs& a_in, int B, hipStream_t s) {
   if (a.NPAD > 80 && a.cert_done && a.dsc) {
     const char* ce = getenv("BLSQ_CERT0");
     if (!(ce && ce[0] == '0')) {
-      const size_t lds0 = sizeof(double) * (4 + 32) * (size_t)a.NPAD;
+      const size_t lds0 = sizeof(double) * (4 + 32 + 1) * (size_t)a.NPAD;
       static std::atomic<size_t> granted[64];
       hipError_t ge = gram_grant_lds(gram_cert0_kernel, lds0, granted);
       if (ge != hipSuccess) return ge;
