@@ -682,6 +682,7 @@ def main():
                     "host_to_device_GBps": 8.0 * B * m * (n + 1) * kh / ep / 1e9}
             except Exception as exc:                           # noqa: BLE001
                 extras["h2d_inclusive"]["pinned"] = {"error": str(exc)[:200]}
+        def front_end_leg():
             try:
                 # per-iteration cost of the drop-in front end on ONE 4096 x 256 problem with host callbacks
                 # (least_squares.py:351-371: fun and jac return numpy arrays every iteration)
@@ -727,6 +728,10 @@ def main():
                     side_hung = True
                     break
             extras["side_configs"] = side
+        # (last: its numpy callbacks wake the BLAS thread pool, whose workers then spin for tens of milliseconds on
+        #  the box's CPU share — measured: a latency-bound side leg that follows at once, c2-single, ran at HALF speed)
+        if not args.no_h2d and not side_hung:
+            front_end_leg()
     if world > 1 and main_line and not args.no_side:
         # the tall problem of config 5 over ALL ranks (250 000 rows each): the library's own RCCL
         # communicator, Gram all-reduce inside blsq_tsqr_factor_dev.  A side figure: guarded, timed out.
