@@ -278,8 +278,18 @@ class Context:
         return float(out[0]), float(out[1]), float(out[2])
 
     # ---- timing ------------------------------------------------------------
-    def timing(self, on=True):
-        self.check(self.lib.blsq_timing_enable(self.h, 1 if on else 0), "timing_enable")
+    def timing(self, on=True, only=None):
+        """Per-kernel HIP-event timing: every slot, or (only = slot name) the launches of one slot — two events
+        around EVERY launch cost the step about 2 %."""
+        mode = 1 if on else 0
+        if on and only is not None:
+            names = []
+            for i in range(self.lib.blsq_timing_count(self.h)):
+                name = C.c_char_p(); ms = C.c_double(); cnt = C.c_int64()
+                self.check(self.lib.blsq_timing_get(self.h, i, C.byref(name), C.byref(ms), C.byref(cnt)), "timing_get")
+                names.append(name.value.decode())
+            mode = 2 + names.index(only)
+        self.check(self.lib.blsq_timing_enable(self.h, mode), "timing_enable")
 
     def timing_reset(self):
         self.check(self.lib.blsq_timing_reset(self.h), "timing_reset")

@@ -64,7 +64,8 @@ int blsq_host_alloc(blsq_ctx* ctx, size_t bytes, void** hptr);
 int blsq_host_free(blsq_ctx* ctx, void* hptr);
 int blsq_memcpy_d2h(blsq_ctx* ctx, void* dst, const void* src, size_t bytes);
 
-/* per-kernel device timing (HIP events on the ctx stream, for bench.py) */
+/* per-kernel device timing (HIP events on the ctx stream, for bench.py).  on: 0 off; 1 every kernel slot (two events
+ * around every launch: they cost the step they measure about 2 %); 2 + s: slot s only (its index in blsq_timing_get) */
 int blsq_timing_enable(blsq_ctx* ctx, int on);
 int blsq_timing_reset(blsq_ctx* ctx);
 int blsq_timing_count(const blsq_ctx* ctx);                    /* number of kernel slots */
