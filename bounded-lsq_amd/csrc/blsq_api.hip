@@ -591,6 +591,7 @@ struct blsq_trf_plan {
   DevBuf aug_mask;                  // [B] launch mask of the stacked QR of [R D; E] (trf_aug_trivial_kernel)
   DevBuf aug_lam;                   // [B] proven bound on lambda_max of the equilibrated H (LmState::lam)
   DevBuf aug_ym, aug_r1;            // [B] the factor kernel's share of the certificate's stage 0 (GramCholArgs::cert_ym)
+  DevBuf aug_open;                  // [B] stage 0's note for the problems it leaves open (GramCholArgs::cert_open)
   DevBuf aug_hmax;                  // [B] largest diagonal entry of H (LmState::hmax: which Newton systems of a
                                     // Householder-path problem may be factored from the Gram)
   bool gram_valid = false;          // tree.gram_keep holds the Grams of the current factor call's problems
@@ -933,11 +934,13 @@ int trf_alloc_state(blsq_trf_plan* p) {
   ALLOC(p->aug_lam, sizeof(double) * (size_t)B);
   ALLOC(p->aug_ym, sizeof(double) * (size_t)B);
   ALLOC(p->aug_r1, sizeof(double) * (size_t)B);
+  ALLOC(p->aug_open, sizeof(double) * (size_t)B);
   ALLOC(p->aug_mask, sizeof(int) * (size_t)B);
   ALLOC(p->lm_sc, sizeof(double) * (size_t)B * 16);
   ALLOC(p->lm_ph, sizeof(double) * vs);
   HIPCHK(ctx, hipMemsetAsync(p->lm_sa.p, 0, p->lm_sa.bytes, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(p->aug_ym.p, 0, p->aug_ym.bytes, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(p->aug_open.p, 0, p->aug_open.bytes, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(p->lm_Xa.p, 0, p->lm_Xa.bytes, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(p->lm_ints.p, 0, p->lm_ints.bytes, ctx->stream));
   {
@@ -1060,7 +1063,11 @@ GramCholArgs trf_chol_args(blsq_trf_plan* p, const int* mask) {
   c.cert_flag = t.gram_cflag.as<int>(); c.cert_tau = t.gram_ctau.as<double>();
   c.colinfo = p->aug_colinfo.as<double>();
   c.hmax = p->aug_hmax.as<double>(); c.lam_out = p->aug_lam.as<double>();
-  if (p->ld > 80) { c.cert_ym = p->aug_ym.as<double>(); c.cert_r1 = p->aug_r1.as<double>(); }
+  if (p->ld > 80) {
+    c.cert_ym = p->aug_ym.as<double>(); c.cert_r1 = p->aug_r1.as<double>();
+    const char* oe = getenv("BLSQ_CERT_DIRECT");          // 0: every open problem through the norm stage (explicit inverse)
+    c.cert_open = (oe && oe[0] == '0') ? nullptr : p->aug_open.as<double>();
+  }
   if (p->ld <= 80) {                        // (the register-resident kernel also does the rank gate's sure case)
     c.lmfin.fast = p->lm.fast; c.lmfin.ncols_jac = p->lm.ncols_jac; c.lmfin.sc = p->lm.sc; c.lmfin.st = p->lm.st;
     c.unsettled = t.fb_count() + 2;
@@ -1446,7 +1453,7 @@ extern "C" int blsq_trf_plan_destroy(blsq_trf_plan* p) {
   p->o_info.release(); p->in_J.release(); p->in_f.release(); p->in_vec.release();
   p->in_scal.release();
   p->lm_sa.release(); p->lm_Xa.release(); p->lm_ints.release(); p->lm_sc.release();
-  p->lm_ph.release(); p->aug_colinfo.release(); p->aug_hmax.release(); p->aug_lam.release(); p->aug_ym.release(); p->aug_r1.release(); p->aug_mask.release();
+  p->lm_ph.release(); p->aug_colinfo.release(); p->aug_hmax.release(); p->aug_lam.release(); p->aug_ym.release(); p->aug_r1.release(); p->aug_open.release(); p->aug_mask.release();
   delete p;
   return 0;
 }

@@ -123,6 +123,10 @@ struct GramCholArgs {
   double* cert_ym;        // optional [B] out (N > 80, right-looking factor kernel) / in (stage 0 of the certificate):
   double* cert_r1;        //   max_j (M(R')^-T e)_j and ||R'||_1, accumulated row block by row block while the factor
                           //   is produced (0: not computed — stage 0 then makes its own two passes for them)
+  double* cert_open;      // optional [B] (N > 80): what stage 0 leaves for a problem it cannot settle — > 0: Lambda_0 =
+                          //   min(||R'||_1 ||R'||_inf, n) >= lambda_max(C): the problem skips the explicit inverse of the norm
+                          //   stage and goes to the third stage directly; < 0: hopeless (1 / min r'_jj^2 > k2_max): rejected;
+                          //   0: nothing (settled, or stage 0 in its four-pass form)
   int* cert_done;         // optional [B]: 1 = the factor kernel itself proved K2 <= GRAM_K2_MAX (N <= 80: the
                           // register-resident kernel has R' at hand); launch_gram_gate then skips the problem
   // dogbox, N <= 80 (optional; g == nullptr: off): the register-resident kernel also does what

@@ -1829,15 +1829,44 @@ __global__ __launch_bounds__(TRI_NT) void gram_cert0_kernel(GramCholArgs a) {
     const double kmax = a.k2_max > 0.0 ? a.k2_max : GRAM_K2_MAX;
     const double k2 = (r1 * rinf) * (zm * ym) * (1.0 + 1.0e-9);
     const bool passed = k2 <= kmax;                     // (NaN / inf fail)
+    // for a problem left open: Lambda_0 for the third stage, or "hopeless" — lambda_min(C) <= min_j r'_jj^2 and
+    // lambda_max(C) >= 1, so kappa_2(C) >= 1 / min_j r'_jj^2 (r'_jj = T_jj / ||J_j||: 1 / (invd_j / dl_j))
+    double pinv = 0.0, emax = 0.0;
+    if (a.cert_open && !passed) {
+      const double* edv = a.diag_vec ? a.diag_vec + (long)b * a.stride_vec : nullptr;
+      for (int i = tid; i < n; i += TRI_NT) {
+        const double t = invd[i] / dl[i];
+        pinv = nanmax2(pinv, t * t);
+        if (edv) emax = nanmax2(emax, fabs(edv[i]));
+      }
+      pinv = block_max(pinv, red);
+      emax = block_max(emax, red);
+    }
     if (tid == 0) {
       a.cert_done[b] = passed ? 1 : 0;
       if (passed) {
         if (a.k2_out) a.k2_out[b] = k2;
         if (a.lam_out) a.lam_out[b] = fmin(r1 * rinf, (double)n);
       }
+      if (a.cert_open) {
+        const double lam0 = fmin(r1 * rinf, (double)n);
+        // kappa_2 >= pinv: beyond the gate the problem is hopeless.  Otherwise the note depends on what the system IS:
+        // with a Coleman-Li block (E != 0: a variable near a bound in its descent direction) the comparison-matrix
+        // bound fails long before the system is ill conditioned, and the norm stage settles such a problem more cheaply
+        // than a factorisation (bench, bounded mix: certificate 0.26 against 0.36 ms); a pure Jacobian system (E = 0)
+        // that fails it is usually near or beyond the gate, where the norm stage — 3.5 ... 13 of overestimate — cannot
+        // decide and the third stage is where the problem ends up anyway (unbounded mix: 0.84 -> 0.56 ms).
+        double note = 0.0;
+        if (!passed && is_finite(lam0) && lam0 >= 1.0) {
+          if (!(pinv <= kmax)) note = -1.0;
+          else if (emax == 0.0) note = lam0;
+        }
+        a.cert_open[b] = note;
+      }
     }
     return;
   }
+  if (a.cert_open && tid == 0) a.cert_open[b] = 0.0;    // (four-pass form: the norm stage below keeps its own counsel)
   // the two comparison solves FIRST: ||R'||_1 ||R'||_inf >= lambda_max(C) >= 1, so a product of the two maxima
   // beyond the gate already decides "not settled here" and the norm passes are skipped
   tri_invdiag(T, n, NPAD, invd);
@@ -1968,6 +1997,73 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_cond_kernel(GramCholArgs a) {
     for (int q = 1; q < NWP; ++q) t = fmax(t, vals[q]);
     return t;
   };
+  // Stage 0 has been here (N > 80, GramCholArgs::cert_open): it could not settle the problem, but it left
+  // Lambda_0 = min(||R'||_1 ||R'||_inf, n) >= lambda_max(C) — or the verdict "hopeless" from the smallest pivot.  The
+  // explicit inverse below would only produce looser bounds than the shifted factorisation of the third stage proves
+  // anyway: the problem goes there directly, with tau from Lambda = min(Lambda_0, ||C||_F) (one pass over the Gram).
+  if constexpr (NWP == 8) {
+    const double open0 = a.cert_open ? a.cert_open[b] : 0.0;
+    if (open0 != 0.0) {
+      const double kmax = a.k2_max > 0.0 ? a.k2_max : GRAM_K2_MAX;
+      double lam = open0;
+      if (open0 > 0.0 && a.cert_flag) {
+        const int* gidx = a.gather ? a.gather + (long)b * a.stride_vec : nullptr;
+        auto src = [&](int i) -> int { return gidx ? (i < n ? gidx[i] : a.n) : i; };
+        const double* Gs = a.Gsrc + (long)b * NPAD * NPAD;
+        const double* csv = a.colscale ? a.colscale + (long)b * a.stride_vec : nullptr;
+        const double* edv = a.diag_vec ? a.diag_vec + (long)b * a.stride_vec : nullptr;
+        double* scl = cs4;                  // [NPAD] cs_j dl_j
+        double* tdl = cs4 + NPAD;           // [NPAD] e_j^2 dl_j^2
+        for (int j = tid; j < NPAD; j += PT) {
+          const double cs = (csv && j < n) ? csv[j] : 1.0;
+          const double ej = (edv && j < n) ? edv[j] : 0.0;
+          scl[j] = cs * dl[j];
+          tdl[j] = (ej * ej) * dl[j] * dl[j];
+        }
+        psync();
+        double cf = 0.0;                    // this wave's share of ||C||_F^2 (fixed order)
+        int q = 0;
+        for (int j = 0; j < NTn; ++j) {
+          for (int i = 0; i <= j; ++i, ++q) {
+            if (q % NWP != w) continue;     // (wave-uniform)
+            double c2 = 0.0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int row = 16 * i + lr + 4 * g, col = 16 * j + lc;
+              double v = 0.0;
+              if (row < n && col < n) {
+                int sr_ = src(row), sc_ = src(col);
+                if (sr_ > sc_) { const int t_ = sr_; sr_ = sc_; sc_ = t_; }
+                v = Gs[(long)sr_ * NPAD + sc_] * scl[row] * scl[col];
+                if (row == col) v += tdl[row];
+              }
+              c2 = fma(v, v, c2);
+            }
+            cf = fma((i == j) ? 1.0 : 2.0, wave_sum(c2), cf);
+          }
+        }
+        psync();
+        if (lane == 0) vals[w] = cf;
+        psync();
+        cf = 0.0;
+        for (int qq = 0; qq < NWP; ++qq) cf += vals[qq];
+        lam = fmin(lam, sqrt(cf));                        // lambda_max(C) <= ||C||_F
+      }
+      if (tid == 0) {
+        if (a.k2_out) a.k2_out[b] = __builtin_inf();     // (no proven bound from here; the third stage writes k2_max)
+        if (open0 > 0.0 && a.cert_flag && lam >= 1.0 && is_finite(lam)) {
+          if (a.lam_out) a.lam_out[b] = lam;
+          a.cert_tau[b] = lam / kmax;
+          a.cert_flag[b] = 1;
+        } else {
+          a.fb_mask[b] = a.n + 1;
+          if (a.path_out) a.path_out[b] = a.n + 1;
+          { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
+        }
+      }
+      return;
+    }
+  }
   // ---- ||R'||_1 (thread per column) and ||R'||_inf (wave per row) ----
   double r1 = 0.0;
   for (int j = tid; j < n; j += PT) {
@@ -2306,7 +2402,10 @@ hipError_t launch_gram_gate(const GramCholArgs& a_in, int B, hipStream_t s) {
     } else {
       hipError_t me = hipMemsetAsync(a.cert_done, 0, sizeof(int) * (size_t)B, s);
       if (me != hipSuccess) return me;
+      a.cert_open = nullptr;                            // (no stage 0: nothing for the norm stage to go by)
     }
+  } else {
+    a.cert_open = nullptr;
   }
   const size_t per1 = sizeof(double) * (6 * (size_t)a.NPAD + 16 * 1 + 64);
   const size_t per8 = sizeof(double) * (6 * (size_t)a.NPAD + 16 * 8 + 64);

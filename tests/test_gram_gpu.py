@@ -947,3 +947,39 @@ def test_flag_driven_cholesky_is_race_free_under_repetition(bl, monkeypatch):
                 ref = got
             else:
                 assert all(np.array_equal(a, b) for a, b in zip(ref, got)), (B, m, n, kind, rep)
+
+
+def test_open_jacobian_systems_go_to_the_third_stage_directly(bl, monkeypatch):
+    """A problem stage 0 cannot settle whose system is J^T J itself (no Coleman-Li block) skips the explicit inverse
+    of the norm stage and is decided by the shifted factorisation (GramCholArgs::cert_open; BLSQ_CERT_DIRECT = 0:
+    everybody through the norm stage).  Both routes PROVE what they decide, so paths and steps agree wherever both
+    settle a problem the same way — here: true kappa_2 well inside / well beyond the gate — and every reported bound
+    is one; a hopeless problem (a pivot beyond the gate) is rejected without any further stage."""
+    from bounded_lsq import _synth, _abi
+    B, m, n = 10, 1500, 130
+    P = _synth.trf_batch(141, B, m, n, unbounded=True)
+    rng = np.random.default_rng(5)
+    kap = [1.0, 30.0, 100.0, 200.0, 3e3, 1e5, 1e7, 150.0, 60.0, 2e4]      # kappa(J): gate near 480
+    for b in range(B):
+        U, _ = np.linalg.qr(rng.standard_normal((m, n)))
+        V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        P["J"][b] = (U * np.logspace(0, -np.log10(kap[b]), n)) @ V.T * np.sqrt(m)
+    P["J"][6][:, 7] = P["J"][6][:, 3] * (1 + 1e-9)                          # two columns nearly equal: a tiny pivot
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("BLSQ_CERT_DIRECT", flag)
+        ctx = _abi.Context(0)
+        sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
+        ctx.gram_stats(reset=True)
+        sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+        stats = ctx.gram_stats()
+        k2 = sol.debug_cond().copy()
+        S = sol.step(np.full(B, 0.7), np.zeros(B))
+        outs.append((stats, k2, S.step.copy()))
+        sol.close(); ctx.close()
+    (s1, k1, st1), (s0, k0, st0) = outs
+    assert s1 == s0 and s1[0] >= 5 and s1[1] >= 3, (s1, s0)               # the same paths either way
+    for b in range(B):
+        assert np.linalg.norm(st1[b] - st0[b]) <= 1e-10 * np.linalg.norm(st0[b])
+    _certificate_holds(P, k1, s1)
+    _certificate_holds(P, k0, s0)
