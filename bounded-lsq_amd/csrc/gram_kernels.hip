@@ -978,7 +978,13 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s, d
     const long wgs = (long)chunks * B;
     // (only when the row chunks alone leave most CUs idle: every group re-reads the rows)
     tg = tenv > 0 ? tenv : (wgs <= 64 ? (int)((256 + wgs - 1) / wgs) : 1);
-    if (tg > 8) tg = 8;
+    // (Every group re-reads the rows: 8 groups at most — but a launch of a handful of workgroups is bound by the
+    //  MFMAs of its few CUs: ONE problem of 4096 x 256 took 0.27 ms in 16 workgroups of four tile slots per wave,
+    //  0.17 ms in 64 of one slot.  A tile sees the same k-steps in the same order whatever the split: same bits.
+    //  Measured and not kept: both halves of the next rows requested a whole chunk ahead — slower, the loads are
+    //  not what such a launch waits for.)
+    const int tcap = (tenv > 0 || wgs <= 4) ? 32 : 8;
+    if (tg > tcap) tg = tcap;
     if (tg > ntile) tg = ntile;
     if (tg < 1) tg = 1;
   }
@@ -1009,7 +1015,15 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s, d
     }
   }
   const int per = (((ntile + tg - 1) / tg) + GR_NW - 1) / GR_NW;   // tile slots a wave needs
-  if (per <= 4) {                                       // n <= 111, or tile groups
+  if (per <= 1 && tg > 8) {                             // (many tile groups of a tiny launch: one tile per wave)
+    if (ncb <= 1) BLSQ_GRAM_LAUNCH(1, 1);
+    else if (ncb <= 2) BLSQ_GRAM_LAUNCH(1, 2);
+    else BLSQ_GRAM_LAUNCH(1, 5);
+  } else if (per <= 2 && tg > 8) {
+    if (ncb <= 1) BLSQ_GRAM_LAUNCH(2, 1);
+    else if (ncb <= 2) BLSQ_GRAM_LAUNCH(2, 2);
+    else BLSQ_GRAM_LAUNCH(2, 5);
+  } else if (per <= 4) {                                // n <= 111, or tile groups
     if (ncb <= 1) BLSQ_GRAM_LAUNCH(4, 1);
     else if (ncb <= 2) BLSQ_GRAM_LAUNCH(4, 2);
     else BLSQ_GRAM_LAUNCH(4, 5);
