@@ -1766,14 +1766,18 @@ __global__ __launch_bounds__(TRI_NT) void gram_cert0_kernel(GramCholArgs a) {
   double* rowsB = pfbuf + 32 * NPAD;     // [NPAD] row sums gathered DURING the backward solve
   for (int j = tid; j < NPAD; j += TRI_NT) dl[j] = a.dsc[(long)b * NPAD + j];
   __syncthreads();
+  const bool stp = b == 0; (void)stp;
+  CST(stp && w == 0, 0, 18, 0);
   if (a.cert_ym && a.cert_ym[b] > 0.0) {
     // The factor kernel has done the transposed solve and the column sums on its way (GramCholArgs::cert_ym):
     // what is left is ONE pass over the factor — the backward solve M(T) x = e by column panels, each thread adding
     // the panel's share of its row's |T_ij| / ||J_j|| sum while the panel is in LDS.
     const double ym = a.cert_ym[b], r1 = a.cert_r1[b];
+    CST(stp && w == 0, 0, 18, 1);
     tri_invdiag(T, n, NPAD, invd);
     for (int i = tid; i < NPAD; i += TRI_NT) { x[i] = 1.0; rowsB[i] = 0.0; }
     __syncthreads();
+    CST(stp && w == 0, 0, 18, 2);
     {
       const int nblk = (n + 15) / 16;
       const int bsz = 16 * NPAD;
@@ -1820,8 +1824,10 @@ __global__ __launch_bounds__(TRI_NT) void gram_cert0_kernel(GramCholArgs a) {
         }
         lds_barrier();
         cur ^= 1;
+        CST(stp && w == 0, 1, kb, 0);
       }
     }
+    CST(stp && w == 0, 0, 18, 3);
     double zm = 0.0, rinf = 0.0;
     for (int i = tid; i < n; i += TRI_NT) { zm = nanmax2(zm, x[i] / dl[i]); rinf = fmax(rinf, rowsB[i]); }
     zm = block_max(zm, red);
@@ -1848,6 +1854,7 @@ __global__ __launch_bounds__(TRI_NT) void gram_cert0_kernel(GramCholArgs a) {
         if (a.k2_out) a.k2_out[b] = k2;
         if (a.lam_out) a.lam_out[b] = fmin(r1 * rinf, (double)n);
       }
+      CST(stp, 0, 18, 4);
       if (a.cert_open) {
         const double lam0 = fmin(r1 * rinf, (double)n);
         // kappa_2 >= pinv: beyond the gate the problem is hopeless.  Otherwise the note depends on what the system IS:
