@@ -1788,43 +1788,82 @@ __global__ __launch_bounds__(TRI_NT) void gram_cert0_kernel(GramCholArgs a) {
         const int c0 = kb * 16;
         const int bs = (n - c0 < 16) ? n - c0 : 16;
         const double* bq = pfbuf + cur * bsz;
+        CST(stp && (w == 0 || w == 2), w == 0 ? 1 : 2, kb, 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CST(stp && (w == 0 || w == 2), w == 0 ? 1 : 2, kb, 2);
         lds_barrier();                                   // every wave's pieces have landed
+        CST(stp && (w == 0 || w == 2), w == 0 ? 1 : 2, kb, 3);
         if (kb > 0) tri_pf_issue_upper<TRI_NT>(T, NPAD, c0 - 16, pfbuf + (cur ^ 1) * bsz);
+        CST(stp && (w == 0 || w == 2), w == 0 ? 1 : 2, kb, 4);
+        // (all LDS operands of a phase are requested before the first is used: read -> wait -> fma sixteen times in a row
+        //  cost 0.9 us per phase, tools/cert0_stamps.py)
+        const unsigned xb_ = lds_addr(x) + 8u * (unsigned)c0, db_ = lds_addr(dl) + 8u * (unsigned)c0;
         if (tid < 64) {                                  // wave 0 (lanes >= 16 are idle copies)
           const int i = tid & 15;
-          double D[16], rs = 0.0;
-#pragma unroll
-          for (int s_ = 0; s_ < 16; ++s_) {
-            const double av = fabs(bq[(c0 + i) * 16 + s_]);
-            D[s_] = (i < bs && s_ < bs && s_ > i) ? -av : 0.0;
-            if (i < bs && s_ < bs && s_ >= i) rs = fma(av, dl[c0 + s_], rs);
-          }
+          double bv[16], dv[16], D[16], rs = 0.0;
+          const unsigned rb_ = lds_addr(bq) + 8u * (unsigned)((c0 + i) * 16);
+          static_for<0, 16>([&](auto is) { constexpr int s_ = decltype(is)::value; lds_read64_off<8 * s_>(bv[s_], rb_); });
+          static_for<0, 16>([&](auto is) { constexpr int s_ = decltype(is)::value; lds_read64_off<8 * s_>(dv[s_], db_); });
           double r = (i < bs) ? x[c0 + i] : 0.0;
           const double iv = (i < bs) ? invd[c0 + i] : 0.0;
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(bv[4]), "+v"(bv[5]), "+v"(bv[6]), "+v"(bv[7]),
+                         "+v"(bv[8]), "+v"(bv[9]), "+v"(bv[10]), "+v"(bv[11]), "+v"(bv[12]), "+v"(bv[13]), "+v"(bv[14]),
+                         "+v"(bv[15]));
+          asm volatile("" : "+v"(dv[0]), "+v"(dv[1]), "+v"(dv[2]), "+v"(dv[3]), "+v"(dv[4]), "+v"(dv[5]), "+v"(dv[6]), "+v"(dv[7]),
+                            "+v"(dv[8]), "+v"(dv[9]), "+v"(dv[10]), "+v"(dv[11]), "+v"(dv[12]), "+v"(dv[13]), "+v"(dv[14]),
+                            "+v"(dv[15]));
+#pragma unroll
+          for (int s_ = 0; s_ < 16; ++s_) {
+            const double av = fabs(bv[s_]);
+            D[s_] = (i < bs && s_ < bs && s_ > i) ? -av : 0.0;
+            if (i < bs && s_ < bs && s_ >= i) rs = fma(av, dv[s_], rs);
+          }
+          CST(stp && w == 0, 3, kb, 0);
 #pragma unroll
           for (int s_ = 15; s_ >= 0; --s_) {
             const double xs = read_lane(r * iv, s_);
             if (i < s_) r = fma(-D[s_], xs, r);
           }
+          asm volatile("" : "+v"(r));
+          CST(stp && w == 0, 3, kb, 1);
           if (tid < bs) { x[c0 + tid] = r * iv; rowsB[c0 + tid] += rs; }
         }
+        CST(stp && (w == 0 || w == 2), w == 0 ? 1 : 2, kb, 5);
         lds_barrier();
-        for (int i = tid; i < c0; i += TRI_NT) {         // rows above the block
-          const double* row = bq + i * 16;
-          double acc = 0.0, rs = 0.0;
+        CST(stp && (w == 0 || w == 2), w == 0 ? 1 : 2, kb, 6);
+        if (tid < c0) {                                   // rows above the block (c0 <= 256 = TRI_NT: one row per thread)
+          double xv[16], dv[16];
+          static_for<0, 16>([&](auto is) { constexpr int s_ = decltype(is)::value; lds_read64_off<8 * s_>(xv[s_], xb_); });
+          static_for<0, 16>([&](auto is) { constexpr int s_ = decltype(is)::value; lds_read64_off<8 * s_>(dv[s_], db_); });
+          for (int i = tid; i < c0; i += TRI_NT) {
+            double rv[16];
+            const unsigned rb_ = lds_addr(bq) + 8u * (unsigned)(i * 16);
+            static_for<0, 16>([&](auto is) { constexpr int s_ = decltype(is)::value; lds_read64_off<8 * s_>(rv[s_], rb_); });
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]), "+v"(rv[7]),
+                           "+v"(rv[8]), "+v"(rv[9]), "+v"(rv[10]), "+v"(rv[11]), "+v"(rv[12]), "+v"(rv[13]), "+v"(rv[14]),
+                           "+v"(rv[15]));
+            asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]), "+v"(xv[6]), "+v"(xv[7]),
+                              "+v"(xv[8]), "+v"(xv[9]), "+v"(xv[10]), "+v"(xv[11]), "+v"(xv[12]), "+v"(xv[13]), "+v"(xv[14]),
+                              "+v"(xv[15]), "+v"(dv[0]), "+v"(dv[1]), "+v"(dv[2]), "+v"(dv[3]), "+v"(dv[4]), "+v"(dv[5]),
+                              "+v"(dv[6]), "+v"(dv[7]), "+v"(dv[8]), "+v"(dv[9]), "+v"(dv[10]), "+v"(dv[11]), "+v"(dv[12]),
+                              "+v"(dv[13]), "+v"(dv[14]), "+v"(dv[15]));
+            double acc = 0.0, rs = 0.0;
 #pragma unroll
-          for (int s_ = 0; s_ < 16; ++s_) {
-            const double av = fabs(row[s_]);
-            acc = fma(-av, (s_ < bs) ? x[c0 + s_] : 0.0, acc);
-            if (s_ < bs) rs = fma(av, dl[c0 + s_], rs);
+            for (int s_ = 0; s_ < 16; ++s_) {
+              const double av = fabs(rv[s_]);
+              acc = fma(-av, (s_ < bs) ? xv[s_] : 0.0, acc);
+              if (s_ < bs) rs = fma(av, dv[s_], rs);
+            }
+            x[i] -= acc;
+            rowsB[i] += rs;
           }
-          x[i] -= acc;
-          rowsB[i] += rs;
         }
+        CST(stp && (w == 0 || w == 2), w == 0 ? 1 : 2, kb, 7);
         lds_barrier();
         cur ^= 1;
-        CST(stp && w == 0, 1, kb, 0);
+        CST(stp && (w == 0 || w == 2), w == 0 ? 1 : 2, kb, 0);
       }
     }
     CST(stp && w == 0, 0, 18, 3);

@@ -20,3 +20,13 @@ print("B = %d: entry -> scales + share read %.2f, invdiag + init %.2f, 16 block 
       % (B, us(m[1] - m[0]), us(m[2] - m[1]), us(m[3] - m[2]), us(m[4] - m[3]), us(m[4] - m[0])))
 steps = [us(st[1][kb][0]) for kb in range(15, -1, -1)]
 print("block steps (us):", np.round(np.diff([us(m[2])] + steps), 2))
+for wv, tag in ((1, "wave 0"), (2, "wave 2")):
+    print(tag + ": per step — wait for the panel, barrier, issue of the next, [chain], barrier, update, barrier")
+    for kb in (15, 12, 8, 4, 1):
+        r = st[wv][kb]
+        print("  kb %2d: vmcnt %.2f  barrier %.2f  issue %.2f  chain %.2f  barrier %.2f  update %.2f  barrier %.2f"
+              % (kb, us(r[2] - r[1]), us(r[3] - r[2]), us(r[4] - r[3]), us(r[5] - r[4]), us(r[6] - r[5]), us(r[7] - r[6]), us(r[0] - r[7])))
+
+for kb in (15, 8, 1):
+    print("  kb %2d chain of wave 0: operands from LDS %.2f us, 16-step substitution %.2f us, store %.2f us"
+          % (kb, us(st[3][kb][0] - st[1][kb][4]), us(st[3][kb][1] - st[3][kb][0]), us(st[1][kb][5] - st[3][kb][1])))
