@@ -2,9 +2,41 @@
 // resident in global memory / L2), executed by ONE workgroup of TRI_NT threads.
 // Vectors live in LDS.  Used by the SVD-free trust-region path (lm_kernels.hip).
 #pragma once
+#include <type_traits>
+
 #include "blsq_device.h"
 
 namespace blsq {
+
+// Sixteen LDS operands requested together and waited for ONCE: written as a plain loop the compiler emitted
+// read -> wait -> fma sixteen times in a row (0.9 us per phase of a block step, tools/cert0_stamps.py).
+// base: LDS byte address (per lane); element k is at base + 8 * STRIDE * k.
+template <int STRIDE>
+__device__ __forceinline__ void tri_lds16_issue(double (&v)[16], unsigned base) {
+#define BLSQ_TRI_RD(K) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v[K]) : "v"(base), "n"(8 * STRIDE * (K)));
+  if constexpr (8 * STRIDE * 15 < 65536) {
+    BLSQ_TRI_RD(0) BLSQ_TRI_RD(1) BLSQ_TRI_RD(2) BLSQ_TRI_RD(3) BLSQ_TRI_RD(4) BLSQ_TRI_RD(5) BLSQ_TRI_RD(6) BLSQ_TRI_RD(7)
+    BLSQ_TRI_RD(8) BLSQ_TRI_RD(9) BLSQ_TRI_RD(10) BLSQ_TRI_RD(11) BLSQ_TRI_RD(12) BLSQ_TRI_RD(13) BLSQ_TRI_RD(14) BLSQ_TRI_RD(15)
+  }
+#undef BLSQ_TRI_RD
+}
+// (run-time element stride, in doubles)
+__device__ __forceinline__ void tri_lds16_issue_rt(double (&v)[16], unsigned base, unsigned stride_bytes) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) asm volatile("ds_read_b64 %0, %1" : "=v"(v[k]) : "v"(base + stride_bytes * (unsigned)k));
+}
+__device__ __forceinline__ void tri_lds16_wait(double (&v)[16]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                 "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+}
+__device__ __forceinline__ void tri_lds16_tie(double (&v)[16]) {       // (already waited for: pin behind that wait)
+  asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                    "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+}
+__device__ __forceinline__ unsigned tri_lds_addr(const double* p) {
+  return (unsigned)(unsigned long)(lptr_t*)p;
+}
 
 static constexpr int TRI_NT = 256;
 static constexpr int TRI_NW = TRI_NT / WAVE;
@@ -208,14 +240,16 @@ __device__ __forceinline__ void tri_solve_upper_pf(const double* R, int n, int l
     if (kb > 0) tri_pf_issue_upper<NT>(R, ld, c0 - 16, buf + (cur ^ 1) * bsz);
     if (tid < 64) {                                      // wave 0 (lanes >= 16 are idle copies)
       const int i = tid & 15;
-      double D[16];
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const double val = CMP ? -fabs(b[(c0 + i) * 16 + s]) : b[(c0 + i) * 16 + s];
-        D[s] = (i < bs && s < bs && s > i) ? val : 0.0;
-      }
+      double D[16], bv[16];
+      tri_lds16_issue<1>(bv, tri_lds_addr(b) + 8u * (unsigned)((c0 + i) * 16));
       double r = (i < bs) ? x[c0 + i] : 0.0;
       const double iv = (i < bs) ? invd[c0 + i] : 0.0;
+      tri_lds16_wait(bv);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const double val = CMP ? -fabs(bv[s]) : bv[s];
+        D[s] = (i < bs && s < bs && s > i) ? val : 0.0;
+      }
 #pragma unroll
       for (int s = 15; s >= 0; --s) {
         const double xs = read_lane(r * iv, s);
@@ -224,12 +258,19 @@ __device__ __forceinline__ void tri_solve_upper_pf(const double* R, int n, int l
       if (tid < bs) x[c0 + tid] = r * iv;
     }
     lds_barrier();
-    for (int i = tid; i < c0; i += NT) {             // rows above the block
-      const double* row = b + i * 16;
-      double acc = 0.0;
+    if (tid < c0) {                                      // rows above the block
+      double xv[16];
+      tri_lds16_issue<1>(xv, tri_lds_addr(x) + 8u * (unsigned)c0);
+      for (int i = tid; i < c0; i += NT) {
+        double rv[16];
+        tri_lds16_issue<1>(rv, tri_lds_addr(b) + 8u * (unsigned)(i * 16));
+        tri_lds16_wait(rv);
+        tri_lds16_tie(xv);
+        double acc = 0.0;
 #pragma unroll
-      for (int s = 0; s < 16; ++s) acc = fma(CMP ? -fabs(row[s]) : row[s], (s < bs) ? x[c0 + s] : 0.0, acc);
-      x[i] -= acc;
+        for (int s = 0; s < 16; ++s) acc = fma(CMP ? -fabs(rv[s]) : rv[s], (s < bs) ? xv[s] : 0.0, acc);
+        x[i] -= acc;
+      }
     }
     lds_barrier();
     cur ^= 1;
@@ -255,14 +296,16 @@ __device__ __forceinline__ void tri_solve_upper_t_pf(const double* R, int n, int
     if (kb + 1 < nblk) tri_pf_issue_lower<NT>(R, ld, c0 + 16, buf + (cur ^ 1) * bsz);
     if (tid < 64) {
       const int i = tid & 15;               // row i of the lower-triangular block = column i of R's block
-      double D[16];
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const double val = CMP ? -fabs(b[s * L + i]) : b[s * L + i];
-        D[s] = (i < bs && s < bs && s < i) ? val : 0.0;
-      }
+      double D[16], bv[16];
+      tri_lds16_issue_rt(bv, tri_lds_addr(b) + 8u * (unsigned)i, 8u * (unsigned)L);
       double r = (i < bs) ? y[c0 + i] : 0.0;
       const double iv = (i < bs) ? invd[c0 + i] : 0.0;
+      tri_lds16_wait(bv);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const double val = CMP ? -fabs(bv[s]) : bv[s];
+        D[s] = (i < bs && s < bs && s < i) ? val : 0.0;
+      }
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
         const double ys = read_lane(r * iv, s);
@@ -271,12 +314,19 @@ __device__ __forceinline__ void tri_solve_upper_t_pf(const double* R, int n, int
       if (tid < bs) y[c0 + tid] = r * iv;
     }
     lds_barrier();
-    for (int j = c0 + 16 + tid; j < n; j += NT) {    // columns to the right of the block
-      double acc = 0.0;
+    if (c0 + 16 + tid < n) {                             // columns to the right of the block
+      double yv[16];
+      tri_lds16_issue<1>(yv, tri_lds_addr(y) + 8u * (unsigned)c0);
+      for (int j = c0 + 16 + tid; j < n; j += NT) {
+        double cv[16];
+        tri_lds16_issue_rt(cv, tri_lds_addr(b) + 8u * (unsigned)(j - c0), 8u * (unsigned)L);
+        tri_lds16_wait(cv);
+        tri_lds16_tie(yv);
+        double acc = 0.0;
 #pragma unroll
-      for (int s = 0; s < 16; ++s)
-        acc = fma(CMP ? -fabs(b[s * L + (j - c0)]) : b[s * L + (j - c0)], (s < bs) ? y[c0 + s] : 0.0, acc);
-      y[j] -= acc;
+        for (int s = 0; s < 16; ++s) acc = fma(CMP ? -fabs(cv[s]) : cv[s], (s < bs) ? yv[s] : 0.0, acc);
+        y[j] -= acc;
+      }
     }
     lds_barrier();
     cur ^= 1;
