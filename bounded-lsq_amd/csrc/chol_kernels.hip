@@ -1801,15 +1801,12 @@ __global__ __launch_bounds__(TRI_NT) void gram_cert0_kernel(GramCholArgs a) {
         if (tid < 64) {                                  // wave 0 (lanes >= 16 are idle copies)
           const int i = tid & 15;
           double bv[16], dv[16], D[16], rs = 0.0;
-          const unsigned rb_ = lds_addr(bq) + 8u * (unsigned)((c0 + i) * 16);
-          static_for<0, 16>([&](auto is) { constexpr int s_ = decltype(is)::value; lds_read64_off<8 * s_>(bv[s_], rb_); });
+          tri_v2d bt[8];
+          tri_pf_upper_issue(bt, bq, c0 + i);
           static_for<0, 16>([&](auto is) { constexpr int s_ = decltype(is)::value; lds_read64_off<8 * s_>(dv[s_], db_); });
           double r = (i < bs) ? x[c0 + i] : 0.0;
           const double iv = (i < bs) ? invd[c0 + i] : 0.0;
-          asm volatile("s_waitcnt lgkmcnt(0)"
-                       : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]), "+v"(bv[4]), "+v"(bv[5]), "+v"(bv[6]), "+v"(bv[7]),
-                         "+v"(bv[8]), "+v"(bv[9]), "+v"(bv[10]), "+v"(bv[11]), "+v"(bv[12]), "+v"(bv[13]), "+v"(bv[14]),
-                         "+v"(bv[15]));
+          tri_pf_upper_wait(bt, bv);
           asm volatile("" : "+v"(dv[0]), "+v"(dv[1]), "+v"(dv[2]), "+v"(dv[3]), "+v"(dv[4]), "+v"(dv[5]), "+v"(dv[6]), "+v"(dv[7]),
                             "+v"(dv[8]), "+v"(dv[9]), "+v"(dv[10]), "+v"(dv[11]), "+v"(dv[12]), "+v"(dv[13]), "+v"(dv[14]),
                             "+v"(dv[15]));
@@ -1838,12 +1835,9 @@ __global__ __launch_bounds__(TRI_NT) void gram_cert0_kernel(GramCholArgs a) {
           static_for<0, 16>([&](auto is) { constexpr int s_ = decltype(is)::value; lds_read64_off<8 * s_>(dv[s_], db_); });
           for (int i = tid; i < c0; i += TRI_NT) {
             double rv[16];
-            const unsigned rb_ = lds_addr(bq) + 8u * (unsigned)(i * 16);
-            static_for<0, 16>([&](auto is) { constexpr int s_ = decltype(is)::value; lds_read64_off<8 * s_>(rv[s_], rb_); });
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(rv[0]), "+v"(rv[1]), "+v"(rv[2]), "+v"(rv[3]), "+v"(rv[4]), "+v"(rv[5]), "+v"(rv[6]), "+v"(rv[7]),
-                           "+v"(rv[8]), "+v"(rv[9]), "+v"(rv[10]), "+v"(rv[11]), "+v"(rv[12]), "+v"(rv[13]), "+v"(rv[14]),
-                           "+v"(rv[15]));
+            tri_v2d rt[8];
+            tri_pf_upper_issue(rt, bq, i);
+            tri_pf_upper_wait(rt, rv);
             asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]), "+v"(xv[6]), "+v"(xv[7]),
                               "+v"(xv[8]), "+v"(xv[9]), "+v"(xv[10]), "+v"(xv[11]), "+v"(xv[12]), "+v"(xv[13]), "+v"(xv[14]),
                               "+v"(xv[15]), "+v"(dv[0]), "+v"(dv[1]), "+v"(dv[2]), "+v"(dv[3]), "+v"(dv[4]), "+v"(dv[5]),

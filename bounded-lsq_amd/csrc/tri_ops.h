@@ -200,10 +200,32 @@ __device__ __forceinline__ void tri_pf_issue_upper(const double* R, int ld, int 
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nrow = c0 + 16;                              // multiple of 16: whole 8-row DMA pieces
+  // A panel row is 128 bytes: one row per thread, every thread at the same column, is a 32-way bank conflict in the
+  // plain row-major image (1.2 us of a block step at 240 rows).  The DMA writes 1 KB of LDS per instruction in lane
+  // order, but WHICH 16-byte piece a lane fetches is free: piece (row r, column pair c) of the 8-row block g goes to
+  // slot ((r ^ (g & 1)) * 8 + (c ^ r)) of the block — sixteen consecutive rows then hit sixteen different 4-bank
+  // groups at every column pair (tri_pf_upper_read16 below undoes it).
   for (int r0 = w * 8; r0 < nrow; r0 += (NT / WAVE) * 8) {
-    const int row = r0 + (lane >> 3);
-    glds16(R + c0, (unsigned)(row * ld + 2 * (lane & 7)) * 8u, dst + r0 * 16);
+    const int g1 = (r0 >> 3) & 1;
+    const int r = (lane >> 3) ^ g1, c = (lane & 7) ^ r;
+    glds16(R + c0, (unsigned)((r0 + r) * ld + 2 * c) * 8u, dst + r0 * 16);
   }
+}
+// the sixteen entries of panel row `row` (staged by tri_pf_issue_upper) as eight 16-byte reads: issue, then
+// tri_pf_upper_wait (the registers hold nothing before it), which also unpacks into v
+typedef double tri_v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void tri_pf_upper_issue(tri_v2d (&t)[8], const double* b, int row) {
+  const int r = row & 7, g1 = (row >> 3) & 1;
+  const unsigned blk = tri_lds_addr(b) + 8u * (unsigned)((row & ~7) * 16) + 128u * (unsigned)(r ^ g1);
+#define BLSQ_TRI_RD2(C) asm volatile("ds_read_b128 %0, %1" : "=v"(t[C]) : "v"(blk + 16u * (unsigned)((C) ^ r)));
+  BLSQ_TRI_RD2(0) BLSQ_TRI_RD2(1) BLSQ_TRI_RD2(2) BLSQ_TRI_RD2(3) BLSQ_TRI_RD2(4) BLSQ_TRI_RD2(5) BLSQ_TRI_RD2(6) BLSQ_TRI_RD2(7)
+#undef BLSQ_TRI_RD2
+}
+__device__ __forceinline__ void tri_pf_upper_wait(tri_v2d (&t)[8], double (&v)[16]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { v[2 * c] = t[c][0]; v[2 * c + 1] = t[c][1]; }
 }
 // rows c0 .. c0+15, columns c0 .. ld-1  ->  dst[s * (ld - c0) + col - c0]
 template <int NT = TRI_NT>
@@ -241,10 +263,11 @@ __device__ __forceinline__ void tri_solve_upper_pf(const double* R, int n, int l
     if (tid < 64) {                                      // wave 0 (lanes >= 16 are idle copies)
       const int i = tid & 15;
       double D[16], bv[16];
-      tri_lds16_issue<1>(bv, tri_lds_addr(b) + 8u * (unsigned)((c0 + i) * 16));
+      tri_v2d bt[8];
+      tri_pf_upper_issue(bt, b, c0 + i);
       double r = (i < bs) ? x[c0 + i] : 0.0;
       const double iv = (i < bs) ? invd[c0 + i] : 0.0;
-      tri_lds16_wait(bv);
+      tri_pf_upper_wait(bt, bv);
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
         const double val = CMP ? -fabs(bv[s]) : bv[s];
@@ -263,8 +286,9 @@ __device__ __forceinline__ void tri_solve_upper_pf(const double* R, int n, int l
       tri_lds16_issue<1>(xv, tri_lds_addr(x) + 8u * (unsigned)c0);
       for (int i = tid; i < c0; i += NT) {
         double rv[16];
-        tri_lds16_issue<1>(rv, tri_lds_addr(b) + 8u * (unsigned)(i * 16));
-        tri_lds16_wait(rv);
+        tri_v2d rt[8];
+        tri_pf_upper_issue(rt, b, i);
+        tri_pf_upper_wait(rt, rv);
         tri_lds16_tie(xv);
         double acc = 0.0;
 #pragma unroll
