@@ -8,7 +8,7 @@ set -o pipefail
 TAG=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out
-SHORT="--no-cpu --no-householder --no-side --no-h2d --no-probe --check 0"
+SHORT="--no-cpu --no-householder --no-side --no-h2d --no-probe --check 0 --min-time 0"
 if [ "$2" != "nobench" ]; then
 timeout -k 10 600 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err || exit 1
 tail -c 400 $O/${TAG}_bench.json; echo
