@@ -323,6 +323,8 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
   const double* edv = a.diag_vec ? a.diag_vec + (long)b * a.stride_vec : nullptr;
   const double sa = a.diag_sqrt ? a.diag_sqrt[b] : 0.0;
   int* sidx = (int*)Ria;           // [NPAD] source indices — only until the tiles are loaded (Ria is free till then)
+  const bool stpr = pidx == 500; (void)stpr;
+  CST(stpr, 0, 19, 0);
   // 0. column scales from the diagonal of H
   int bad = 0;
   for (int j = tid; j < NPAD; j += WAVE) {
@@ -355,36 +357,47 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
     tv[0] = mn; tv[1] = sm;                             // (kept for the dogbox finish)
   }
   bad = __any(bad);
+  CST(stpr, 0, 19, 1);
   // 1. the scaled source tiles -> accumulators (the source may alias the output: every read comes
   //    before any write)
   v4d acc[MT * (MT + 1) / 2];
   auto tix = [](int i, int j) { return i * MT - i * (i - 1) / 2 + (j - i); };   // upper tile (i, j) of a 5 x 5 grid
   if (!bad) {
-    // (unconditional loads from clamped indices, all in flight together; selected afterwards)
+    // Every tile's loads FIRST, from clamped indices and without a branch between them, then the scaling: a uniform
+    // `if (j < NT)` around each tile made fifteen basic blocks, i.e. fifteen memory round trips in a row (17 of this
+    // kernel's 57 us, tools/reg_stamps.py).
+    int scol[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) { const int col = 16 * j + lc; scol[j] = sidx[col < N ? col : N - 1]; }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       int srow[4];
-      double scr_[4];
-      if (i < NT) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { const int row = 16 * i + lr + 4 * g; srow[g] = sidx[row < N ? row : N - 1]; }
+#pragma unroll
+      for (int j = i; j < MT; ++j) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int row = 16 * i + lr + 4 * g;
-          srow[g] = sidx[row < N ? row : N - 1];
-          scr_[g] = sc[row];
+          const int lo_ = srow[g] < scol[j] ? srow[g] : scol[j], hi_ = srow[g] < scol[j] ? scol[j] : srow[g];   // symmetric: upper tiles
+          acc[tix(i, j)][g] = Gs[(long)lo_ * NPAD + hi_];
         }
       }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      double scr_[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) { const int row = 16 * i + lr + 4 * g; scr_[g] = sc[row < NPAD ? row : NPAD - 1]; }
 #pragma unroll
       for (int j = i; j < MT; ++j) {
         v4d v4 = {0.0, 0.0, 0.0, 0.0};
         if (j < NT) {
           const int col = 16 * j + lc;
-          const int scol = sidx[col < N ? col : N - 1];
           const double scj = sc[col];
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int row = 16 * i + lr + 4 * g;
-            const int lo_ = srow[g] < scol ? srow[g] : scol, hi_ = srow[g] < scol ? scol : srow[g];   // symmetric: upper tiles
-            double v = Gs[(long)lo_ * NPAD + hi_];
+            double v = acc[tix(i, j)][g];
             v = (row < N && col < N) ? v * scr_[g] * scj : 0.0;
             if (j == i && lr + 4 * g == lc) v += td[row];
             v4[g] = v;
@@ -412,6 +425,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
       for (int c = 16 * NT + lane; c < NPAD; c += WAVE) Gb[(long)r * NPAD + c] = 0.0;
   }
   double pmin = 1.0;
+  CST(stpr, 0, 19, 2);
 #pragma unroll
   for (int kb = 0; kb < MT; ++kb) {
     if (kb < NT) {
@@ -480,6 +494,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
       if (!fail && a.k2_out) a.k2_out[b] = kmax;        // proven: kappa_2 <= Lambda / tau
     }
   }
+  CST(stpr, 0, 19, 3);
   // 5. The first bound of the conditioning certificate (gram_cond_kernel below: same quantities, same
   //    definition) while R' and the inverse diagonal tiles are still at hand:
   //        K2 = ||R'||_1 ||R'||_inf ||Y||_1 ||Y||_inf ,   Y = R'^-T  column block by column block.
@@ -583,6 +598,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
       if (passed && a.k2_out) a.k2_out[b] = k2;
     }
   }
+  CST(stpr, 0, 19, 4);
   // 5b. TRF finish (GramCholArgs::lmfin): the `sure` branch of lm_gate_kernel, same expressions
   if (a.lmfin.fast && tid == 0) {
     bool finished = false;
@@ -600,6 +616,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
     }
     if (!finished) unsettle();
   }
+  CST(stpr, 0, 19, 5);
   // 6. dogbox finish (GramCholArgs::dog): what dog_gate_solve_kernel computes for a problem on this path —
   //    Cauchy step -(g.g)/(J_f g . J_f g) g_f with |J_f g_f| = |R g_f|, and, when the column-norm bound
   //    already proves the free block full rank (the `sure` case there), the Newton step -R_f^-1 c_f —
@@ -686,6 +703,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
       if (!(finished && passed)) unsettle();
     }
   }
+  CST(stpr, 0, 19, 6);
 }
 
 // ---- N <= 80: ALL Newton rounds of a problem in one launch ----------------------------------------
@@ -918,6 +936,24 @@ __global__ __launch_bounds__(REG_NT, 1) void lm_rounds_reg_kernel(GramCholArgs a
     }
     wsync();
     sqn = sq[n];
+    // (every tile's loads FIRST, from clamped indices and without a branch between them — a uniform `if (j < NT)` around
+    //  each tile made fifteen basic blocks, i.e. fifteen memory round trips in a row: 15 of this kernel's us per round,
+    //  tools/reg_stamps.py — then the scaling)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int j = i; j < MT; ++j) {
+        const int col = 16 * j + lc;
+        const int ccl = col < N ? col : N - 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * i + lr + 4 * g;
+          const int rcl = row < N ? row : N - 1;
+          const int lo_ = rcl < ccl ? rcl : ccl, hi_ = rcl < ccl ? ccl : rcl;
+          acc[tix(i, j)][g] = Gs[(long)lo_ * NPAD + hi_];
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       double scr_[4];
@@ -928,14 +964,11 @@ __global__ __launch_bounds__(REG_NT, 1) void lm_rounds_reg_kernel(GramCholArgs a
         v4d v4 = {0.0, 0.0, 0.0, 0.0};
         if (j < NT) {
           const int col = 16 * j + lc;
-          const int ccl = col < N ? col : N - 1;
           const double scj = sc[col];
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int row = 16 * i + lr + 4 * g;
-            const int rcl = row < N ? row : N - 1;
-            const int lo_ = rcl < ccl ? rcl : ccl, hi_ = rcl < ccl ? ccl : rcl;
-            double v = Gs[(long)lo_ * NPAD + hi_];
+            double v = acc[tix(i, j)][g];
             v = (row < N && col < N) ? v * scr_[g] * scj : 0.0;
             if (j == i && lr + 4 * g == lc) v += td[row];
             v4[g] = v;
