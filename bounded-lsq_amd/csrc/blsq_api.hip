@@ -1546,6 +1546,8 @@ namespace blsq { int chol_debug_stamps(long long* host); }
 extern "C" int blsq_debug_chol_stamps(long long* host) { return blsq::chol_debug_stamps(host); }
 namespace blsq { int gram_debug_stamps(long long* host); }
 extern "C" int blsq_debug_gram_stamps(long long* host) { return blsq::gram_debug_stamps(host); }
+namespace blsq { int cqr2_debug_stamps(long long* host); }
+extern "C" int blsq_debug_cqr2_stamps(long long* host) { return blsq::cqr2_debug_stamps(host); }
 #endif
 extern "C" int blsq_debug_qr_stamps(void* dbuf) {
   set_qr_debug_buffer(reinterpret_cast<double*>(dbuf));

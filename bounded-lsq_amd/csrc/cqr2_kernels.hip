@@ -61,11 +61,19 @@ constexpr int cqr2_split(int T0, int T1) {
 // block; the A operands X[row][16 k + 4 s + lr] come from LDS, each fragment feeding both column tiles.
 // FULL: sixteen column tiles (n = 241 .. 256) — every wave has two column tiles with W + 1 and 16 - W B tiles, no
 // guard is left in the MFMA stream (the generic form spent ~2500 instructions per chunk around its 136 MFMAs).
+#ifdef BLSQ_CHOL_STAMPS
+__device__ long long g_cq_st[8][130][8];               // [wave][chunk][phase] of ONE workgroup (diagnostic build)
+#define QST(c, i) do { if (qstp && lane == 0 && (c) < 130) g_cq_st[W][c][i] = (long long)wall_clock64(); } while (0)
+int cqr2_debug_stamps(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_cq_st), sizeof(g_cq_st)); }
+#else
+#define QST(c, i) do { } while (0)
+#endif
 template <int W, int NCB, bool FULL>
 __device__ __forceinline__ void cqr2_wave(const Cqr2Args& a, double* lds, int b) {
   constexpr int T0 = W + 1, T1 = 16 - W;                // B tiles of column tile W / of column tile NTJ - 1 - W (at most)
   const int tid = threadIdx.x, lane = tid & 63;
   const int lr = lane >> 4, lc = lane & 15;
+  const bool qstp = blockIdx.y == 100 && blockIdx.x == 0; (void)qstp;
   const int n = a.n, N = n + 1, NPAD = a.NPAD;
   const int NTJ = FULL ? 16 : (n + 15) / 16;
   const int LDX = cqr2_ldx(N);
@@ -165,11 +173,13 @@ __device__ __forceinline__ void cqr2_wave(const Cqr2Args& a, double* lds, int b)
     const bool more = row0 + GR_RC < m;
     const double* X = (cidx & 1) ? X1 : X0;
     double* Xn = (cidx & 1) ? X0 : X1;
+    QST(cidx, 0);
     if (more) issue(row0 + GR_RC, 0);
     // Waves 4 .. 7 (the SIMDs' second waves) store the tiles of the PREVIOUS chunk first and compute after, waves
     // 0 .. 3 compute first and store after: the two waves of a SIMD are out of phase, the stores (and w_f) of one
     // run under the MFMAs of the other instead of all eight waves leaving the pipe idle together.
     if (LATE && cidx > 0) store_tiles(row0 - GR_RC);
+    QST(cidx, 1);
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) { acc[rt][0] = v4d{0.0, 0.0, 0.0, 0.0}; acc[rt][1] = v4d{0.0, 0.0, 0.0, 0.0}; }
     const double* Xa = X + lc * LDX + lr;               // A[m = lc][kk = lr] of row tile 0
@@ -210,9 +220,13 @@ __device__ __forceinline__ void cqr2_wave(const Cqr2Args& a, double* lds, int b)
     // for those loads at the end of every chunk
     constexpr int KS = cqr2_split(T0, T1);
     static_for<0, KS>(ktile);
+    QST(cidx, 2);
     if (more) { commit(row0 + GR_RC, 0, Xn); issue(row0 + GR_RC, 1); }
+    QST(cidx, 3);
     if constexpr (T1 > KS) static_for<KS, T1>(ktile);
+    QST(cidx, 4);
     if (!LATE) store_tiles(row0);
+    QST(cidx, 5);
     // w_f = f - x^T z for the 32 rows of the chunk: waves 0 .. 3, eight rows each, 16 lanes per row
     if (!LATE) {
 #pragma unroll
@@ -224,8 +238,10 @@ __device__ __forceinline__ void cqr2_wave(const Cqr2Args& a, double* lds, int b)
         if (cg == 0 && row0 + row < m) Wfb[row0 + row] = X[row * LDX + n] - sum;
       }
     }
+    QST(cidx, 6);
     if (more) commit(row0 + GR_RC, 1, Xn);
     __syncthreads();
+    QST(cidx, 7);
   }
   if (LATE && cidx > 0) store_tiles(r_lo + (cidx - 1) * GR_RC);
 }
