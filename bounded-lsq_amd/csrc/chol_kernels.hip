@@ -274,7 +274,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
   constexpr int MT = 5;                                 // tile rows at most (N <= 80)
   extern __shared__ double sh_all[];
   const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int pidx = (int)blockIdx.x * REG_NW + wv;
+  const int pidx = reg_problem((int)blockIdx.x, wv);
   if (pidx >= a.count) return;                          // (wave-uniform)
   if (a.count_dev && pidx >= *a.count_dev) return;
   const int b = a.batch_list ? a.batch_list[pidx] : pidx;
@@ -283,6 +283,10 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
   const int NPAD = a.NPAD;
   double* sh = sh_all + (size_t)wv * (8 * (size_t)NPAD + 256 + MT * 256 + 64 + 16);
   auto wsync = []() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); };
+  // LDS hand-over between the lanes of this one wave: its DS instructions execute in order, the compiler only has to
+  // keep them in order too.  (A `vmcnt(0)` here also waits for every store of the factor issued so far — a round trip
+  // to memory per row block on the critical path of a kernel that is one problem's latency.)
+  auto lsync = []() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
   auto unsettle = [&]() { if (tid == 0 && a.unsettled) atomicAdd(a.unsettled, 1); };
   if (a.mask && a.mask[b] <= 1) {
     if (tid == 0 && a.fb_mask) a.fb_mask[b] = 0;
@@ -383,25 +387,30 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
         }
       }
     }
+    // (the scales of a lane's rows and columns and the diagonal shifts read FIRST, no branch around a tile: what is
+    //  outside the N x N block scales to zero anyway)
+    double scj_[MT], tdl_[MT], scr_[MT][4];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      double scr_[4];
+      const int col = 16 * i + lc;
+      scj_[i] = sc[col < NPAD ? col : NPAD - 1];
+      tdl_[i] = td[col < NPAD ? col : NPAD - 1];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) { const int row = 16 * i + lr + 4 * g; scr_[g] = sc[row < NPAD ? row : NPAD - 1]; }
+      for (int g = 0; g < 4; ++g) { const int row = 16 * i + lr + 4 * g; scr_[i][g] = sc[row < NPAD ? row : NPAD - 1]; }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
 #pragma unroll
       for (int j = i; j < MT; ++j) {
-        v4d v4 = {0.0, 0.0, 0.0, 0.0};
-        if (j < NT) {
-          const int col = 16 * j + lc;
-          const double scj = sc[col];
+        v4d v4;
+        const int col = 16 * j + lc;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int row = 16 * i + lr + 4 * g;
-            double v = acc[tix(i, j)][g];
-            v = (row < N && col < N) ? v * scr_[g] * scj : 0.0;
-            if (j == i && lr + 4 * g == lc) v += td[row];
-            v4[g] = v;
-          }
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * i + lr + 4 * g;
+          double v = acc[tix(i, j)][g];
+          v = (row < N && col < N) ? v * scr_[i][g] * scj_[j] : 0.0;
+          if (j == i && lr + 4 * g == lc && row < 16 * NT) v += tdl_[i];
+          v4[g] = v;
         }
         acc[tix(i, j)] = v4;
       }
@@ -418,11 +427,19 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
     return;
   }
   // strictly lower tiles and everything beyond 16 NT are part of the triangle's image: zero
-  for (int r = 0; r < NPAD; ++r) {
-    const int cend = (r < 16 * NT) ? (r & ~15) : NPAD;
-    for (int c = lane; c < cend; c += WAVE) Gb[(long)r * NPAD + c] = 0.0;
-    if (r < 16 * NT)
-      for (int c = 16 * NT + lane; c < NPAD; c += WAVE) Gb[(long)r * NPAD + c] = 0.0;
+  // (tile by tile in the accumulators' lane layout: 4 stores per tile, none of them waited for)
+#pragma unroll
+  for (int ti = 0; ti < MT; ++ti) {
+#pragma unroll
+    for (int tj = 0; tj < MT; ++tj) {
+      if (16 * ti < NPAD && 16 * tj < NPAD && (ti >= NT || tj < ti || tj >= NT)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int row = 16 * ti + lr + 4 * g, col = 16 * tj + lc;
+          if (row < NPAD && col < NPAD) Gb[(long)row * NPAD + col] = 0.0;
+        }
+      }
+    }
   }
   double pmin = 1.0;
   CST(stpr, 0, 19, 2);
@@ -479,7 +496,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
           }
         }
       }
-      wsync();                                          // (Dt / Ri are rewritten by the next chain)
+      lsync();                                          // (Dt / Ri are rewritten by the next chain)
     }
   }
   const double kmax = a.k2_max > 0.0 ? a.k2_max : GRAM_K2_MAX;
@@ -533,9 +550,9 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
       for (int jj = 0; jj < MT; ++jj) {
         if (jj < NTn) {
           xs[lane] = colp[jj];
-          wsync();
+          lsync();
           r1 = fmax(r1, (xs[lc] + xs[16 + lc]) + (xs[32 + lc] + xs[48 + lc]));
-          wsync();
+          lsync();
         }
       }
       r1 = wave_max(r1);
@@ -579,9 +596,9 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
             }
           }
           xs[lane] = cY;
-          wsync();
+          lsync();
           y1 = fmax(y1, (xs[lc] + xs[16 + lc]) + (xs[32 + lc] + xs[48 + lc]));
-          wsync();
+          lsync();
         }
       }
       y1 = wave_max(y1);
@@ -626,7 +643,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
     if (!fail && a.colinfo) {
       const int NTn = (n + 15) / 16;
       const double mn = tv[0], sm = tv[1];
-      wsync();
+      lsync();
       const double* gb = a.dog.g + (long)b * a.stride_vec;
       double gg = 0.0;
       for (int q = lane; q < NPAD; q += WAVE) {
@@ -635,7 +652,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
         gg = fma(gq, gq, gg);
       }
       gg = wave_sum(gg);
-      wsync();
+      lsync();
       double uu = 0.0;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
@@ -681,7 +698,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
 #pragma unroll
               for (int g = 0; g < 4; ++g) tv[lr + 4 * g] = cv[16 * kk + lr + 4 * g] - part[g];
             }
-            wsync();
+            lsync();
             const int nb = (n - 16 * kk < 16) ? n - 16 * kk : 16;
             const double* Rk = Ria + kk * 256;
             double yi = 0.0;
@@ -689,7 +706,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
             for (int c = 0; c < 16; ++c) yi = fma(Rk[lc * 16 + c], (c < nb) ? tv[c] : 0.0, yi);
             if (lc >= nb) yi = 0.0;
             if (lr == 0) yv[16 * kk + lc] = yi;
-            wsync();
+            lsync();
           }
         }
         const double sqn = sq[n];
@@ -734,7 +751,7 @@ __global__ __launch_bounds__(REG_NT, 1) void lm_rounds_reg_kernel(GramCholArgs a
   constexpr bool start = true;
   extern __shared__ double sh_all[];
   const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int b = (int)blockIdx.x * REG_NW + wv;
+  const int b = reg_problem((int)blockIdx.x, wv);
   if (b >= lm.B) return;
   if (lm.path && lm.path[b] != 0) return;               // (Householder-path problem: lm_start and the round loop)
   const int lane = threadIdx.x & 63, lr = lane >> 4, lc = lane & 15;
@@ -1063,7 +1080,7 @@ hipError_t launch_lm_rounds_reg(const GramCholArgs& c, const LmState& lm, const 
   static std::atomic<size_t> granted[64];
   hipError_t ge = gram_grant_lds(lm_rounds_reg_kernel, per * REG_NW, granted);
   if (ge != hipSuccess) return ge;
-  hipLaunchKernelGGL(lm_rounds_reg_kernel, dim3((lm.B + REG_NW - 1) / REG_NW), dim3(REG_NT), per * REG_NW, s, c, lm,
+  hipLaunchKernelGGL(lm_rounds_reg_kernel, dim3(reg_grid(lm.B)), dim3(REG_NT), per * REG_NW, s, c, lm,
                      Delta, alpha_in);
   return hipGetLastError();
 }
@@ -2396,7 +2413,7 @@ hipError_t launch_gram_chol(const GramCholArgs& a_in, int B, hipStream_t s) {
       static std::atomic<size_t> granted[64];
       hipError_t ge = gram_grant_lds(gram_chol_reg_kernel, per_reg * REG_NW, granted);
       if (ge != hipSuccess) return ge;
-      hipLaunchKernelGGL(gram_chol_reg_kernel, dim3((B + REG_NW - 1) / REG_NW), dim3(REG_NT), per_reg * REG_NW,
+      hipLaunchKernelGGL(gram_chol_reg_kernel, dim3(reg_grid(B)), dim3(REG_NT), per_reg * REG_NW,
                          s, a);
     }
   } else {

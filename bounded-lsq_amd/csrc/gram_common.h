@@ -16,6 +16,11 @@ static constexpr int GR_NW = GR_NT / WAVE;
 static constexpr int GR_RC = 32;          // rows per staged chunk (8 MFMA k-steps)
 static constexpr int REG_NW = 4;          // one-wave-per-problem kernels (N <= 80): problems (waves) per workgroup —
 static constexpr int REG_NT = REG_NW * WAVE;   // 1024 problems spread over 256 workgroups instead of 128
+// Problem of wave `wv` of workgroup `w` in the one-wave-per-problem kernels.  Workgroups are dealt round-robin over
+// the eight XCDs and the Gram kernel that has just written the problem's matrix ran as workgroup b (one per problem):
+// b and the workgroup that reads it back agree mod 8, so the read finds the matrix in the L2 it was written through.
+__device__ __forceinline__ int reg_problem(int w, int wv) { return (((w >> 3) * REG_NW + wv) << 3) | (w & 7); }
+static inline unsigned reg_grid(int B) { return (unsigned)(((B + 8 * REG_NW - 1) / (8 * REG_NW)) * 8); }
 static constexpr double GRAM_SMIN = GRAM_SMIN_PROVEN;   // early reject: a pivot of R' below what the certificate could accept
 
 template <class K>
