@@ -39,6 +39,18 @@ inline bool merge_fits(int n) { return 2 * ((n + 15) / 16) <= QR_MAX_TILES; }
 
 }  // namespace
 
+// Device counters -> host without a blit: ONE lane stores [v0, v1, v2, seq] as a single 16-byte write into a
+// pinned slot the host polls for `seq`.  (A hipMemcpyAsync of 12 bytes is a blit kernel of 4 us and a signal the
+// next dispatch waits 6 - 9 us behind — `tools/trace_gaps.py` — four times per step-solve call of the headline
+// batch, once in the middle of a 0.17 ms step of the 512 x 64 batches.)
+__global__ void publish_ints_kernel(const int* __restrict__ src, int n, int* dst, int seq) {
+  if (threadIdx.x != 0) return;
+  int4 v;
+  v.x = n > 0 ? src[0] : 0; v.y = n > 1 ? src[1] : 0; v.z = n > 2 ? src[2] : 0; v.w = seq;
+  *reinterpret_cast<int4*>(dst) = v;
+  __threadfence_system();
+}
+
 struct blsq_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -52,8 +64,10 @@ struct blsq_ctx {
   struct Pending { int slot; hipEvent_t a, b; };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> pool;
-  int* pinned = nullptr;            // 32 pinned host ints: device -> host counters without staging
-                                    // ([0..3] one-shot read-backs, [8 + r] Newton-round counters)
+  int* pinned = nullptr;            // 128 pinned host ints: device -> host counters without staging
+                                    // ([0..3] one-shot read-backs, [32 + 4 r ..] the slot of Newton round r)
+  int pub_seq = 0;                  // sequence number of the last publish()
+  bool pub_direct = true;           // BLSQ_PUBLISH = 0: hipMemcpyAsync + event instead of the publishing kernel
   hipEvent_t lm_ev[2] = {nullptr, nullptr};   // read-back of the counter of round r has landed (r & 1)
   long long gram_fast = 0, gram_fallback = 0;   // problems factored by the normal equations / handed to the QR tree
   unsigned long long* cq_accept_dev = nullptr;  // device counter: rejected problems the CholeskyQR2 tier factored
@@ -68,6 +82,31 @@ struct blsq_ctx {
   int fail(hipError_t e, const char* where) {
     err = std::string(where) + ": " + hipGetErrorString(e);
     return (int)e;
+  }
+  // n <= 3 device ints -> the 16-byte pinned slot `slot` ([3] = sequence number, returned in *expect); `ev` is
+  // recorded on the blit route only
+  hipError_t publish(const int* src, int n, int* slot, hipEvent_t ev, int* expect) {
+    if (!pub_direct) {
+      hipError_t e = hipMemcpyAsync(slot, src, n * sizeof(int), hipMemcpyDeviceToHost, stream);
+      if (e == hipSuccess) e = hipEventRecord(ev, stream);
+      return e;
+    }
+    *expect = ++pub_seq;
+    hipLaunchKernelGGL(publish_ints_kernel, dim3(1), dim3(64), 0, stream, src, n, slot, *expect);
+    return hipGetLastError();
+  }
+  // ... and the wait for it: polls the slot; looks at the stream now and then so that a failed launch cannot hang it
+  hipError_t await(const int* slot, hipEvent_t ev, int expect) {
+    if (!pub_direct) return hipEventSynchronize(ev);
+    for (unsigned long it = 1;; ++it) {
+      if (__atomic_load_n(slot + 3, __ATOMIC_ACQUIRE) == expect) return hipSuccess;
+      if ((it & 0x3fff) == 0) {
+        const hipError_t q = hipStreamQuery(stream);
+        if (q == hipSuccess) return __atomic_load_n(slot + 3, __ATOMIC_ACQUIRE) == expect ? hipSuccess : hipErrorUnknown;
+        if (q != hipErrorNotReady) return q;
+      }
+      __builtin_ia32_pause();
+    }
   }
   int bad(int argidx, const char* what) {
     err = std::string("invalid argument: ") + what;
@@ -632,8 +671,9 @@ struct blsq_trf_plan {
   // Second guess (N <= 80): every problem is settled inside the Cholesky kernel (certificate + rank gate),
   // so the certificate and gate launches are not even enqueued; checked with the same read-back.
   bool guess_settled = false, pend_tail = false;
-  int* pend_pin = nullptr;          // 4 pinned ints of this plan
+  int* pend_pin = nullptr;          // 4 pinned ints of this plan ([3]: sequence number of the publish)
   hipEvent_t pend_ev = nullptr;
+  int pend_seq = 0;
   const double* pend_dJ = nullptr; const double* pend_df = nullptr;
   int pend_ldJ = 0, pend_scale_mode = 0;
   double* pend_scale_io = nullptr;
@@ -658,6 +698,7 @@ struct blsq_dogbox_plan {
   bool guess_settled = false, pend_tail = false;   // second guess: every problem settled inside the Cholesky kernel
   int* pend_pin = nullptr;
   hipEvent_t pend_ev = nullptr;
+  int pend_seq = 0;
   const double* pend_dJ = nullptr; const double* pend_df = nullptr;
   int pend_ldJ = 0, pend_scale_mode = 0;
   double* pend_scale_io = nullptr;
@@ -687,8 +728,10 @@ extern "C" int blsq_ctx_create(int device_id, blsq_ctx** out) {
   if (e != hipSuccess) { delete c; return (int)e; }
   e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { hipStreamDestroy(c->stream); delete c; return (int)e; }
-  e = hipHostMalloc((void**)&c->pinned, 32 * sizeof(int), hipHostMallocDefault);
+  e = hipHostMalloc((void**)&c->pinned, 128 * sizeof(int), hipHostMallocDefault);
   if (e != hipSuccess) { hipStreamDestroy(c->stream); delete c; return (int)e; }
+  memset(c->pinned, 0, 128 * sizeof(int));
+  { const char* pe = getenv("BLSQ_PUBLISH"); c->pub_direct = !(pe && pe[0] == '0'); }
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->lm_ev[i], hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc((void**)&c->cq_accept_dev, sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemset(c->cq_accept_dev, 0, sizeof(unsigned long long));
@@ -1132,9 +1175,7 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, 
     p->lm.colinfo = p->aug_colinfo.as<double>();
   } else if ((rc = trf_gate_tail(p, c, mask == nullptr))) return rc;
   if (defer) {                              // the counters travel; the verdict is read by trf_resolve
-    HIPCHK(ctx, hipMemcpyAsync(p->pend_pin, t.fb_count(), 3 * sizeof(int), hipMemcpyDeviceToHost,
-                               ctx->stream));
-    HIPCHK(ctx, hipEventRecord(p->pend_ev, ctx->stream));
+    HIPCHK(ctx, ctx->publish(t.fb_count(), 3, p->pend_pin, p->pend_ev, &p->pend_seq));
     p->pending = true; p->pend_tail = skip_tail;
     *nfb = 0;
     p->gate_done = true;
@@ -1190,7 +1231,7 @@ int trf_factor_core(blsq_trf_plan* p, const double* dJ, const double* df, int ld
     // a verdict nobody asked for belongs to a factor that is being overwritten: no repair, but it is still
     // read — the path statistics and the decision whether to guess again depend on it
     p->pending = false;
-    HIPCHK(ctx, hipEventSynchronize(p->pend_ev));
+    HIPCHK(ctx, ctx->await(p->pend_pin, p->pend_ev, p->pend_seq));
     const int nfb_ = p->pend_pin[0], njac_ = p->pend_pin[1];
     if (p->pend_tail) { if (!(p->ld <= 80 && p->pend_pin[2] == 0)) p->guess_settled = false; }
     else if (nfb_ > 0 || njac_ > 0) {
@@ -1222,7 +1263,7 @@ int trf_resolve(blsq_trf_plan* p, bool* redo) {
   if (!p->pending) return 0;
   blsq_ctx* ctx = p->ctx;
   p->pending = false;
-  HIPCHK(ctx, hipEventSynchronize(p->pend_ev));
+  HIPCHK(ctx, ctx->await(p->pend_pin, p->pend_ev, p->pend_seq));
   int nfb = p->pend_pin[0], njac = p->pend_pin[1];
   const bool settled = (p->ld <= 80 && p->pend_pin[2] == 0);
   QrTree& t = p->tree;
@@ -1296,7 +1337,8 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
       p->lm.fused_gram = 1;
     }
   }
-  int* pin = ctx->pinned + 8;
+  int* pin = ctx->pinned + 32;                           // slot of round r: pin + 4 r
+  int pin_seq[16] = {0};
   if (!p->lm_counts_clean) HIPCHK(ctx, hipMemsetAsync(counts, 0, 16 * sizeof(int), ctx->stream));
   p->lm_counts_clean = false;
   ctx->begin(K_LM_SOLVE);
@@ -1304,10 +1346,9 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_lm_start");
   auto read_back = [&](int r) -> hipError_t {            // counter of round r -> pin[r], event r & 1
-    hipError_t ee = hipMemcpyAsync(pin + r, counts + r, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-    if (ee == hipSuccess) ee = hipEventRecord(ctx->lm_ev[r & 1], ctx->stream);
-    return ee;
+    return ctx->publish(counts + r, 1, pin + 4 * r, ctx->lm_ev[r & 1], &pin_seq[r]);
   };
+  auto landed = [&](int r) -> hipError_t { return ctx->await(pin + 4 * r, ctx->lm_ev[r & 1], pin_seq[r]); };
   auto chol_round = [&](int round, int grid, int expect, const int* count_dev) -> hipError_t {
     // R_alpha = chol(D G D + E^2 + alpha I) straight from the Gram, active Gram-path problems
     GramCholArgs c{};
@@ -1359,8 +1400,8 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
     for (int round = 0; round < 12; ++round) {
       const bool ahead = round < ahead_rounds;
       if (!ahead) {
-        HIPCHK(ctx, hipEventSynchronize(ctx->lm_ev[round & 1]));
-        const int active = pin[round];
+        HIPCHK(ctx, landed(round));
+        const int active = pin[4 * round];
         if (round == 0) p->lm_expect0 = active > 0 ? active : -1;
         if (active == 0) break;
         bound = expect = active;
@@ -1378,8 +1419,8 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
       if (e != hipSuccess) return ctx->fail(e, "launch_lm_update");
       HIPCHK(ctx, read_back(round + 1));
       if (ahead) {
-        HIPCHK(ctx, hipEventSynchronize(ctx->lm_ev[round & 1]));
-        const int active = pin[round];                  // what round `round` really worked on
+        HIPCHK(ctx, landed(round));
+        const int active = pin[4 * round];                  // what round `round` really worked on
         if (round == 0) p->lm_expect0 = active > 0 ? active : -1;
         if (active == 0) break;                         // (the round just enqueued is empty)
         bound = expect = active;
@@ -1389,7 +1430,7 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
     p->lm_rounds_last = done_rounds;
     return 0;
   }
-  HIPCHK(ctx, hipEventSynchronize(ctx->lm_ev[0]));
+  HIPCHK(ctx, landed(0));
   int active = pin[0];
   for (int round = 0; round < 12 && active > 0; ++round) {
     if (p->use_chol && !p->lm.fused_gram) {
@@ -1406,8 +1447,8 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_lm_update");
     HIPCHK(ctx, read_back(round + 1));
-    HIPCHK(ctx, hipEventSynchronize(ctx->lm_ev[(round + 1) & 1]));
-    active = pin[round + 1];
+    HIPCHK(ctx, landed(round + 1));
+    active = pin[4 * (round + 1)];
   }
   return 0;
 }
@@ -1431,6 +1472,7 @@ extern "C" int blsq_trf_plan_create(blsq_ctx* ctx, int B, int m, int n, blsq_trf
     const char* oe = getenv("BLSQ_OPTIMISTIC");
     p->optimistic = !(oe && oe[0] == '0');
     hipError_t e = hipHostMalloc((void**)&p->pend_pin, 4 * sizeof(int), hipHostMallocDefault);
+    if (e == hipSuccess) memset(p->pend_pin, 0, 4 * sizeof(int));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->pend_ev, hipEventDisableTiming);
     if (e != hipSuccess) rc = ctx->fail(e, "optimistic-verdict resources");
   }
@@ -2102,7 +2144,7 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
   int rc;
   if (p->pending) {                         // (as trf_factor_core: read the dropped verdict, no repair)
     p->pending = false;
-    HIPCHK(ctx, hipEventSynchronize(p->pend_ev));
+    HIPCHK(ctx, ctx->await(p->pend_pin, p->pend_ev, p->pend_seq));
     const int nfb_ = p->pend_pin[0], njac_ = p->pend_pin[1];
     if (p->pend_tail) { if (!(p->ld <= 80 && p->pend_pin[2] == 0)) p->guess_settled = false; }
     else if (nfb_ > 0 || njac_ > 0) {
@@ -2136,8 +2178,7 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
   if (!skip_tail && (rc = dog_gate_tail(p, c))) return rc;
   int nfb = 0;
   if (defer) {                              // guess: nobody leaves the path, nobody needs the SVD (dog_resolve checks)
-    HIPCHK(ctx, hipMemcpyAsync(p->pend_pin, t.fb_count(), 3 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipEventRecord(p->pend_ev, ctx->stream));
+    HIPCHK(ctx, ctx->publish(t.fb_count(), 3, p->pend_pin, p->pend_ev, &p->pend_seq));
     p->pending = true; p->pend_tail = skip_tail;
     p->pend_dJ = dJ; p->pend_df = df; p->pend_ldJ = ldJ; p->pend_scale_mode = scale_mode;
     p->gate_done = true;
@@ -2170,7 +2211,7 @@ int dog_resolve(blsq_dogbox_plan* p, bool* redo) {
   blsq_ctx* ctx = p->ctx;
   QrTree& t = p->tree;
   p->pending = false;
-  HIPCHK(ctx, hipEventSynchronize(p->pend_ev));
+  HIPCHK(ctx, ctx->await(p->pend_pin, p->pend_ev, p->pend_seq));
   int nfb = p->pend_pin[0], njac = p->pend_pin[1];
   const bool settled = (p->ld <= 80 && p->pend_pin[2] == 0);
   if (p->pend_tail) {
@@ -2228,6 +2269,7 @@ extern "C" int blsq_dogbox_plan_create(blsq_ctx* ctx, int B, int m, int n,
     const char* oe = getenv("BLSQ_OPTIMISTIC");
     p->optimistic = !(oe && oe[0] == '0');
     hipError_t e = hipHostMalloc((void**)&p->pend_pin, 4 * sizeof(int), hipHostMallocDefault);
+    if (e == hipSuccess) memset(p->pend_pin, 0, 4 * sizeof(int));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->pend_ev, hipEventDisableTiming);
     if (e != hipSuccess) rc = ctx->fail(e, "optimistic-verdict resources");
   }
