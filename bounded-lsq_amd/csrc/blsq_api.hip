@@ -674,6 +674,10 @@ struct blsq_trf_plan {
   int* pend_pin = nullptr;          // 4 pinned ints of this plan ([3]: sequence number of the publish)
   hipEvent_t pend_ev = nullptr;
   int pend_seq = 0;
+  // the caller's vectors of a device-resident factor call, copied into the state layout by the prep launch
+  // (BLSQ_FUSE_PACK = 0: by a pack_vecs launch in front of the Gram, as before)
+  bool pack_pend = false;
+  PackVecs pack_pv{};
   const double* pend_dJ = nullptr; const double* pend_df = nullptr;
   int pend_ldJ = 0, pend_scale_mode = 0;
   double* pend_scale_io = nullptr;
@@ -699,6 +703,10 @@ struct blsq_dogbox_plan {
   int* pend_pin = nullptr;
   hipEvent_t pend_ev = nullptr;
   int pend_seq = 0;
+  // the caller's vectors of a device-resident factor call, copied into the state layout by the prep launch
+  // (BLSQ_FUSE_PACK = 0: by a pack_vecs launch in front of the Gram, as before)
+  bool pack_pend = false;
+  PackVecs pack_pv{};
   const double* pend_dJ = nullptr; const double* pend_df = nullptr;
   int pend_ldJ = 0, pend_scale_mode = 0;
   double* pend_scale_io = nullptr;
@@ -1146,6 +1154,23 @@ int trf_gate_tail(blsq_trf_plan* p, const GramCholArgs& c, bool full = true) {
   return 0;
 }
 
+static bool fuse_pack() {
+  static const bool on = [] { const char* e = getenv("BLSQ_FUSE_PACK"); return !(e && e[0] == '0'); }();
+  return on;
+}
+// the deferred vectors of this factor call: handed to the prep launch (returns them), or — a masked call keeps the
+// other problems' state, so its prep launch cannot do the copy — packed by the stand-alone launch right here
+template <class Plan>
+static int take_pack(Plan* p, const int* mask, const PackVecs** pk) {
+  *pk = nullptr;
+  if (!p->pack_pend) return 0;
+  p->pack_pend = false;
+  if (!mask) { *pk = &p->pack_pv; return 0; }
+  hipError_t e = launch_pack_vecs(p->pack_pv, p->n, p->ld, p->B, p->ctx->stream);
+  if (e != hipSuccess) return p->ctx->fail(e, "launch_pack_vecs");
+  return 0;
+}
+
 // prep from the Gram, Cholesky of H with the pivot gate, conditioning gate; *nfb = problems of this
 // call that must go to the Householder tree (their indices are flagged in tree.fb_mask()).
 int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, bool defer = false) {
@@ -1154,8 +1179,10 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, 
   if (!t.fb_zeroed) HIPCHK(ctx, hipMemsetAsync(t.fb_count(), 0, 3 * sizeof(int), ctx->stream));
   t.fb_zeroed = false;
   p->st.Rt = t.Rfinal(); p->st.Gk = t.gram_keep.as<double>(); p->st.path = t.path_rw();
+  const PackVecs* pk = nullptr;
+  { int rc_ = take_pack(p, mask, &pk); if (rc_) return rc_; }
   ctx->begin(K_PREP);
-  hipError_t e = launch_trf_prep(p->st, scale_mode, 1, mask, 0, ctx->stream);
+  hipError_t e = launch_trf_prep(p->st, scale_mode, 1, mask, 0, ctx->stream, pk);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_trf_prep(gram)");
   GramCholArgs c = trf_chol_args(p, mask);
@@ -1508,6 +1535,12 @@ static int trf_put_bounds(blsq_trf_plan* p, const double* x, const double* lb, c
     // (the two gate counters of the factor call that follows are cleared by the same launch)
     PackVecs pv{{x, lb, ub, scale, nullptr}, {p->st.x, p->st.lb, p->st.ub, p->st.scale, nullptr},
                 (zero_counts && p->tree.gram) ? p->tree.fb_count() : nullptr, 3};
+    p->pack_pend = false;
+    if (zero_counts && p->tree.gram && fuse_pack()) {   // (the Gram stage's prep launch does it: trf_gram_stage)
+      p->pack_pv = pv; p->pack_pend = true;
+      p->tree.fb_zeroed = true;
+      return 0;
+    }
     hipError_t e = launch_pack_vecs(pv, p->n, p->ld, p->B, ctx->stream);
     if (e != hipSuccess) return ctx->fail(e, "launch_pack_vecs");
     p->tree.fb_zeroed = zero_counts && p->tree.gram;
@@ -2016,6 +2049,12 @@ int dog_put(blsq_dogbox_plan* p, const double* x, const double* lb, const double
   if (kind == hipMemcpyDeviceToDevice) {
     PackVecs pv{{x, lb, ub, scale, on_bound}, {p->st.x, p->st.lb, p->st.ub, p->st.scale, p->st.on_bound},
                 (zero_counts && p->tree.gram) ? p->tree.fb_count() : nullptr, 3};
+    p->pack_pend = false;
+    if (zero_counts && p->tree.gram && fuse_pack()) {   // (the Gram stage's prep launch does it: dog_factor_core)
+      p->pack_pv = pv; p->pack_pend = true;
+      p->tree.fb_zeroed = true;
+      return 0;
+    }
     hipError_t e = launch_pack_vecs(pv, p->n, p->ld, p->B, ctx->stream);
     if (e != hipSuccess) return ctx->fail(e, "launch_pack_vecs");
     p->tree.fb_zeroed = zero_counts && p->tree.gram;
@@ -2160,8 +2199,10 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
   if (!t.fb_zeroed) HIPCHK(ctx, hipMemsetAsync(t.fb_count(), 0, 3 * sizeof(int), ctx->stream));
   t.fb_zeroed = false;
   p->st.Rt = t.Rfinal(); p->st.Gk = t.gram_keep.as<double>(); p->st.path = t.path_rw();
+  const PackVecs* pk = nullptr;
+  { int rc_ = take_pack(p, mask, &pk); if (rc_) return rc_; }
   ctx->begin(K_PREP);
-  hipError_t e = launch_dog_prep(p->st, scale_mode, 1, mask, 0, ctx->stream);
+  hipError_t e = launch_dog_prep(p->st, scale_mode, 1, mask, 0, ctx->stream, pk);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_dog_prep(gram)");
   const GramCholArgs c = dog_chol_args(p, mask);

@@ -261,8 +261,10 @@ struct TrfState {         // all device pointers, batch-major, vector stride ld
 // up to five caller vectors [B][n] (8-byte elements; nullptr: skipped) -> the [B][ld] state layout, one launch
 struct PackVecs { const void* src[5]; void* dst[5]; int* zero; int nzero; };   // zero[0 .. nzero): counters cleared on the way
 hipError_t launch_pack_vecs(const PackVecs& pv, int n, int ld, int B, hipStream_t s);
+// (pk: the caller's vectors of this factor call, stride n — copied into the state layout by the prep launch itself
+//  instead of a pack_vecs launch in front of the Gram; only with sel == nullptr)
 hipError_t launch_trf_prep(const TrfState& st, int jac_scaling, int from_gram, const int* sel,
-                           int redo, hipStream_t s);
+                           int redo, hipStream_t s, const PackVecs* pk = nullptr);
 
 struct TrfStepOut {       // device pointers
   double* step_h;         // [B][ld]
@@ -371,7 +373,7 @@ struct DogState {
 // from_gram / sel / redo: as launch_trf_prep (a Gram-path problem gets neither the compacted
 // columns S nor — yet — its Cauchy step: that comes from X in dog_gate_solve)
 hipError_t launch_dog_prep(const DogState& st, int jac_scaling, int from_gram, const int* sel,
-                           int redo, hipStream_t s);
+                           int redo, hipStream_t s, const PackVecs* pk = nullptr);
 hipError_t launch_dog_solve(const DogState& st, const int* skip, hipStream_t s);
 // path / colinfo (optional): Gram-path flags and the column-norm summary of the free block
 // done (optional [B]): problems the Cholesky kernel already finished (GramCholArgs::dog) are skipped

@@ -46,11 +46,12 @@ __device__ static void full_matvec_d(const double* M, int n, int ld, const doubl
 
 // ------------------------------------------------------------------ prep --
 __global__ __launch_bounds__(DG_NT) void dog_prep_kernel(DogState st, int jac_scaling, int from_gram,
-                                                         const int* sel, int redo) {
+                                                         const int* sel, int redo, PackVecs pk) {
   extern __shared__ double sh[];
   __shared__ double red[32];
   __shared__ int nfree_s;
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (b == 0 && pk.zero && tid < pk.nzero) pk.zero[tid] = 0;
   if (sel && sel[b] <= 1) return;
   const int n = st.n, ld = st.ld;
   const long vo = (long)b * ld;
@@ -83,6 +84,14 @@ __global__ __launch_bounds__(DG_NT) void dog_prep_kernel(DogState st, int jac_sc
         }
       }
     }
+    }
+    if (pk.src[0]) {                                         // the caller's vectors (stride n) -> state layout
+      const long so = (long)b * n + j;
+      st.x[vo + j] = static_cast<const double*>(pk.src[0])[so];
+      st.lb[vo + j] = static_cast<const double*>(pk.src[1])[so];
+      st.ub[vo + j] = static_cast<const double*>(pk.src[2])[so];
+      st.scale[vo + j] = static_cast<const double*>(pk.src[3])[so];
+      st.on_bound[vo + j] = static_cast<const long long*>(pk.src[4])[so];
     }
     double sc = redo ? st.scale_in[vo + j] : st.scale[vo + j];
     if (!redo) st.scale_in[vo + j] = sc;
@@ -136,10 +145,11 @@ __global__ __launch_bounds__(DG_NT) void dog_prep_kernel(DogState st, int jac_sc
 }
 
 hipError_t launch_dog_prep(const DogState& st, int jac_scaling, int from_gram, const int* sel,
-                           int redo, hipStream_t s) {
+                           int redo, hipStream_t s, const PackVecs* pk) {
   const size_t lds = sizeof(double) * 2 * (size_t)st.ld + sizeof(int) * (size_t)st.ld;
+  const PackVecs none{{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}, nullptr, 0};
   hipLaunchKernelGGL(dog_prep_kernel, dim3(st.B), dim3(DG_NT), lds, s, st, jac_scaling, from_gram,
-                     sel, redo);
+                     sel, redo, (pk && !sel) ? *pk : none);
   return hipGetLastError();
 }
 

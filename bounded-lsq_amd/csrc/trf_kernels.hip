@@ -20,9 +20,10 @@ static constexpr double EPS = 2.220446049250313e-16;
 
 // ------------------------------------------------------------------ prep --
 __global__ __launch_bounds__(NS_NT) void trf_prep_kernel(TrfState st, int jac_scaling, int from_gram,
-                                                         const int* sel, int redo) {
+                                                         const int* sel, int redo, PackVecs pk) {
   __shared__ double red[32];
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (b == 0 && pk.zero && tid < pk.nzero) pk.zero[tid] = 0;
   if (sel && sel[b] <= 1) return;
   const int n = st.n, ld = st.ld;
   const double* Rt = st.Rt + (long)b * ld * ld;
@@ -53,6 +54,13 @@ __global__ __launch_bounds__(NS_NT) void trf_prep_kernel(TrfState st, int jac_sc
         }
       }
     }
+    }
+    if (pk.src[0]) {                                      // the caller's vectors (stride n) -> state layout
+      const long so = (long)b * n + j;
+      st.x[vo + j] = static_cast<const double*>(pk.src[0])[so];
+      st.lb[vo + j] = static_cast<const double*>(pk.src[1])[so];
+      st.ub[vo + j] = static_cast<const double*>(pk.src[2])[so];
+      st.scale[vo + j] = static_cast<const double*>(pk.src[3])[so];
     }
     double sc = redo ? st.scale_in[vo + j] : st.scale[vo + j];
     if (!redo) st.scale_in[vo + j] = sc;
@@ -91,9 +99,10 @@ __global__ __launch_bounds__(NS_NT) void trf_prep_kernel(TrfState st, int jac_sc
 }
 
 hipError_t launch_trf_prep(const TrfState& st, int jac_scaling, int from_gram, const int* sel,
-                           int redo, hipStream_t s) {
+                           int redo, hipStream_t s, const PackVecs* pk) {
+  const PackVecs none{{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}, nullptr, 0};
   hipLaunchKernelGGL(trf_prep_kernel, dim3(st.B), dim3(NS_NT), 0, s, st, jac_scaling, from_gram, sel,
-                     redo);
+                     redo, (pk && !sel) ? *pk : none);
   return hipGetLastError();
 }
 
