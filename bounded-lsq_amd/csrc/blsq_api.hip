@@ -68,6 +68,7 @@ struct blsq_ctx {
                                     // ([0..3] one-shot read-backs, [32 + 4 r ..] the slot of Newton round r)
   int pub_seq = 0;                  // sequence number of the last publish()
   bool pub_direct = true;           // BLSQ_PUBLISH = 0: hipMemcpyAsync + event instead of the publishing kernel
+  bool fuse_pack = true;            // BLSQ_FUSE_PACK = 0: the caller's vectors are packed by a launch of their own
   hipEvent_t lm_ev[2] = {nullptr, nullptr};   // read-back of the counter of round r has landed (r & 1)
   long long gram_fast = 0, gram_fallback = 0;   // problems factored by the normal equations / handed to the QR tree
   unsigned long long* cq_accept_dev = nullptr;  // device counter: rejected problems the CholeskyQR2 tier factored
@@ -740,6 +741,7 @@ extern "C" int blsq_ctx_create(int device_id, blsq_ctx** out) {
   if (e != hipSuccess) { hipStreamDestroy(c->stream); delete c; return (int)e; }
   memset(c->pinned, 0, 128 * sizeof(int));
   { const char* pe = getenv("BLSQ_PUBLISH"); c->pub_direct = !(pe && pe[0] == '0'); }
+  { const char* pe = getenv("BLSQ_FUSE_PACK"); c->fuse_pack = !(pe && pe[0] == '0'); }
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->lm_ev[i], hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc((void**)&c->cq_accept_dev, sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemset(c->cq_accept_dev, 0, sizeof(unsigned long long));
@@ -1154,10 +1156,6 @@ int trf_gate_tail(blsq_trf_plan* p, const GramCholArgs& c, bool full = true) {
   return 0;
 }
 
-static bool fuse_pack() {
-  static const bool on = [] { const char* e = getenv("BLSQ_FUSE_PACK"); return !(e && e[0] == '0'); }();
-  return on;
-}
 // the deferred vectors of this factor call: handed to the prep launch (returns them), or — a masked call keeps the
 // other problems' state, so its prep launch cannot do the copy — packed by the stand-alone launch right here
 template <class Plan>
@@ -1536,7 +1534,7 @@ static int trf_put_bounds(blsq_trf_plan* p, const double* x, const double* lb, c
     PackVecs pv{{x, lb, ub, scale, nullptr}, {p->st.x, p->st.lb, p->st.ub, p->st.scale, nullptr},
                 (zero_counts && p->tree.gram) ? p->tree.fb_count() : nullptr, 3};
     p->pack_pend = false;
-    if (zero_counts && p->tree.gram && fuse_pack()) {   // (the Gram stage's prep launch does it: trf_gram_stage)
+    if (zero_counts && p->tree.gram && ctx->fuse_pack) {   // (the Gram stage's prep launch does it: trf_gram_stage)
       p->pack_pv = pv; p->pack_pend = true;
       p->tree.fb_zeroed = true;
       return 0;
@@ -2050,7 +2048,7 @@ int dog_put(blsq_dogbox_plan* p, const double* x, const double* lb, const double
     PackVecs pv{{x, lb, ub, scale, on_bound}, {p->st.x, p->st.lb, p->st.ub, p->st.scale, p->st.on_bound},
                 (zero_counts && p->tree.gram) ? p->tree.fb_count() : nullptr, 3};
     p->pack_pend = false;
-    if (zero_counts && p->tree.gram && fuse_pack()) {   // (the Gram stage's prep launch does it: dog_factor_core)
+    if (zero_counts && p->tree.gram && ctx->fuse_pack) {   // (the Gram stage's prep launch does it: dog_factor_core)
       p->pack_pv = pv; p->pack_pend = true;
       p->tree.fb_zeroed = true;
       return 0;

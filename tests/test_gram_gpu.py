@@ -600,6 +600,57 @@ def test_optimistic_verdict_of_the_dogbox_device_api(bl, monkeypatch):
             assert np.array_equal(x1, x0)
 
 
+@pytest.mark.parametrize("solver", ["trf", "dogbox"])
+def test_counter_and_vector_routes_of_the_device_api_give_the_same_bits(bl, monkeypatch, solver):
+    """Two routes of the device-resident calls that change no arithmetic: the verdict / Newton-round counters reach
+    the host through a one-lane kernel and a polled pinned slot (BLSQ_PUBLISH = 0: hipMemcpyAsync + event), and the
+    caller's x / lb / ub / scale / on_bound are packed into the state layout by the prep launch (BLSQ_FUSE_PACK = 0:
+    by a launch of their own in front of the Gram).  Right and wrong guesses, two calls on the same plan, several
+    Newton rounds: same bits, same path statistics on every combination."""
+    from bounded_lsq import _synth, _abi
+    B, m, n = 6, 700, 64
+    if solver == "trf":
+        good = _synth.trf_batch(464, B, m, n)
+        keys = ("J", "f", "x", "lb", "ub", "scale")
+        Delta = np.array([0.5, 0.05, 5.0, 0.2, 0.3, 1.0])
+    else:
+        good = _synth.dogbox_batch(500, B, m, n)
+        keys = ("J", "f", "x", "lb", "ub", "scale", "on_bound")
+        Delta = np.full(B, 0.05)
+    mixed = {k: v.copy() for k, v in good.items()}
+    mixed["J"][2] = _equicorrelated(1, m, n, 1 - 1e-9, 3)[0]            # fails the certificate
+    mixed["lb"][2] = -np.inf; mixed["ub"][2] = np.inf
+    if solver == "dogbox":
+        mixed["on_bound"][2] = 0
+    for P, expect_fb in ((good, 0), (mixed, 1)):
+        outs = []
+        for publish, fuse in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+            monkeypatch.setenv("BLSQ_PUBLISH", publish)
+            monkeypatch.setenv("BLSQ_FUSE_PACK", fuse)
+            ctx = _abi.Context(0)
+            sol = (bl.TrfStepSolver if solver == "trf" else bl.DogboxStepSolver)(B, m, n, ctx=ctx)
+            d = {k: ctx.to_device(P[k]) for k in keys}
+            extra = [ctx.to_device(Delta)] + ([ctx.to_device(np.zeros(B))] if solver == "trf" else [])
+            ctx.gram_stats(reset=True)
+            for _ in range(3):
+                sol.factor_dev(*[d[k] for k in keys])
+                sol.step_dev(*extra)
+            S = sol.fetch_step()
+            assert ctx.gram_stats() == (3 * (B - expect_fb), 3 * expect_fb), (publish, fuse)
+            if solver == "trf":
+                outs.append((S.step.copy(), np.asarray(S.alpha).copy(), np.asarray(S.n_iter).copy(), S.hits.copy(),
+                             sol.fetch_factor().g.copy()))
+            else:
+                outs.append((S.step.copy(), S.on_bound_new.copy(), S.predicted_reduction.copy()))
+            sol.close()
+            for v in list(d.values()) + extra:
+                ctx.free(v)
+            ctx.close()
+        for o in outs[1:]:
+            for x1, x0 in zip(outs[0], o):
+                assert np.array_equal(x1, x0)
+
+
 def test_direct_kernel_wave_counts(bl, monkeypatch):
     """Narrow problems (at most four column tiles): the direct Gram kernel runs two, four or eight
     waves per workgroup by the row count (about 256 rows per wave; BLSQ_GRAM_DIRECT_NW forces one).
