@@ -209,12 +209,14 @@ __device__ void tri_matvec(const double* R, const double* dvec, int n, int ld, c
         if (i < n && j < n) acc[r] = fma(dvec ? rv[r] * dvec[j] : rv[r], svec[j], acc[r]);
       }
     }
+    // (the eight row totals by one transposed butterfly: the tree of wave_sum for each of them, see tri_matvec3)
+    static_assert(RB == 8, "one sixteen-value reduction");
+    double v[16];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      const int i = i0 + r * NS_NW;
-      const double t = wave_sum(acc[r]);
-      if (lane == 0 && i < n) u[i] = t;
-    }
+    for (int r = 0; r < RB; ++r) { v[r] = acc[r]; v[8 + r] = 0.0; }
+    wave_sum16(v);
+    const int idx = wave_sum16_index(lane), ri = i0 + (idx & 7) * NS_NW;
+    if (lane < 16 && idx < 8 && ri < n) u[ri] = v[0];
   }
   __syncthreads();
 }
@@ -255,40 +257,57 @@ __device__ void full_matvec(const double* M, int n, int ld, const double* svec, 
 __device__ void tri_matvec3(const double* R, const double* dvec, int n, int ld, const double* s1,
                             double* u1, const double* s2, double* u2, const double* g3, double* u3) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  constexpr int RB = 8;
+  // Four rows x four 64-column chunks per wave pass: sixteen loads in flight (a pass of eight rows x one chunk
+  // was 32 dependent memory round trips for ONE 256-variable problem — 38 of the step kernel's 52 us,
+  // tools/step_stamps.py).  Per row the products are accumulated chunk after chunk as before: same bits.
+  constexpr int RB = 8, JU = 1;
   for (int i0 = w; i0 < n; i0 += NS_NW * RB) {
     double a1[RB], a2[RB], a3[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) { a1[r] = 0.0; a2[r] = 0.0; a3[r] = 0.0; }
-    for (int jj = 0; i0 + lane + jj < n; jj += WAVE) {
-      double rv[RB];
+    for (int jj = 0; i0 + jj < n; jj += WAVE * JU) {        // (wave-uniform: the longest row, i0)
+      double rv[JU][RB];
 #pragma unroll
-      for (int r = 0; r < RB; ++r) {
-        const int i = i0 + r * NS_NW;
-        const int ic = (i < n) ? i : n - 1;
-        const int j = ic + lane + jj;
-        rv[r] = R[(long)ic * ld + ((j < n) ? j : n - 1)];
+      for (int q = 0; q < JU; ++q) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const int i = i0 + r * NS_NW;
+          const int ic = (i < n) ? i : n - 1;
+          const int j = ic + lane + jj + WAVE * q;
+          rv[q][r] = R[(long)ic * ld + ((j < n) ? j : n - 1)];
+        }
       }
 #pragma unroll
-      for (int r = 0; r < RB; ++r) {
-        const int i = i0 + r * NS_NW;
-        const int j = i + lane + jj;
-        if (i < n && j < n) {
-          const double rd = dvec ? rv[r] * dvec[j] : rv[r];
-          a1[r] = fma(rd, s1[j], a1[r]);
-          if (s2) a2[r] = fma(rd, s2[j], a2[r]);
-          a3[r] = fma(rd, -g3[j], a3[r]);
+      for (int q = 0; q < JU; ++q) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const int i = i0 + r * NS_NW;
+          const int j = i + lane + jj + WAVE * q;
+          if (i < n && j < n) {
+            const double rd = dvec ? rv[q][r] * dvec[j] : rv[q][r];
+            a1[r] = fma(rd, s1[j], a1[r]);
+            if (s2) a2[r] = fma(rd, s2[j], a2[r]);
+            a3[r] = fma(rd, -g3[j], a3[r]);
+          }
         }
       }
     }
+    // The 24 row totals by two transposed butterflies (wave_sum16: the same tree as wave_sum for every one of them — xor 1,
+    // 2, 4, 8 inside the 16-lane rows, then (r0 + r16) + (r32 + r48) — in 15 exchanges per sixteen totals instead of 64).
+    static_assert(RB == 8, "two sixteen-value reductions");
+    double v[16];
+    const int idx = wave_sum16_index(lane), ri = i0 + (idx & 7) * NS_NW;
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      const int i = i0 + r * NS_NW;
-      const double t1 = wave_sum(a1[r]);
-      const double t2 = s2 ? wave_sum(a2[r]) : 0.0;
-      const double t3 = wave_sum(a3[r]);
-      if (lane == 0 && i < n) { u1[i] = t1; if (s2) u2[i] = t2; u3[i] = t3; }
+    for (int r = 0; r < RB; ++r) { v[r] = a1[r]; v[8 + r] = s2 ? a2[r] : 0.0; }
+    wave_sum16(v);
+    if (lane < 16 && ri < n) {
+      if (idx < 8) u1[ri] = v[0];
+      else if (s2) u2[ri] = v[0];
     }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) { v[r] = a3[r]; v[8 + r] = 0.0; }
+    wave_sum16(v);
+    if (lane < 16 && idx < 8 && ri < n) u3[ri] = v[0];
   }
   __syncthreads();
 }
@@ -357,6 +376,13 @@ __device__ double quad_min_dev(double a, double b, double lo, double hi) {
 // the matrix streams from HBM: 0.118 -> 0.106 ms at 4096 x 256 x 512; for small n the extra
 // accumulators cost occupancy — 0.042 -> 0.060 ms at 512 x 64 x 1024 — so those keep three passes).
 // Same results bit for bit.
+#ifdef BLSQ_CHOL_STAMPS
+__device__ long long g_step_st[32];                    // phases of ONE problem's step (diagnostic build; tools/step_stamps.py)
+#define SST(i) do { if (b == 0 && tid == 0) g_step_st[i] = (long long)wall_clock64(); } while (0)
+int step_debug_stamps(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_step_st), sizeof(g_step_st)); }
+#else
+#define SST(i) do { } while (0)
+#endif
 template <bool MV3>
 __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int* lm_fast,
                                                          const double* lm_ph, const double* lm_sc,
@@ -397,6 +423,7 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
   const double theta = st.theta[b];
   int status = 0;
 
+  SST(0);
   // ---------------- solve_lsq_trust_region (trust_region.py:56-152) --------
   const double smax = st.srange[2 * b], smin = st.srange[2 * b + 1];
   bool full_rank = false;
@@ -409,13 +436,6 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     if (!gp) tri_matvec(Rh, dg, n, ld, svec, u);
     else if (fast) tri_matvec(X, nullptr, n, ld, svec, u);
     else full_matvec(X, n, ld, svec, u);
-  };
-  // u1 = J_h s1, u2 = J_h s2 (s2 may be null), u3 = J_h (-g3) in one pass over the matrix
-  auto model_mv3 = [&](const double* s1, double* u1, const double* s2, double* u2, const double* g3,
-                       double* u3) {
-    if (!gp) tri_matvec3(Rh, dg, n, ld, s1, u1, s2, u2, g3, u3);
-    else if (fast) tri_matvec3(X, nullptr, n, ld, s1, u1, s2, u2, g3, u3);
-    else full_matvec3(X, n, ld, s1, u1, s2, u2, g3, u3);
   };
   if (fast) {
     for (int j = tid; j < n; j += NS_NT) ph[j] = lm_ph[vo + j];
@@ -518,12 +538,14 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
   }
   __syncthreads();
 
+  SST(1);
   // ---------------- feasibility of x + p (trf.py:286-292) ------------------
   const double to_bound = step_to_bound_dev(cx, xg, tmp, tmp2);
   for (int j = tid; j < n; j += NS_NT) {
     const long long hit = (tmp2[j] == to_bound) ? (long long)sign_of(tmp[j]) : 0;
     out.hits[vo + j] = hit;
   }
+  SST(2);
   int branch, choice = 0;
   double qp[3] = {0.0, 0.0, 0.0};
   const double* step_h;
@@ -533,9 +555,10 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     branch = 0;
     const double tt = theta * to_bound;
     const double f = (tt < 1.0) ? tt : 1.0;                  // min(theta*to_bound, 1)
-    for (int j = tid; j < n; j += NS_NT) ph[j] *= f;
+    for (int j = tid; j < n; j += NS_NT) { ph[j] *= f; tmp[j] = dg[j]; }   // (d staged in LDS: tmp = p is done with)
     __syncthreads();
-    model_mv(ph, up);
+    if (!gp) tri_matvec(Rh, tmp, n, ld, ph, up);
+    else model_mv(ph, up);
     const double q2 = dot_dev(up, up, n, red);
     double dq = 0.0, lin = 0.0;
     for (int j = tid; j < n; j += NS_NT) {
@@ -564,6 +587,7 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
       tmp[j] = dg[j] * rh[j];                                // r = d * r_h
     }
     __syncthreads();
+    SST(3);
     // intersect_trust_region(p_h, r_h, Delta) (trust_region.py:11-44)
     const double ia = dot_dev(rh, rh, n, red);
     const double ib = dot_dev(ph, rh, n, red);
@@ -577,6 +601,7 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
       const double t1 = qq / ia, t2 = ic / qq;
       to_tr = (t1 < t2) ? t2 : t1;
     }
+    SST(4);
     double* steps2 = coef;
     double to_b2 = step_to_bound_dev(cx, tmp2, tmp, steps2);
     to_b2 *= theta;
@@ -584,14 +609,22 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     double r_lo;
     if (r_hi > 0.0) r_lo = (1.0 - theta) * p_stride / r_hi;
     else r_lo = -1.0;
+    SST(5);
     // J_h p_h (stride-scaled), J_h r_h (if the reflected step exists) and J_h (-g_h) in one pass
     const bool need_r = (status == 0 && r_lo <= r_hi);
     if constexpr (MV3) {
-      model_mv3(ph, up, need_r ? rh : nullptr, ur, gh, ug);
+      // (d and g_h staged in LDS — tmp and tmp2 are free from here to the gradient step: the pass reads them once per
+      //  matrix element, and from global memory every one of those reads was a dependent load in front of its fma)
+      for (int j = tid; j < n; j += NS_NT) { tmp[j] = dg[j]; tmp2[j] = gh[j]; }
+      __syncthreads();
+      if (!gp) tri_matvec3(Rh, tmp, n, ld, ph, up, need_r ? rh : nullptr, ur, tmp2, ug);
+      else if (fast) tri_matvec3(X, nullptr, n, ld, ph, up, need_r ? rh : nullptr, ur, tmp2, ug);
+      else full_matvec3(X, n, ld, ph, up, need_r ? rh : nullptr, ur, tmp2, ug);
     } else {
       model_mv(ph, up);
       if (need_r) model_mv(rh, ur);
     }
+    SST(6);
     bool have_r = false;
     double r_t = 0.0;
     if (need_r) {
@@ -605,6 +638,7 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
       r_t = quad_min_dev(qa, qb, r_lo, r_hi);
       have_r = true;
     }
+    SST(7);
     // r_h = p_h + r_h * r_stride ;  p_h *= theta
     for (int j = tid; j < n; j += NS_NT) {
       const double pj = ph[j];
@@ -618,6 +652,7 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     __syncthreads();
     double to_bg = step_to_bound_dev(cx, xg, tmp, steps2);
     to_bg *= theta;
+    SST(8);
     const double ghn = sqrt(dot_dev(gh, gh, n, red));
     const double to_trg = Delta / ghn;
     double g_hi = (to_trg < to_bg) ? to_trg : to_bg;
@@ -631,6 +666,7 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     const double g_t = quad_min_dev(ga, gb, 0.0, g_hi);
     for (int j = tid; j < n; j += NS_NT) tmp[j] = -g_t * gh[j];   // c_h
     __syncthreads();
+    SST(9);
     // ---- evaluate_quadratic_function on [p_h, r_h, c_h] (trf.py:79-102) ----
     // J_h p_h(final) = theta * up ;  J_h r_h = up + r_t ur ;  J_h c_h = g_t * ug
     double q0 = 0.0, q1 = 0.0, q2 = 0.0;
@@ -659,6 +695,7 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     step_h = (choice == 0) ? ph : ((choice == 1) ? rh : tmp);
   }
 
+  SST(10);
   // ---------------- step, x_new (trf.py:301-308,318-324) -------------------
   const double pred = -2.0 * qp[choice];
   double sn2 = 0.0, corr = 0.0;
@@ -687,6 +724,7 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     }
     out.active_new[vo + j] = act;
   }
+  SST(11);
   sn2 = block_sum(sn2, red);
   corr = block_sum(corr, red);
   if (tid == 0) {
@@ -696,6 +734,7 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     int* inf = out.info + (long)b * 4;
     inf[0] = n_iter; inf[1] = branch; inf[2] = choice; inf[3] = status;
   }
+  SST(12);
 }
 
 hipError_t launch_trf_step(const TrfState& st, const LmState* lm, const double* Delta,
