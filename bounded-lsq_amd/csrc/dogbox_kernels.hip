@@ -17,16 +17,40 @@ static constexpr int DG_NT = 256;
 static constexpr int DG_NW = DG_NT / WAVE;
 static constexpr double EPS = 2.220446049250313e-16;
 
-// u = R s  (R upper triangular n x n, row-major, stride ld): one wave per row
+// u = R s  (R upper triangular n x n, row-major, stride ld): one wave per row, eight rows per wave pass — their
+// loads in flight together (a row at a time was a memory round trip per row: 16 in a row for n = 64, most of the step
+// kernel's 19 us), their eight totals by one transposed butterfly (wave_sum16: the tree of wave_sum for each).  Per row
+// the products are accumulated in the same order as before: same bits.
 __device__ static void tri_matvec_d(const double* R, int n, int ld, const double* svec,
                                     double* u) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int i = w; i < n; i += DG_NW) {
-    const double* row = R + (long)i * ld;
-    double acc = 0.0;
-    for (int j = i + lane; j < n; j += WAVE) acc = fma(row[j], svec[j], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) u[i] = acc;
+  constexpr int RB = 8;
+  for (int i0 = w; i0 < n; i0 += DG_NW * RB) {
+    double acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = 0.0;
+    for (int jj = 0; i0 + jj < n; jj += WAVE) {             // (wave-uniform: the longest row, i0)
+      double rv[RB];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int i = i0 + r * DG_NW;
+        const int ic = (i < n) ? i : n - 1;
+        const int j = ic + lane + jj;
+        rv[r] = R[(long)ic * ld + ((j < n) ? j : n - 1)];
+      }
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int i = i0 + r * DG_NW;
+        const int j = i + lane + jj;
+        if (i < n && j < n) acc[r] = fma(rv[r], svec[j], acc[r]);
+      }
+    }
+    double v[16];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) { v[r] = acc[r]; v[8 + r] = 0.0; }
+    wave_sum16(v);
+    const int idx = wave_sum16_index(lane), ri = i0 + (idx & 7) * DG_NW;
+    if (lane < 16 && idx < 8 && ri < n) u[ri] = v[0];
   }
   __syncthreads();
 }
