@@ -69,6 +69,7 @@ struct blsq_ctx {
   int pub_seq = 0;                  // sequence number of the last publish()
   bool pub_direct = true;           // BLSQ_PUBLISH = 0: hipMemcpyAsync + event instead of the publishing kernel
   bool fuse_pack = true;            // BLSQ_FUSE_PACK = 0: the caller's vectors are packed by a launch of their own
+  bool pub_ride = true;             // BLSQ_PUBLISH_RIDE = 0: the verdict's counters get a publishing launch of their own
   hipEvent_t lm_ev[2] = {nullptr, nullptr};   // read-back of the counter of round r has landed (r & 1)
   long long gram_fast = 0, gram_fallback = 0;   // problems factored by the normal equations / handed to the QR tree
   unsigned long long* cq_accept_dev = nullptr;  // device counter: rejected problems the CholeskyQR2 tier factored
@@ -675,6 +676,8 @@ struct blsq_trf_plan {
   int* pend_pin = nullptr;          // 4 pinned ints of this plan ([3]: sequence number of the publish)
   hipEvent_t pend_ev = nullptr;
   int pend_seq = 0;
+  bool pend_unpub = false;          // the verdict's counters have not been sent yet: the step kernel of the next
+                                    // step call stores them on its way in (or verdict_published() sends them now)
   // the caller's vectors of a device-resident factor call, copied into the state layout by the prep launch
   // (BLSQ_FUSE_PACK = 0: by a pack_vecs launch in front of the Gram, as before)
   bool pack_pend = false;
@@ -704,6 +707,8 @@ struct blsq_dogbox_plan {
   int* pend_pin = nullptr;
   hipEvent_t pend_ev = nullptr;
   int pend_seq = 0;
+  bool pend_unpub = false;          // the verdict's counters have not been sent yet: the step kernel of the next
+                                    // step call stores them on its way in (or verdict_published() sends them now)
   // the caller's vectors of a device-resident factor call, copied into the state layout by the prep launch
   // (BLSQ_FUSE_PACK = 0: by a pack_vecs launch in front of the Gram, as before)
   bool pack_pend = false;
@@ -742,6 +747,7 @@ extern "C" int blsq_ctx_create(int device_id, blsq_ctx** out) {
   memset(c->pinned, 0, 128 * sizeof(int));
   { const char* pe = getenv("BLSQ_PUBLISH"); c->pub_direct = !(pe && pe[0] == '0'); }
   { const char* pe = getenv("BLSQ_FUSE_PACK"); c->fuse_pack = !(pe && pe[0] == '0'); }
+  { const char* pe = getenv("BLSQ_PUBLISH_RIDE"); c->pub_ride = !(pe && pe[0] == '0'); }
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->lm_ev[i], hipEventDisableTiming);
   if (e == hipSuccess) e = hipMalloc((void**)&c->cq_accept_dev, sizeof(unsigned long long));
   if (e == hipSuccess) e = hipMemset(c->cq_accept_dev, 0, sizeof(unsigned long long));
@@ -1169,6 +1175,25 @@ static int take_pack(Plan* p, const int* mask, const PackVecs** pk) {
   return 0;
 }
 
+// The counters of a pending verdict are on their way to the host (a stand-alone publish unless a step kernel has
+// taken them along) — to be called before anything waits for them or overwrites them.
+template <class Plan>
+static int verdict_published(Plan* p) {
+  if (!p->pend_unpub) return 0;
+  p->pend_unpub = false;
+  blsq_ctx* ctx = p->ctx;
+  HIPCHK(ctx, ctx->publish(p->tree.fb_count(), 3, p->pend_pin, p->pend_ev, &p->pend_seq));
+  return 0;
+}
+// ... and the arguments with which the step kernel of this call takes them along (dst == nullptr: nothing to do)
+template <class Plan>
+static PublishArgs verdict_rides(Plan* p) {
+  if (!p->pend_unpub) return PublishArgs{nullptr, 0, nullptr, 0};
+  p->pend_unpub = false;
+  p->pend_seq = ++p->ctx->pub_seq;
+  return PublishArgs{p->tree.fb_count(), 3, p->pend_pin, p->pend_seq};
+}
+
 // prep from the Gram, Cholesky of H with the pivot gate, conditioning gate; *nfb = problems of this
 // call that must go to the Householder tree (their indices are flagged in tree.fb_mask()).
 int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, bool defer = false) {
@@ -1200,7 +1225,8 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, 
     p->lm.colinfo = p->aug_colinfo.as<double>();
   } else if ((rc = trf_gate_tail(p, c, mask == nullptr))) return rc;
   if (defer) {                              // the counters travel; the verdict is read by trf_resolve
-    HIPCHK(ctx, ctx->publish(t.fb_count(), 3, p->pend_pin, p->pend_ev, &p->pend_seq));
+    p->pend_unpub = ctx->pub_direct && ctx->pub_ride;
+    if (!p->pend_unpub) HIPCHK(ctx, ctx->publish(t.fb_count(), 3, p->pend_pin, p->pend_ev, &p->pend_seq));
     p->pending = true; p->pend_tail = skip_tail;
     *nfb = 0;
     p->gate_done = true;
@@ -1256,7 +1282,8 @@ int trf_factor_core(blsq_trf_plan* p, const double* dJ, const double* df, int ld
     // a verdict nobody asked for belongs to a factor that is being overwritten: no repair, but it is still
     // read — the path statistics and the decision whether to guess again depend on it
     p->pending = false;
-    HIPCHK(ctx, ctx->await(p->pend_pin, p->pend_ev, p->pend_seq));
+    { int rc_ = verdict_published(p); if (rc_) return rc_; }
+  HIPCHK(ctx, ctx->await(p->pend_pin, p->pend_ev, p->pend_seq));
     const int nfb_ = p->pend_pin[0], njac_ = p->pend_pin[1];
     if (p->pend_tail) { if (!(p->ld <= 80 && p->pend_pin[2] == 0)) p->guess_settled = false; }
     else if (nfb_ > 0 || njac_ > 0) {
@@ -1288,6 +1315,7 @@ int trf_resolve(blsq_trf_plan* p, bool* redo) {
   if (!p->pending) return 0;
   blsq_ctx* ctx = p->ctx;
   p->pending = false;
+  { int rc_ = verdict_published(p); if (rc_) return rc_; }
   HIPCHK(ctx, ctx->await(p->pend_pin, p->pend_ev, p->pend_seq));
   int nfb = p->pend_pin[0], njac = p->pend_pin[1];
   const bool settled = (p->ld <= 80 && p->pend_pin[2] == 0);
@@ -1562,8 +1590,9 @@ extern "C" int blsq_trf_factor_dev(blsq_trf_plan* p, const double* dJ, const dou
   if (!dscale_io) return ctx->bad(7, "scale is NULL");
   if (scale_mode < 0 || scale_mode > 2) return ctx->bad(8, "scale_mode");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  int rc = trf_put_bounds(p, dx, dlb, dub, dscale_io, hipMemcpyDeviceToDevice, true);
+  int rc = verdict_published(p);               // (a verdict nobody read: its counters leave before they are cleared)
   if (rc) return rc;
+  if ((rc = trf_put_bounds(p, dx, dlb, dub, dscale_io, hipMemcpyDeviceToDevice, true))) return rc;
   p->pend_scale_io = dscale_io;
   if ((rc = trf_factor_core(p, dJ, df, p->n, scale_mode, nullptr, true))) return rc;
   if (scale_mode != BLSQ_SCALE_GIVEN) {
@@ -1586,8 +1615,9 @@ extern "C" int blsq_trf_step_dev(blsq_trf_plan* p, const double* dDelta, const d
     int rc = trf_lm_rounds(p, dDelta, dalpha_in);
     if (rc) return rc;
     ctx->begin(K_STEP);
+    const PublishArgs pub = verdict_rides(p);
     hipError_t e = launch_trf_step(p->st, &p->lm, dDelta, dalpha_in, active_rtol, p->out,
-                                   ctx->stream);
+                                   ctx->stream, &pub);
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_trf_step");
     p->lm_counts_clean = true;              // (the step kernel leaves the round counters zeroed)
@@ -2183,7 +2213,8 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
   int rc;
   if (p->pending) {                         // (as trf_factor_core: read the dropped verdict, no repair)
     p->pending = false;
-    HIPCHK(ctx, ctx->await(p->pend_pin, p->pend_ev, p->pend_seq));
+    { int rc_ = verdict_published(p); if (rc_) return rc_; }
+  HIPCHK(ctx, ctx->await(p->pend_pin, p->pend_ev, p->pend_seq));
     const int nfb_ = p->pend_pin[0], njac_ = p->pend_pin[1];
     if (p->pend_tail) { if (!(p->ld <= 80 && p->pend_pin[2] == 0)) p->guess_settled = false; }
     else if (nfb_ > 0 || njac_ > 0) {
@@ -2219,7 +2250,8 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
   if (!skip_tail && (rc = dog_gate_tail(p, c))) return rc;
   int nfb = 0;
   if (defer) {                              // guess: nobody leaves the path, nobody needs the SVD (dog_resolve checks)
-    HIPCHK(ctx, ctx->publish(t.fb_count(), 3, p->pend_pin, p->pend_ev, &p->pend_seq));
+    p->pend_unpub = ctx->pub_direct && ctx->pub_ride;
+    if (!p->pend_unpub) HIPCHK(ctx, ctx->publish(t.fb_count(), 3, p->pend_pin, p->pend_ev, &p->pend_seq));
     p->pending = true; p->pend_tail = skip_tail;
     p->pend_dJ = dJ; p->pend_df = df; p->pend_ldJ = ldJ; p->pend_scale_mode = scale_mode;
     p->gate_done = true;
@@ -2252,6 +2284,7 @@ int dog_resolve(blsq_dogbox_plan* p, bool* redo) {
   blsq_ctx* ctx = p->ctx;
   QrTree& t = p->tree;
   p->pending = false;
+  { int rc_ = verdict_published(p); if (rc_) return rc_; }
   HIPCHK(ctx, ctx->await(p->pend_pin, p->pend_ev, p->pend_seq));
   int nfb = p->pend_pin[0], njac = p->pend_pin[1];
   const bool settled = (p->ld <= 80 && p->pend_pin[2] == 0);
@@ -2349,7 +2382,9 @@ extern "C" int blsq_dogbox_factor_dev(blsq_dogbox_plan* p, const double* dJ, con
   if (scale_mode < 0 || scale_mode > 2) return ctx->bad(8, "scale_mode");
   if (!don_bound) return ctx->bad(9, "on_bound is NULL");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  int rc = dog_put(p, dx, dlb, dub, dscale_io, don_bound, hipMemcpyDeviceToDevice, true);
+  int rc = verdict_published(p);               // (a verdict nobody read: its counters leave before they are cleared)
+  if (rc) return rc;
+  rc = dog_put(p, dx, dlb, dub, dscale_io, don_bound, hipMemcpyDeviceToDevice, true);
   if (rc) return rc;
   p->pend_scale_io = dscale_io;
   if ((rc = dog_factor_core(p, dJ, df, p->n, scale_mode, nullptr, true))) return rc;
@@ -2368,7 +2403,8 @@ extern "C" int blsq_dogbox_step_dev(blsq_dogbox_plan* p, const double* dDelta) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   for (int pass = 0; pass < 2; ++pass) {    // (pass 1 only after a wrong optimistic guess)
     ctx->begin(K_STEP);
-    hipError_t e = launch_dog_step(p->st, dDelta, p->out, ctx->stream);
+    const PublishArgs pub = verdict_rides(p);
+    hipError_t e = launch_dog_step(p->st, dDelta, p->out, ctx->stream, &pub);
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_dog_step");
     bool redo = false;

@@ -281,9 +281,19 @@ struct TrfStepOut {       // device pointers
 // for the problems that still need the stacked QR, 0 for the rest (path / sel as the QR launch would see them)
 hipError_t launch_trf_aug_trivial(const TrfState& st, const int* path, int* mask, const int* sel, hipStream_t s);
 struct LmState;
+// Counters the host is waiting for, stored by the FIRST lane of a step kernel before anything else: [src[0 .. n), seq]
+// as one 16-byte write into the pinned slot dst (blsq_ctx::publish; dst == nullptr: nothing to publish).
+struct PublishArgs { const int* src; int n; int* dst; int seq; };
+__device__ __forceinline__ void publish_ints(const PublishArgs& pub) {
+  if (!pub.dst) return;
+  int4 v;
+  v.x = pub.n > 0 ? pub.src[0] : 0; v.y = pub.n > 1 ? pub.src[1] : 0; v.z = pub.n > 2 ? pub.src[2] : 0; v.w = pub.seq;
+  *reinterpret_cast<int4*>(pub.dst) = v;
+  __threadfence_system();
+}
 hipError_t launch_trf_step(const TrfState& st, const LmState* lm, const double* Delta,
                            const double* alpha_in, double active_rtol,
-                           const TrfStepOut& out, hipStream_t s);
+                           const TrfStepOut& out, hipStream_t s, const PublishArgs* pub = nullptr);
 
 // ------------------------------------------------ SVD-free TR sub-problem ----
 struct LmState {
@@ -389,7 +399,7 @@ struct DogStepOut {
   int* info;              // [B][4]: tr_hit, fallback, all_active, status
 };
 hipError_t launch_dog_step(const DogState& st, const double* Delta,
-                           const DogStepOut& out, hipStream_t s);
+                           const DogStepOut& out, hipStream_t s, const PublishArgs* pub = nullptr);
 
 
 // ------------------------------------------- batched outer drivers (8f-1) ----

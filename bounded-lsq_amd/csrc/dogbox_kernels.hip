@@ -247,10 +247,11 @@ __device__ static double to_box(const BoxCtx& c, const double* x0, const double*
 }
 
 __global__ __launch_bounds__(DG_NT) void dog_step_kernel(DogState st, const double* Delta_in,
-                                                         DogStepOut out) {
+                                                         DogStepOut out, PublishArgs pub) {
   extern __shared__ double sh[];
   __shared__ double red[32];
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (b == 0 && tid == 0) publish_ints(pub);            // (the verdict counters of the factor call: final since it ended)
   const int n = st.n, ld = st.ld;
   const long vo = (long)b * ld;
   const int N = st.ncols[b];
@@ -394,9 +395,10 @@ __global__ __launch_bounds__(DG_NT) void dog_step_kernel(DogState st, const doub
 }
 
 hipError_t launch_dog_step(const DogState& st, const double* Delta, const DogStepOut& out,
-                           hipStream_t s) {
+                           hipStream_t s, const PublishArgs* pub) {
   const size_t lds = sizeof(double) * 11 * (size_t)st.ld;
-  hipLaunchKernelGGL(dog_step_kernel, dim3(st.B), dim3(DG_NT), lds, s, st, Delta, out);
+  hipLaunchKernelGGL(dog_step_kernel, dim3(st.B), dim3(DG_NT), lds, s, st, Delta, out,
+                     pub ? *pub : PublishArgs{nullptr, 0, nullptr, 0});
   return hipGetLastError();
 }
 

@@ -388,10 +388,12 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
                                                          const double* lm_ph, const double* lm_sc,
                                                          const int* lm_st, const double* Delta_in,
                                                          const double* alpha_in,
-                                                         double active_rtol, TrfStepOut out, int* lm_counts) {
+                                                         double active_rtol, TrfStepOut out, int* lm_counts,
+                                                         PublishArgs pub) {
   extern __shared__ double sh[];
   __shared__ double red[32];
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (b == 0 && tid == 0) publish_ints(pub);            // (the verdict counters of the factor call: final since it ended)
   // (the Newton-round counters of the NEXT step call: the rounds of this one are over — a fill launch less)
   if (b == 0 && tid < 16 && lm_counts) lm_counts[tid] = 0;
   const int n = st.n, ld = st.ld, m = st.m;
@@ -739,16 +741,17 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
 
 hipError_t launch_trf_step(const TrfState& st, const LmState* lm, const double* Delta,
                            const double* alpha_in, double active_rtol, const TrfStepOut& out,
-                           hipStream_t s) {
+                           hipStream_t s, const PublishArgs* pub) {
+  const PublishArgs pa = pub ? *pub : PublishArgs{nullptr, 0, nullptr, 0};
   const size_t lds = sizeof(double) * 8 * (size_t)st.ld;
   if (st.n >= 128)
     hipLaunchKernelGGL(trf_step_kernel<true>, dim3(st.B), dim3(NS_NT), lds, s, st,
                        lm ? lm->fast : nullptr, lm ? lm->ph : nullptr, lm ? lm->sc : nullptr,
-                       lm ? lm->st : nullptr, Delta, alpha_in, active_rtol, out, lm ? lm->active_count : nullptr);
+                       lm ? lm->st : nullptr, Delta, alpha_in, active_rtol, out, lm ? lm->active_count : nullptr, pa);
   else
     hipLaunchKernelGGL(trf_step_kernel<false>, dim3(st.B), dim3(NS_NT), lds, s, st,
                        lm ? lm->fast : nullptr, lm ? lm->ph : nullptr, lm ? lm->sc : nullptr,
-                       lm ? lm->st : nullptr, Delta, alpha_in, active_rtol, out, lm ? lm->active_count : nullptr);
+                       lm ? lm->st : nullptr, Delta, alpha_in, active_rtol, out, lm ? lm->active_count : nullptr, pa);
   return hipGetLastError();
 }
 

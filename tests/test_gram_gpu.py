@@ -605,8 +605,9 @@ def test_counter_and_vector_routes_of_the_device_api_give_the_same_bits(bl, monk
     """Two routes of the device-resident calls that change no arithmetic: the verdict / Newton-round counters reach
     the host through a one-lane kernel and a polled pinned slot (BLSQ_PUBLISH = 0: hipMemcpyAsync + event), and the
     caller's x / lb / ub / scale / on_bound are packed into the state layout by the prep launch (BLSQ_FUSE_PACK = 0:
-    by a launch of their own in front of the Gram).  Right and wrong guesses, two calls on the same plan, several
-    Newton rounds: same bits, same path statistics on every combination."""
+    by a launch of their own in front of the Gram); the verdict's counters ride on the step kernel of the next step call
+    (BLSQ_PUBLISH_RIDE = 0: a publishing launch of their own at the end of the factor call).  Right and wrong guesses,
+    three calls on the same plan, several Newton rounds: same bits, same path statistics on every combination."""
     from bounded_lsq import _synth, _abi
     B, m, n = 6, 700, 64
     if solver == "trf":
@@ -624,9 +625,11 @@ def test_counter_and_vector_routes_of_the_device_api_give_the_same_bits(bl, monk
         mixed["on_bound"][2] = 0
     for P, expect_fb in ((good, 0), (mixed, 1)):
         outs = []
-        for publish, fuse in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+        for publish, fuse, ride in (("1", "1", "1"), ("0", "1", "1"), ("1", "0", "1"), ("0", "0", "1"), ("1", "1", "0"),
+                                    ("1", "0", "0")):
             monkeypatch.setenv("BLSQ_PUBLISH", publish)
             monkeypatch.setenv("BLSQ_FUSE_PACK", fuse)
+            monkeypatch.setenv("BLSQ_PUBLISH_RIDE", ride)
             ctx = _abi.Context(0)
             sol = (bl.TrfStepSolver if solver == "trf" else bl.DogboxStepSolver)(B, m, n, ctx=ctx)
             d = {k: ctx.to_device(P[k]) for k in keys}
@@ -636,7 +639,7 @@ def test_counter_and_vector_routes_of_the_device_api_give_the_same_bits(bl, monk
                 sol.factor_dev(*[d[k] for k in keys])
                 sol.step_dev(*extra)
             S = sol.fetch_step()
-            assert ctx.gram_stats() == (3 * (B - expect_fb), 3 * expect_fb), (publish, fuse)
+            assert ctx.gram_stats() == (3 * (B - expect_fb), 3 * expect_fb), (publish, fuse, ride)
             if solver == "trf":
                 outs.append((S.step.copy(), np.asarray(S.alpha).copy(), np.asarray(S.n_iter).copy(), S.hits.copy(),
                              sol.fetch_factor().g.copy()))
