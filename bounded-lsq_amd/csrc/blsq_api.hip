@@ -1392,6 +1392,8 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
   }
   int* pin = ctx->pinned + 32;                           // slot of round r: pin + 4 r
   int pin_seq[16] = {0};
+  bool rides[16] = {false};
+  int ride_rounds = 0;                                   // rounds [0, ride_rounds) are enqueued before their counter is read
   if (!p->lm_counts_clean) HIPCHK(ctx, hipMemsetAsync(counts, 0, 16 * sizeof(int), ctx->stream));
   p->lm_counts_clean = false;
   ctx->begin(K_LM_SOLVE);
@@ -1399,6 +1401,8 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_lm_start");
   auto read_back = [&](int r) -> hipError_t {            // counter of round r -> pin[r], event r & 1
+    // (a round that is enqueued ahead of its counter takes the counter along: lm_update_kernel of that round stores it)
+    if (ride_rounds > r && ctx->pub_direct && ctx->pub_ride) { rides[r] = true; return hipSuccess; }
     return ctx->publish(counts + r, 1, pin + 4 * r, ctx->lm_ev[r & 1], &pin_seq[r]);
   };
   auto landed = [&](int r) -> hipError_t { return ctx->await(pin + 4 * r, ctx->lm_ev[r & 1], pin_seq[r]); };
@@ -1435,13 +1439,14 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
     ctx->end();
     return ee;
   };
+  const bool chol_any = p->gram_valid && p->lm_enable && (p->use_chol || p->lm.hmax != nullptr) &&
+                        !(p->lm.fused_gram && !p->lm.hmax);
+  if (chol_any) ride_rounds = p->lm_rounds_last < 12 ? p->lm_rounds_last : 12;
   HIPCHK(ctx, read_back(0));
   // Run-ahead loop: whenever the Grams of the current problems are at hand.  Householder-path problems join
   // the Cholesky launch where their alpha allows it (LmState::hmax); the stacked QR of the round is enqueued
   // only while the batch holds such problems at all, over the same upper bound, and leaves at once for a
   // problem whose mask is 0.  Their triangles dirty the lm_Xa slots outside the factor: the solves never look.
-  const bool chol_any = p->gram_valid && p->lm_enable && (p->use_chol || p->lm.hmax != nullptr) &&
-                        !(p->lm.fused_gram && !p->lm.hmax);
   if (chol_any) {
     int bound = p->B;                                   // upper bound of the count of the round being enqueued
     int expect = p->lm_expect0 > 0 ? p->lm_expect0 : p->B;   // (kernel choice only: last call's first count)
@@ -1467,7 +1472,12 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
       }
       ctx->begin(K_LM_SOLVE);
       p->lm.round = round;
+      if (rides[round]) {
+        pin_seq[round] = ++ctx->pub_seq;
+        p->lm.pub = PublishArgs{counts + round, 1, pin + 4 * round, pin_seq[round]};
+      }
       e = launch_lm_update(p->lm, bound, ctx->stream);
+      p->lm.pub = PublishArgs{nullptr, 0, nullptr, 0};
       ctx->end();
       if (e != hipSuccess) return ctx->fail(e, "launch_lm_update");
       HIPCHK(ctx, read_back(round + 1));

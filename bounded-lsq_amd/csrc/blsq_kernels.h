@@ -320,6 +320,7 @@ struct LmState {
   const int* path;        // optional [B]: != 0 -> the problem's Newton systems are factored by QR,
                           // 0 -> by Cholesky of the modified Gram (nullptr: QR for all)
   int round;              // evaluation number of this launch (host-set)
+  PublishArgs pub{nullptr, 0, nullptr, 0};   // lm_update_kernel: the count of ITS round, sent to the host on the way in (host-set)
   const double* g_h;      // optional [B][ld]: the gradient of the scaled problem, d * (J^T f) (TrfState::g_h).
                           // ||A^T b|| of trust_region.py:119 for the augmented A = [J D; E], b = [f; 0] IS its
                           // norm; without it lm_start forms R_aug^T c_aug — one more pass over the triangle

@@ -171,6 +171,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_update_kernel(LmState lm) {
   extern __shared__ double sh[];
   __shared__ double red[32];
   // launched over the compacted list of evaluation lm.round; writes the next one
+  if (blockIdx.x == 0 && threadIdx.x == 0) publish_ints(lm.pub);   // (the count of this round: final since the last round ended)
   if ((int)blockIdx.x >= lm.active_count[lm.round]) return;   // (launched over an upper bound)
   const int b = lm.active_list[(long)(lm.round & 1) * lm.B + blockIdx.x];
   if (!lm.fast[b]) return;
