@@ -1232,13 +1232,15 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, 
     p->gate_done = true;
     p->njac = 0;
   } else {
-    HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 1, t.fb_count(), 3 * sizeof(int), hipMemcpyDeviceToHost,
-                               ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    *nfb = ctx->pinned[1];
+    // (the synchronous verdict: published and polled for — slot [4 .. 8) of the pinned ints — instead of a blit and a
+    //  stream synchronisation)
+    int seq = 0;
+    HIPCHK(ctx, ctx->publish(t.fb_count(), 3, ctx->pinned + 4, ctx->lm_ev[0], &seq));
+    HIPCHK(ctx, ctx->await(ctx->pinned + 4, ctx->lm_ev[0], seq));
+    *nfb = ctx->pinned[4];
     p->gate_done = (*nfb == 0);
-    p->njac = p->gate_done ? ctx->pinned[2] : -1;
-    if (!mask) p->guess_settled = (c.unsettled && ctx->pinned[3] == 0);
+    p->njac = p->gate_done ? ctx->pinned[5] : -1;
+    if (!mask) p->guess_settled = (c.unsettled && ctx->pinned[6] == 0);
   }
   t.note_paths(ctx, *nfb, mask != nullptr);
   p->path = t.path_rw();
@@ -1964,7 +1966,9 @@ extern "C" int blsq_tsqr_factor_dev(blsq_trf_plan* p, const double* dJ_block, co
   if (p->nranks > 1 && (!ctx->comm || ctx->comm_ranks != p->nranks))
     return ctx->bad(1, "the plan's ranks need a communicator of that size on this ctx (blsq_comm_init)");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  int rc = trf_put_bounds(p, dx, dlb, dub, dscale_io, hipMemcpyDeviceToDevice);
+  // (zero_counts: with the normal-equations front end the prep launch of the Gram stage packs the vectors and clears the
+  //  gate counters — no pack launch, no fill)
+  int rc = trf_put_bounds(p, dx, dlb, dub, dscale_io, hipMemcpyDeviceToDevice, true);
   if (rc) return rc;
   auto put_scale = [&]() -> int {
     if (scale_mode != BLSQ_SCALE_GIVEN)
