@@ -1127,11 +1127,11 @@ GramCholArgs trf_chol_args(blsq_trf_plan* p, const int* mask) {
     const char* oe = getenv("BLSQ_CERT_DIRECT");          // 0: every open problem through the norm stage (explicit inverse)
     c.cert_open = (oe && oe[0] == '0') ? nullptr : p->aug_open.as<double>();
   }
-  if (p->ld <= 80) {                        // (the register-resident kernel also does the rank gate's sure case)
-    c.lmfin.fast = p->lm.fast; c.lmfin.ncols_jac = p->lm.ncols_jac; c.lmfin.sc = p->lm.sc; c.lmfin.st = p->lm.st;
-    c.unsettled = t.fb_count() + 2;
-    c.lmfin.m = p->lm.m; c.lmfin.enable = (p->lm_gate_mask >> 1) & 1;
-  }
+  // (N <= 80: the register-resident factor kernel also does the rank gate's sure case; N > 80: stage 0 of the certificate
+  //  does — gram_cert0_kernel — for the problems it certifies.  `unsettled` counts the others.)
+  c.lmfin.fast = p->lm.fast; c.lmfin.ncols_jac = p->lm.ncols_jac; c.lmfin.sc = p->lm.sc; c.lmfin.st = p->lm.st;
+  c.unsettled = t.fb_count() + 2;
+  c.lmfin.m = p->lm.m; c.lmfin.enable = (p->lm_gate_mask >> 1) & 1;
   return c;
 }
 
@@ -1218,11 +1218,24 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, 
   // second guess (N <= 80): the Cholesky kernel settles EVERY problem itself — certificate by its first
   // bound, rank gate by the column-norm bound — as it did in the last call: then the certificate and gate
   // launches would both be empty and are not enqueued (trf_resolve checks the settled counter)
-  const bool skip_tail = defer && p->guess_settled && c.lmfin.fast != nullptr;
+  // N > 80: stage 0 of the certificate is still launched (it IS what settles a problem there) — the norm stage, the
+  // shifted factorisation and the rank gate, three launches that would find nothing to do, are not.
+  bool skip_tail = defer && p->guess_settled && c.lmfin.fast != nullptr;
+  if (skip_tail && p->ld > 80) {
+    const char* ce = getenv("BLSQ_CERT0");
+    const char* se = getenv("BLSQ_SETTLE0");              // 0: the whole gate tail for N > 80, as before
+    if (!c.cert_ym || (ce && ce[0] == '0') || (se && se[0] == '0')) skip_tail = false;
+  }
   int rc;
   if (skip_tail) {
     p->lm.path = t.path_rw();
     p->lm.colinfo = p->aug_colinfo.as<double>();
+    if (p->ld > 80) {
+      ctx->begin(K_GRAM_GATE);
+      e = launch_gram_gate(c, p->B, ctx->stream, /*stage0_only=*/true);
+      ctx->end();
+      if (e != hipSuccess) return ctx->fail(e, "launch_gram_gate(stage 0)");
+    }
   } else if ((rc = trf_gate_tail(p, c, mask == nullptr))) return rc;
   if (defer) {                              // the counters travel; the verdict is read by trf_resolve
     p->pend_unpub = ctx->pub_direct && ctx->pub_ride;
@@ -1287,7 +1300,7 @@ int trf_factor_core(blsq_trf_plan* p, const double* dJ, const double* df, int ld
     { int rc_ = verdict_published(p); if (rc_) return rc_; }
   HIPCHK(ctx, ctx->await(p->pend_pin, p->pend_ev, p->pend_seq));
     const int nfb_ = p->pend_pin[0], njac_ = p->pend_pin[1];
-    if (p->pend_tail) { if (!(p->ld <= 80 && p->pend_pin[2] == 0)) p->guess_settled = false; }
+    if (p->pend_tail) { if (!(p->pend_pin[2] == 0)) p->guess_settled = false; }
     else if (nfb_ > 0 || njac_ > 0) {
       p->guess_ok = false;
       ctx->gram_fast -= nfb_; ctx->gram_fallback += nfb_;
@@ -1320,7 +1333,7 @@ int trf_resolve(blsq_trf_plan* p, bool* redo) {
   { int rc_ = verdict_published(p); if (rc_) return rc_; }
   HIPCHK(ctx, ctx->await(p->pend_pin, p->pend_ev, p->pend_seq));
   int nfb = p->pend_pin[0], njac = p->pend_pin[1];
-  const bool settled = (p->ld <= 80 && p->pend_pin[2] == 0);
+  const bool settled = (p->pend_pin[2] == 0);
   QrTree& t = p->tree;
   if (p->pend_tail) {
     if (settled) return 0;                  // (settled: certified and gated in the Cholesky kernel — nfb = njac = 0)

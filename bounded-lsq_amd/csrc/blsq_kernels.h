@@ -187,7 +187,9 @@ hipError_t launch_gram(const GramArgs& a, int chunks, int B, hipStream_t s, doub
 hipError_t launch_gram_reduce(const double* Gpart, int chunks, int NPAD, double* Gout,
                               const int* mask, int B, hipStream_t s);
 hipError_t launch_gram_chol(const GramCholArgs& a, int B, hipStream_t s);
-hipError_t launch_gram_gate(const GramCholArgs& a, int B, hipStream_t s);
+// (stage0_only: N > 80 and the flag-driven factor kernel's share at hand — ONLY gram_cert0_kernel, which then also finishes
+//  the problems it certifies (lmfin) and counts the others (unsettled); BLSQ_CERT0 = 0 is ignored for such a launch)
+hipError_t launch_gram_gate(const GramCholArgs& a, int B, hipStream_t s, bool stage0_only = false);
 // third stage of the certificate for the problems launch_gram_gate flagged (a.cert_flag / a.cert_tau):
 // same source, scalings and gather as the factor call `a` describes, output into a.ywork
 hipError_t launch_gram_cert_shift(const GramCholArgs& a, int B, hipStream_t s);

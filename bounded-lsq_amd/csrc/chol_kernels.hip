@@ -1801,11 +1801,14 @@ __global__ __launch_bounds__(TRI_NT) void gram_cert0_kernel(GramCholArgs a) {
   extern __shared__ double sh[];
   __shared__ double red[32];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (a.mask && a.mask[b] <= 1) return;
-  if (a.fb_mask[b] != 0) return;                        // already failed on a pivot
+  // (GramCholArgs::unsettled: problems this launch does NOT finish — certified here AND through the rank gate's sure
+  //  case, as the N <= 80 factor kernel counts them: zero means the rest of the gate has nothing to do)
+  auto unsettle = [&]() { if (tid == 0 && a.unsettled) atomicAdd(a.unsettled, 1); };
+  if (a.mask && a.mask[b] <= 1) { unsettle(); return; }
+  if (a.fb_mask[b] != 0) { unsettle(); return; }        // already failed on a pivot
   const int NPAD = a.NPAD;
   const int n = a.ncols_dev ? a.ncols_dev[b] - 1 : a.n;
-  if (n <= 0) return;
+  if (n <= 0) { unsettle(); return; }
   const double* T = a.G + (long)b * NPAD * NPAD;
   double* x = sh;                        // [NPAD] M(T)^-1 e
   double* y = x + NPAD;                  // [NPAD] M(T)^-T (1 / dl)
@@ -1937,6 +1940,21 @@ __global__ __launch_bounds__(TRI_NT) void gram_cert0_kernel(GramCholArgs a) {
         if (a.k2_out) a.k2_out[b] = k2;
         if (a.lam_out) a.lam_out[b] = fmin(r1 * rinf, (double)n);
       }
+      // TRF finish (GramCholArgs::lmfin): the `sure` branch of lm_gate_kernel, same expressions
+      bool finished = false;
+      if (a.lmfin.fast && passed && a.colinfo && a.lmfin.enable != 0 && a.lmfin.m >= n) {
+        const double mn = a.colinfo[2 * (long)b], sm = a.colinfo[2 * (long)b + 1];
+        const double smin_lb = GRAM_SMIN_PROVEN * mn, smax_ub = sqrt(sm);
+        if (is_finite(sm) && sm > 0.0 && smin_lb > LM_GATE_MARGIN * LM_EPS * a.lmfin.m * smax_ub) {
+          a.lmfin.fast[b] = 1;
+          a.lmfin.ncols_jac[b] = 0;
+          a.lmfin.sc[(long)b * 16 + SC_SMAX] = smax_ub;
+          a.lmfin.sc[(long)b * 16 + SC_SMIN] = smin_lb;
+          a.lmfin.st[(long)b * 4 + ST_PHASE] = LM_IDLE;
+          finished = true;
+        }
+      }
+      if (!finished && a.unsettled) atomicAdd(a.unsettled, 1);
       CST(stp, 0, 18, 4);
       if (a.cert_open) {
         const double lam0 = fmin(r1 * rinf, (double)n);
@@ -1957,6 +1975,7 @@ __global__ __launch_bounds__(TRI_NT) void gram_cert0_kernel(GramCholArgs a) {
     return;
   }
   if (a.cert_open && tid == 0) a.cert_open[b] = 0.0;    // (four-pass form: the norm stage below keeps its own counsel)
+  unsettle();                                           // (... and the rank gate's launch finishes what passes here)
   // the two comparison solves FIRST: ||R'||_1 ||R'||_inf >= lambda_max(C) >= 1, so a product of the two maxima
   // beyond the gate already decides "not settled here" and the norm passes are skipped
   tri_invdiag(T, n, NPAD, invd);
@@ -2476,9 +2495,10 @@ hipError_t launch_gram_cert_shift(const GramCholArgs& a_in, int B, hipStream_t s
   return launch_gram_chol(a, B, s);
 }
 
-hipError_t launch_gram_gate(const GramCholArgs& a_in, int B, hipStream_t s) {
+hipError_t launch_gram_gate(const GramCholArgs& a_in, int B, hipStream_t s, bool stage0_only) {
   GramCholArgs a = a_in;
   a.count = B;
+  if (stage0_only && !(a.NPAD > 80 && a.cert_done && a.dsc && a.cert_ym)) return hipErrorInvalidValue;
   // stage 0 (N > 80; the register-resident factor kernel of the small shapes carries its own first bound):
   // BLSQ_CERT0 = 0 switches it off
   if (a.NPAD > 80 && a.cert_done && a.dsc) {
@@ -2497,6 +2517,7 @@ hipError_t launch_gram_gate(const GramCholArgs& a_in, int B, hipStream_t s) {
   } else {
     a.cert_open = nullptr;
   }
+  if (stage0_only) return hipGetLastError();
   const size_t per1 = sizeof(double) * (6 * (size_t)a.NPAD + 16 * 1 + 64);
   const size_t per8 = sizeof(double) * (6 * (size_t)a.NPAD + 16 * 8 + 64);
   if (a.NPAD <= 80) {                                   // one wave per problem, eight per workgroup

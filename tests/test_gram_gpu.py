@@ -742,13 +742,16 @@ def test_round_loop_follows_the_round_count_of_the_last_call(bl):
     assert 0 in seen and max(seen) >= 2, seen          # (the sequence really had calls without and with rounds)
 
 
-def test_second_guess_of_the_trf_device_api(bl, monkeypatch):
-    """N <= 80, TRF: after a call in which the Cholesky kernel settled every problem (first certificate
-    bound + the rank gate's column-norm bound), the certificate and gate launches of the next call are
-    not enqueued.  Guess holds / fails softly (a column of norm 1e-12) / fails hard (certificate; rank
-    deficiency) / holds again: the bits of the synchronous mode at every call."""
+@pytest.mark.parametrize("shape", [(700, 64), (900, 150)])
+def test_second_guess_of_the_trf_device_api(bl, monkeypatch, shape):
+    """TRF: after a call in which the Cholesky kernel (N <= 80; N > 80: stage 0 of the certificate, which is still
+    launched) settled every problem (first certificate bound + the rank gate's column-norm bound), the remaining
+    certificate and gate launches of the next call are not enqueued.  Guess holds / fails softly (a column of norm
+    1e-12) / fails hard (certificate; rank deficiency) / holds again: the bits of the synchronous mode at every call
+    (and, N > 80, of BLSQ_SETTLE0 = 0, which always enqueues the whole tail)."""
     from bounded_lsq import _synth, _abi
-    B, m, n = 6, 700, 64
+    m, n = shape
+    B = 6
     good = _synth.trf_batch(520, B, m, n)
     other = _synth.trf_batch(521, B, m, n)
     tiny = {k: v.copy() for k, v in good.items()}
@@ -763,8 +766,9 @@ def test_second_guess_of_the_trf_device_api(bl, monkeypatch):
     Delta = np.array([0.5, 0.05, 5.0, 0.2, 0.3, 1.0])
     for scale_mode in (0, 1):
         runs = []
-        for opt in ("1", "0"):
+        for opt, settle in (("1", "1"), ("0", "1"), ("1", "0")):
             monkeypatch.setenv("BLSQ_OPTIMISTIC", opt)
+            monkeypatch.setenv("BLSQ_SETTLE0", settle)
             ctx = _abi.Context(0)
             sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
             dD, dA = ctx.to_device(Delta), ctx.to_device(np.zeros(B))
@@ -780,9 +784,10 @@ def test_second_guess_of_the_trf_device_api(bl, monkeypatch):
                     ctx.free(v)
             runs.append(outs)
             sol.close(); ctx.free(dD); ctx.free(dA); ctx.close()
-        for call, (o1, o0) in enumerate(zip(*runs)):
-            for x1, x0 in zip(o1, o0):
-                assert np.array_equal(x1, x0, equal_nan=True), (scale_mode, call)
+        for other_run in runs[1:]:
+            for call, (o1, o0) in enumerate(zip(runs[0], other_run)):
+                for x1, x0 in zip(o1, o0):
+                    assert np.array_equal(x1, x0, equal_nan=True), (scale_mode, call)
 
 
 def test_second_guess_of_the_dogbox_device_api(bl, monkeypatch):
