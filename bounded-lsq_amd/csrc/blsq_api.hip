@@ -1678,6 +1678,8 @@ namespace blsq { int cqr2_debug_stamps(long long* host); }
 extern "C" int blsq_debug_cqr2_stamps(long long* host) { return blsq::cqr2_debug_stamps(host); }
 namespace blsq { int step_debug_stamps(long long* host); }
 extern "C" int blsq_debug_step_stamps(long long* host) { return blsq::step_debug_stamps(host); }
+namespace blsq { int dog_debug_stamps(long long* host); }
+extern "C" int blsq_debug_dog_stamps(long long* host) { return blsq::dog_debug_stamps(host); }
 #endif
 extern "C" int blsq_debug_qr_stamps(void* dbuf) {
   set_qr_debug_buffer(reinterpret_cast<double*>(dbuf));

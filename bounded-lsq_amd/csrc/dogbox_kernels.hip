@@ -246,12 +246,21 @@ __device__ static double to_box(const BoxCtx& c, const double* x0, const double*
   return block_min(tmin, c.red);
 }
 
+#ifdef BLSQ_CHOL_STAMPS
+__device__ long long g_dog_st[32];                     // phases of ONE problem's dogbox step (diagnostic build)
+#define DST(i) do { if (b == 0 && tid == 0) g_dog_st[i] = (long long)wall_clock64(); } while (0)
+int dog_debug_stamps(long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dog_st), sizeof(g_dog_st)); }
+#else
+#define DST(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(DG_NT) void dog_step_kernel(DogState st, const double* Delta_in,
                                                          DogStepOut out, PublishArgs pub) {
   extern __shared__ double sh[];
   __shared__ double red[32];
   const int b = blockIdx.x, tid = threadIdx.x;
+  DST(6);
   if (b == 0 && tid == 0) publish_ints(pub);            // (the verdict counters of the factor call: final since it ended)
+  DST(7);
   const int n = st.n, ld = st.ld;
   const long vo = (long)b * ld;
   const int N = st.ncols[b];
@@ -279,6 +288,7 @@ __global__ __launch_bounds__(DG_NT) void dog_step_kernel(DogState st, const doub
   const double* newton = st.newton + vo;
   const double* cauchy = st.cauchy + vo;
 
+  DST(0);
   // find_intersection (dogbox.py:9-35)
   for (int q = tid; q < nf; q += DG_NT) {
     const int j = fidx[q];
@@ -292,6 +302,7 @@ __global__ __launch_bounds__(DG_NT) void dog_step_kernel(DogState st, const doub
   __syncthreads();
   BoxCtx cx{nf, lt, ut, red};
 
+  DST(1);
   // dogleg_step (dogbox.py:38-75); faces: -1 / 0 / +1 in `dif` slots as ints later
   int tr_hit = 0;
   bool newton_inside = in_box(cx, newton);
@@ -319,6 +330,7 @@ __global__ __launch_bounds__(DG_NT) void dog_step_kernel(DogState st, const doub
     }
     tr_hit = block_or(th, red);
   }
+  DST(2);
   // bound_hits from hit signs (stepsv holds sign or 0; newton-inside -> none)
   // NB: when newton is inside, stepsv was set to +inf above: treat as no hit.
   auto face_of = [&](int q) -> long long {
@@ -328,6 +340,7 @@ __global__ __launch_bounds__(DG_NT) void dog_step_kernel(DogState st, const doub
     return 0;
   };
 
+  DST(3);
   // predicted reduction (dogbox.py:208-209):  Js.Js and Js.f
   const bool gp = st.path && st.path[b] == 0;
   double uu = 0.0, uc = 0.0;
@@ -371,6 +384,7 @@ __global__ __launch_bounds__(DG_NT) void dog_step_kernel(DogState st, const doub
   }
   __syncthreads();
 
+  DST(4);
   // scatter (dogbox.py:218-220) and the caller-side pieces of :235,253
   for (int j = tid; j < n; j += DG_NT) {
     out.step[vo + j] = 0.0;
@@ -392,6 +406,7 @@ __global__ __launch_bounds__(DG_NT) void dog_step_kernel(DogState st, const doub
     scal[0] = pred; scal[1] = smax; scal[2] = 0.0; scal[3] = 0.0;
     info[0] = tr_hit; info[1] = fallback; info[2] = 0; info[3] = 0;
   }
+  DST(5);
 }
 
 hipError_t launch_dog_step(const DogState& st, const double* Delta, const DogStepOut& out,
