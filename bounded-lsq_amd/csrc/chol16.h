@@ -176,6 +176,16 @@ __device__ __forceinline__ double chol16_blocked3(v4d T, double* Dt, double* Ri,
   double Y[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
+    // The LAST diagonal tile of a factor holds nlive = n mod 16 live variables and the rhs at index nlive; what lies
+    // behind it is padding (exact zeros).  A four-row block of nothing but padding leaves zero rows, a zero block of the
+    // inverse and an unchanged tile — written here without the pivots' dependent chain (n = 64 and n = 256: the whole
+    // last tile but its first block).  Wave-uniform.
+    if (4 * q > nlive) {
+      Dt[(4 * q + lr) * 16 + lc] = 0.0;
+      Ri[lc * 16 + 4 * q + lr] = 0.0;
+      Y[q] = 0.0;
+      continue;
+    }
     double P[4];
     rows_to_all(T[q], P);
     double ri[4], rr[4][4];
