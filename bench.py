@@ -214,6 +214,76 @@ def cpu_baseline(P, Delta, budget_s=24.0):
     }
 
 
+# ---- mutations of the headline batch for the conditioning legs -------------------------------
+def mut_mixed(P):
+    """kappa(J) log-uniform over [1, 1e4] (J = Z V diag(s) V^T, Z Gaussian, s log-spaced over [1/kappa_b, 1]; 64
+    distinct problems tiled to the batch)"""
+    rng = np.random.default_rng(4242)
+    nn = P["J"].shape[2]
+    V, _ = np.linalg.qr(rng.standard_normal((nn, nn)))
+    K = min(64, P["J"].shape[0])
+    kap = 10.0 ** rng.uniform(0.0, 4.0, K)
+    for b in range(K):
+        sv = np.logspace(0.0, -np.log10(kap[b]), nn)
+        P["J"][b] = (P["J"][b] @ (V * sv)) @ V.T
+    for b in range(K, P["J"].shape[0]):
+        P["J"][b] = P["J"][b % K]
+    P["kappa"] = kap
+
+
+def mut_mixed_unbounded(P):
+    mut_mixed(P)
+    P["lb"][:] = -np.inf
+    P["ub"][:] = np.inf
+
+
+def mut_all_rejected(P):
+    """every problem beyond the gate: kappa(J) = 3e3, no bounds — what a batch gets whose problems ALL fail the
+    certificate (`householder_only` is the tree alone)"""
+    rng = np.random.default_rng(4243)
+    nn = P["J"].shape[2]
+    V, _ = np.linalg.qr(rng.standard_normal((nn, nn)))
+    K = min(64, P["J"].shape[0])
+    sv = np.logspace(0.0, -np.log10(3e3), nn)
+    for b in range(K):
+        P["J"][b] = (P["J"][b] @ (V * sv)) @ V.T
+    for b in range(K, P["J"].shape[0]):
+        P["J"][b] = P["J"][b % K]
+    P["lb"][:] = -np.inf
+    P["ub"][:] = np.inf
+
+
+def conditioning_leg(key, mut, ctx, name, batch, steps, check):
+    """one of the conditioning legs -> its record (a side figure, never `value`)"""
+    bm = Bench(name, ctx, 0, 1, batch=batch, mutate=mut)
+    B = bm.B
+    try:
+        km = max(2, min(steps, 20))
+        ctx.csne_stats(reset=True)
+        em, km = time_steps(bm, km, 1, ctx.sync)
+        gsm = ctx.gram_stats()
+        cq2 = ctx.cqr2_stats(reset=True)
+        cs = ctx.csne_stats(reset=True)
+        ncs = cs[0] // (km + 1 + bm.profile[1])          # (routed per factor call: warm-up + profile + timed regions)
+        rec = {
+            "value": B * km / em, "unit": "step-solves/s", "ms_per_step": 1e3 * em / km, "steps": km,
+            "factorisation_paths": {"normal_equations": gsm[0] // km, "csne": ncs, "choleskyqr2": cq2 // km,
+                                    "householder_tree": gsm[1] // km - cq2 // km - ncs,
+                                    "csne_step_solves_delivered_declined": [cs[1], cs[2]]},
+            "parity": bm.parity(min(16, B)) if check > 0 else None,
+            "kernels_ms_per_step": {k: round(v, 4) for k, v in profile_table(bm).items() if v > 0},
+            "note": ("kappa(J) = 3e3 for every problem, no bounds: all of them beyond the gate"
+                     if key == "certificate_rejected" else
+                     "kappa(J) log-uniform over [1, 1e4]; each problem on the path its certificate allows. "
+                     + ("Bounds as in the headline workload: the Coleman-Li block E^2 of the augmented "
+                        "system [J D; E] (trf.py:264-270) keeps the SOLVED system well conditioned."
+                        if key == "mixed_conditioning" else
+                        "No bounds: the solved system is J^T J itself."))}
+    finally:
+        bm.close()
+    return rec
+
+
 # ------------------------------------------------------------- one config --
 class Bench:
     """Device-resident inputs + the step closure of one config on one ctx."""
@@ -610,57 +680,9 @@ def main():
             # A batch of mixed conditioning: kappa(J) log-uniform over [1, 1e4] (J = Z V diag(s) V^T, Z
             # Gaussian, s log-spaced over [1/kappa_b, 1]; 64 distinct problems tiled to the batch).  The
             # certificate sends each problem down its own path; `factorisation_paths` shows the split.
-            def mixed(P):
-                rng = np.random.default_rng(4242)
-                nn = P["J"].shape[2]
-                V, _ = np.linalg.qr(rng.standard_normal((nn, nn)))
-                K = min(64, P["J"].shape[0])
-                kap = 10.0 ** rng.uniform(0.0, 4.0, K)
-                for b in range(K):
-                    sv = np.logspace(0.0, -np.log10(kap[b]), nn)
-                    P["J"][b] = (P["J"][b] @ (V * sv)) @ V.T
-                for b in range(K, P["J"].shape[0]):
-                    P["J"][b] = P["J"][b % K]
-                P["kappa"] = kap
-            def mixed_unbounded(P):
-                mixed(P)
-                P["lb"][:] = -np.inf
-                P["ub"][:] = np.inf
-            def all_rejected(P):
-                # every problem beyond the gate: kappa(J) = 3e3, no bounds — what a batch gets whose problems ALL
-                # fail the certificate (the CholeskyQR2 tier; `householder_only` above is the tree alone)
-                rng = np.random.default_rng(4243)
-                nn = P["J"].shape[2]
-                V, _ = np.linalg.qr(rng.standard_normal((nn, nn)))
-                K = min(64, P["J"].shape[0])
-                sv = np.logspace(0.0, -np.log10(3e3), nn)
-                for b in range(K):
-                    P["J"][b] = (P["J"][b] @ (V * sv)) @ V.T
-                for b in range(K, P["J"].shape[0]):
-                    P["J"][b] = P["J"][b % K]
-                P["lb"][:] = -np.inf
-                P["ub"][:] = np.inf
-            for key, mut in (("mixed_conditioning", mixed), ("mixed_conditioning_unbounded", mixed_unbounded),
-                             ("certificate_rejected", all_rejected)):
-                bm = Bench(name, ctx, 0, 1, batch=args.batch, mutate=mut)
-                km = max(2, min(steps_requested, 20))
-                em, km = time_steps(bm, km, 1, ctx.sync)
-                gsm = ctx.gram_stats()
-                cq2 = ctx.cqr2_stats(reset=True)
-                extras[key] = {
-                    "value": B * km / em, "unit": "step-solves/s", "ms_per_step": 1e3 * em / km, "steps": km,
-                    "factorisation_paths": {"normal_equations": gsm[0] // km, "choleskyqr2": cq2 // km,
-                                            "householder_tree": gsm[1] // km - cq2 // km},
-                    "parity": bm.parity(min(16, B)) if args.check > 0 else None,
-                    "kernels_ms_per_step": {k: round(v, 4) for k, v in profile_table(bm).items() if v > 0},
-                    "note": ("kappa(J) = 3e3 for every problem, no bounds: all of them beyond the gate"
-                             if key == "certificate_rejected" else
-                             "kappa(J) log-uniform over [1, 1e4]; each problem on the path its certificate allows. "
-                             + ("Bounds as in the headline workload: the Coleman-Li block E^2 of the augmented "
-                                "system [J D; E] (trf.py:264-270) keeps the SOLVED system well conditioned."
-                                if key == "mixed_conditioning" else
-                                "No bounds: the solved system is J^T J itself."))}
-                bm.close()
+            for key, mut in (("mixed_conditioning", mut_mixed), ("mixed_conditioning_unbounded", mut_mixed_unbounded),
+                             ("certificate_rejected", mut_all_rejected)):
+                extras[key] = conditioning_leg(key, mut, ctx, name, args.batch, steps_requested, args.check)
         if not args.no_h2d:
             # numpy in, numpy out through blsq_trf_factor / blsq_trf_step: the 8 MiB Jacobian of every
             # problem crosses PCIe inside the call ("including and excluding H2D of J")

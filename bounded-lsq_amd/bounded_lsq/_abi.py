@@ -75,6 +75,8 @@ SIGNATURES = {
     "blsq_debug_cqr_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
     "blsq_debug_gram_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
     "blsq_debug_cqr2_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
+    "blsq_debug_csne_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
+    "blsq_trf_debug_csne": (C.c_int, [vp, vp, vp]),
     "blsq_debug_probe": (C.c_int, [vp, C.c_int, C.c_int, c_double_p]),
     "blsq_outer_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "blsq_outer_destroy": (C.c_int, [vp]),
@@ -237,6 +239,12 @@ class Context:
         out = (C.c_uint64 * 1)()
         self.check(self.lib.blsq_debug_cqr2_stats(self.h, out, 1 if reset else 0), "cqr2_stats")
         return int(out[0])
+
+    def csne_stats(self, reset=False):
+        """-> (problems routed to the CSNE tier by factor calls, step-solves it delivered, step-solves it declined)."""
+        out = (C.c_uint64 * 3)()
+        self.check(self.lib.blsq_debug_csne_stats(self.h, out, 1 if reset else 0), "csne_stats")
+        return int(out[0]), int(out[1]), int(out[2])
 
     # ---- collective over the ranks of one tall problem (RCCL, blsq_comm_*) ---------------------
     def comm_new_id(self):

@@ -148,6 +148,14 @@ class TrfStepSolver:
         self.ctx.check(self.lib.blsq_trf_debug_sweeps(self.h, ptr(sw)), "blsq_trf_debug_sweeps")
         return sw
 
+    def debug_csne(self):
+        """-> (on_tier [B] int32, eta [B]): the CSNE tier's problems and the largest first-order correction the last
+        step call measured for each (-1: the tier declined the problem in that call)."""
+        on = np.empty(self.B, np.int32)
+        eta = np.empty(self.B)
+        self.ctx.check(self.lib.blsq_trf_debug_csne(self.h, ptr(on), ptr(eta)), "blsq_trf_debug_csne")
+        return on, eta
+
     def fetch_step(self):
         B, n = self.B, self.n
         alpha = np.empty(B)

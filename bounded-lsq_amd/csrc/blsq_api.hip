@@ -22,10 +22,11 @@ namespace {
 constexpr int RMAX = QR_MAX_TILES * 16;   // rows a workgroup can stage (qr_panel.hip): 1024
 
 enum Slot { K_QR_LEAF = 0, K_QR_MERGE, K_PREP, K_QR_AUG, K_JACOBI, K_STEP, K_LM_GATE, K_LM_QR, K_LM_SOLVE,
-            K_GRAM, K_GRAM_CHOL, K_GRAM_GATE, K_AUG_CHOL, K_LM_CHOL, K_CQR2_APPLY, K_CQR2_COMBINE, K_NSLOT };
+            K_GRAM, K_GRAM_CHOL, K_GRAM_GATE, K_AUG_CHOL, K_LM_CHOL, K_CQR2_APPLY, K_CQR2_COMBINE, K_CSNE_PASS,
+            K_CSNE_FIX, K_NSLOT };
 const char* kSlotNames[K_NSLOT] = {"qr_leaf", "qr_merge", "prep", "qr_aug", "jacobi_svd", "step",
                                    "lm_gate", "lm_qr", "lm_solve", "gram", "gram_chol", "gram_gate",
-                                   "aug_chol", "lm_chol", "cqr2_apply", "cqr2_combine"};
+                                   "aug_chol", "lm_chol", "cqr2_apply", "cqr2_combine", "csne_pass", "csne_fix"};
 
 inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
 // rows of the stacked systems [R D; E] / [R_aug; sqrt(alpha) I]: two blocks of
@@ -73,6 +74,9 @@ struct blsq_ctx {
   hipEvent_t lm_ev[2] = {nullptr, nullptr};   // read-back of the counter of round r has landed (r & 1)
   long long gram_fast = 0, gram_fallback = 0;   // problems factored by the normal equations / handed to the QR tree
   unsigned long long* cq_accept_dev = nullptr;  // device counter: rejected problems the CholeskyQR2 tier factored
+  // CSNE tier (csne_kernels.hip): problems routed to it by factor calls, step-solves it delivered, step-solves it
+  // declined (acceptance failed at step time: the problem went on to CholeskyQR2 / the tree)
+  unsigned long long csne_routed = 0, csne_steps = 0, csne_declined = 0;
   // collective over the ranks of one tall problem (RCCL over xGMI; blsq_comm_*)
   ncclComm_t comm = nullptr;
   int comm_ranks = 1, comm_rank = 0;
@@ -636,6 +640,15 @@ struct blsq_trf_plan {
   DevBuf aug_hmax;                  // [B] largest diagonal entry of H (LmState::hmax: which Newton systems of a
                                     // Householder-path problem may be factored from the Gram)
   bool gram_valid = false;          // tree.gram_keep holds the Grams of the current factor call's problems
+  // CSNE tier (csne_kernels.hip): rejected problems whose steps are corrected against J in one streaming pass
+  int last_scale_mode = 0;          // scale_mode of the last factor call (a problem that leaves the tier at step time is prepared again)
+  int lm_rounds_done = 0;           // Newton rounds the last trf_lm_rounds call ran (the deepest recording: 1 + that)
+  bool csne_on = false;             // the shape is supported and BLSQ_CSNE != 0
+  int ncsne = 0;                    // problems on the tier now (host copy of cs.counts[0])
+  DevBuf cs_ints;                   // flag [B], list [B], fail_list [B], ne [B], sel_mask [B], counts [4], scratch [4]
+  DevBuf cs_pmin, cs_eta, cs_alpha, cs_hp, cs_vec, cs_part;
+  size_t cs_part_cap = 0;           // (list positions x chunks x NE) the partial-sum buffer holds
+  CsneState cs{};
   // TSQR (multi-rank) extras
   int nranks = 1, m_total = 0;
   bool ranks_agreed = false;        // the ranks have compared their plan configuration (first factor call)
@@ -1027,6 +1040,31 @@ int trf_alloc_state(blsq_trf_plan* p) {
     p->lm_enable = (env && env[0] == '1') ? 0 : 1;
     p->lm_gate_mask = p->lm_enable ? (band ? 2 : 3) : 0;
   }
+  {
+    // CSNE tier: single-rank plans of its shapes with the normal-equations front end on (BLSQ_CSNE = 0: off)
+    const char* ce = getenv("BLSQ_CSNE");
+    p->csne_on = p->tree.gram && p->nranks == 1 && csne_supported(p->m, p->n) && !(ce && ce[0] == '0');
+    if (p->csne_on) {
+      ALLOC(p->cs_ints, sizeof(int) * (5 * (size_t)B + 8));
+      ALLOC(p->cs_pmin, sizeof(double) * (size_t)B);
+      ALLOC(p->cs_eta, sizeof(double) * (size_t)B);
+      ALLOC(p->cs_alpha, sizeof(double) * (size_t)B * CSNE_MAXE);
+      ALLOC(p->cs_hp, sizeof(double) * vs);
+      HIPCHK(ctx, hipMemsetAsync(p->cs_ints.p, 0, p->cs_ints.bytes, ctx->stream));
+      HIPCHK(ctx, hipMemsetAsync(p->cs_pmin.p, 0, p->cs_pmin.bytes, ctx->stream));
+      HIPCHK(ctx, hipMemsetAsync(p->cs_eta.p, 0, p->cs_eta.bytes, ctx->stream));
+      CsneState& cs = p->cs;
+      cs.B = B; cs.m = p->m; cs.n = p->n; cs.ld = ld;
+      int* ii = p->cs_ints.as<int>();
+      cs.flag = ii; cs.list = ii + B; cs.fail_list = ii + 2 * (size_t)B; cs.ne = ii + 3 * (size_t)B;
+      cs.counts = ii + 5 * (size_t)B;                     // (sel_mask: ii + 4 B; scratch counter: counts + 4)
+      cs.ralpha = p->cs_alpha.as<double>(); cs.hp = p->cs_hp.as<double>(); cs.eta = p->cs_eta.as<double>();
+      csne_geometry(p->m, &cs.rows_per_wg, &cs.nchunk);
+      cs.NE = 1;
+      p->st.csne = cs.flag; p->st.csne_hp = cs.hp;
+      p->lm.csne = cs.flag; p->lm.csne_ne = cs.ne; p->lm.csne_alpha = cs.ralpha;
+    }
+  }
   p->aug_RP = std::max(aug_rows(p->n), ld);
   if (aug_rows(p->n) > RMAX) return ctx->bad(4, "n too large for the augmented system (n <= 512)");
   p->aug_LDP = 0;
@@ -1122,6 +1160,7 @@ GramCholArgs trf_chol_args(blsq_trf_plan* p, const int* mask) {
   c.cert_flag = t.gram_cflag.as<int>(); c.cert_tau = t.gram_ctau.as<double>();
   c.colinfo = p->aug_colinfo.as<double>();
   c.hmax = p->aug_hmax.as<double>(); c.lam_out = p->aug_lam.as<double>();
+  if (p->csne_on) c.pmin_out = p->cs_pmin.as<double>();
   if (p->ld > 80) {
     c.cert_ym = p->aug_ym.as<double>(); c.cert_r1 = p->aug_r1.as<double>();
     const char* oe = getenv("BLSQ_CERT_DIRECT");          // 0: every open problem through the norm stage (explicit inverse)
@@ -1276,10 +1315,75 @@ int trf_gram_stage(blsq_trf_plan* p, int scale_mode, const int* mask, int* nfb, 
 }
 
 // the problems the gate rejected: Householder tree on [J f], prep again from the triangle
-int trf_fallback_stage(blsq_trf_plan* p, const double* dJ, const double* df, int ldJ, int scale_mode,
-                       int nfb) {
+// (a masked factor call has refreshed some problems: the tier's list is rebuilt from the flags)
+int trf_csne_relist(blsq_trf_plan* p) {
   blsq_ctx* ctx = p->ctx;
-  int rc = p->tree.run_fallback(ctx, dJ, df, ldJ, nfb);
+  hipError_t e = launch_csne_reroute(p->cs, -1, nullptr, nullptr, nullptr, ctx->stream);
+  if (e != hipSuccess) return ctx->fail(e, "launch_csne_reroute(relist)");
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 9, p->cs.counts, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  p->ncsne = ctx->pinned[9];
+  return 0;
+}
+
+// CSNE tier, factor side: which of the nfb problems the certificate has just rejected (tree.fb_list()) keep their
+// Gram-Cholesky factor as a preconditioner and have their steps corrected against J (csne_kernels.hip).  The bound on
+// kappa_2 of the COMPUTED augmented system comes from the certificate's norm stage run with CSNE_K2_MAX as its gate
+// (explicit inverse, as the CholeskyQR2 tier does for the plain system); *ntree = the problems left for the other tiers.
+int trf_csne_select(blsq_trf_plan* p, const double* dJ, const double* df, int ldJ, int nfb, int* ntree, bool masked) {
+  blsq_ctx* ctx = p->ctx;
+  QrTree& t = p->tree;
+  const int B = p->B;
+  *ntree = nfb;
+  if (!p->csne_on || !p->lm_enable) return 0;
+  hipError_t e = hipSuccess;
+  if (!p->cs_vec.p) {                                     // first use: the recordings (52 KB per problem at n = 256)
+    e = p->cs_vec.alloc(sizeof(double) * (size_t)B * CSNE_MAXE * 3 * p->ld);
+    if (e != hipSuccess) { (void)hipGetLastError(); p->csne_on = false; return 0; }   // (no room: the other tiers)
+    p->cs.rvec = p->cs_vec.as<double>();
+    p->lm.csne_vec = p->cs.rvec;
+  }
+  int* sel = p->cs_ints.as<int>() + 4 * (size_t)B;
+  int* scratch = p->cs.counts + 4;
+  HIPCHK(ctx, hipMemsetAsync(sel, 0, sizeof(int) * (size_t)B, ctx->stream));
+  GramCholArgs cy = trf_chol_args(p, t.fb_mask());        // (mask: the rejected problems only)
+  cy.fb_mask = sel; cy.fail_count = scratch; cy.fail_list = nullptr; cy.path_out = nullptr;
+  cy.cert_done = nullptr; cy.cert_flag = nullptr; cy.cert_tau = nullptr; cy.cert_open = nullptr;
+  cy.cert_ym = nullptr; cy.cert_r1 = nullptr; cy.unsettled = nullptr; cy.lmfin = GramCholArgs::LmFinish{};
+  cy.lam_out = nullptr; cy.hmax = nullptr; cy.colinfo = nullptr; cy.pmin_out = nullptr;
+  cy.k2_max = CSNE_K2_MAX; cy.k2_out = t.gram_k2.as<double>();
+  ctx->begin(K_GRAM_GATE);
+  e = launch_gram_gate(cy, B, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_gram_gate(csne bound)");
+  e = launch_csne_select(p->cs, p->lm, nfb, t.fb_list(), t.fb_mask(), t.fb_count(), t.path_rw(), sel,
+                         t.gram_k2.as<double>(), p->cs_pmin.as<double>(), p->aug_colinfo.as<double>(), ctx->stream);
+  if (e != hipSuccess) return ctx->fail(e, "launch_csne_select");
+  // two counters to the host: the problems left for the tree, the problems on the tier
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 8, t.fb_count(), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 9, p->cs.counts, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  *ntree = ctx->pinned[8];
+  p->ncsne = ctx->pinned[9];
+  ctx->csne_routed += (unsigned long long)(nfb - *ntree);
+  p->cs.J = dJ; p->cs.strideJ = (long)p->m * ldJ; p->cs.ldJ = ldJ; p->cs.F = df; p->cs.strideF = p->m;
+  if (!masked) t.any_qr = *ntree > 0;                     // (a masked call keeps the others' paths: any_qr stays)
+  t.any_gram = t.any_gram || *ntree < nfb;
+  p->use_chol = t.any_gram; p->use_qr = t.any_qr;
+  return 0;
+}
+
+int trf_fallback_stage(blsq_trf_plan* p, const double* dJ, const double* df, int ldJ, int scale_mode,
+                       int nfb, bool masked = false) {
+  blsq_ctx* ctx = p->ctx;
+  int rc;
+  {
+    int ntree = nfb;
+    if ((rc = trf_csne_select(p, dJ, df, ldJ, nfb, &ntree, masked))) return rc;
+    nfb = ntree;
+    if (nfb == 0) return 0;
+  }
+  rc = p->tree.run_fallback(ctx, dJ, df, ldJ, nfb);
   if (rc) return rc;
   ctx->begin(K_PREP);
   hipError_t e = launch_trf_prep(p->st, scale_mode, 0, p->tree.fb_mask(), 1, ctx->stream);
@@ -1311,6 +1415,8 @@ int trf_factor_core(blsq_trf_plan* p, const double* dJ, const double* df, int ld
     return trf_after_triangle(p, p->tree.Rfinal(), scale_mode);
   }
   if (!gram_done && (rc = p->tree.run_gram_only(ctx, dJ, df, ldJ, mask, false))) return rc;
+  p->last_scale_mode = scale_mode;
+  if (!mask) p->ncsne = 0;                                // (the prep launch clears every flag; trf_csne_select sets them anew)
   int nfb = 0;
   // (never in the n-band that always takes the SVD, nor right after a wrong guess)
   const bool defer = may_defer && p->optimistic && p->guess_ok && p->lm_enable && !mask && p->pend_pin &&
@@ -1318,7 +1424,8 @@ int trf_factor_core(blsq_trf_plan* p, const double* dJ, const double* df, int ld
   if ((rc = trf_gram_stage(p, scale_mode, mask, &nfb, defer))) return rc;
   if (defer) { p->pend_dJ = dJ; p->pend_df = df; p->pend_ldJ = ldJ; p->pend_scale_mode = scale_mode; }
   else if (!mask) p->guess_ok = (nfb == 0 && p->njac == 0);
-  if (nfb > 0 && (rc = trf_fallback_stage(p, dJ, df, ldJ, scale_mode, nfb))) return rc;
+  if (nfb > 0 && (rc = trf_fallback_stage(p, dJ, df, ldJ, scale_mode, nfb, mask != nullptr))) return rc;
+  if (nfb == 0 && mask && p->ncsne > 0 && (rc = trf_csne_relist(p))) return rc;   // (refreshed problems have left the tier)
   return trf_finish(p);
 }
 
@@ -1401,6 +1508,7 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
       e = launch_lm_rounds_reg(c, p->lm, dDelta, dalpha_in, ctx->stream);
       ctx->end();
       if (e != hipSuccess) return ctx->fail(e, "launch_lm_rounds_reg");
+      p->lm_rounds_done = 0;
       if (!p->use_qr) return 0;
       p->lm.fused_gram = 1;
     }
@@ -1506,11 +1614,14 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
       done_rounds = round + 1;
     }
     p->lm_rounds_last = done_rounds;
+    p->lm_rounds_done = done_rounds;
     return 0;
   }
   HIPCHK(ctx, landed(0));
   int active = pin[0];
+  p->lm_rounds_done = 0;
   for (int round = 0; round < 12 && active > 0; ++round) {
+    p->lm_rounds_done = round + 1;
     if (p->use_chol && !p->lm.fused_gram) {
       e = chol_round(round, active, active, nullptr);
       if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(lm)");
@@ -1529,6 +1640,65 @@ int trf_lm_rounds(blsq_trf_plan* p, const double* dDelta, const double* dalpha_i
     active = pin[4 * (round + 1)];
   }
   return 0;
+}
+
+// CSNE tier, step side (csne_kernels.hip): ONE streaming pass over the caller's J for every recorded evaluation of
+// every problem on the tier, then the n-space correction (replayed Newton iteration, corrected final step, H p for
+// the step kernel).  Problems whose acceptance fails are listed in cs.fail_list (trf_csne_verdict).
+int trf_csne_correct(blsq_trf_plan* p, const double* dDelta, const double* dalpha_in) {
+  blsq_ctx* ctx = p->ctx;
+  CsneState& cs = p->cs;
+  const int ne_max = std::min(CSNE_MAXE, 1 + std::max(0, p->lm_rounds_done));
+  const int NE = ne_max;
+  cs.NE = NE;
+  const size_t need = (size_t)p->ncsne * cs.nchunk * ((size_t)NE * p->ld + 16);
+  if (need > p->cs_part_cap) {                            // (grows geometrically; hipFree waits for the stream)
+    p->cs_part.release();
+    const size_t cap = std::max(need, 2 * p->cs_part_cap);
+    hipError_t ae = p->cs_part.alloc(sizeof(double) * cap);
+    if (ae != hipSuccess) { p->cs_part_cap = 0; return ctx->fail(ae, "hipMalloc(CSNE partial sums)"); }
+    p->cs_part_cap = cap;
+    cs.part = p->cs_part.as<double>();
+  }
+  HIPCHK(ctx, hipMemsetAsync(cs.counts + 1, 0, sizeof(int), ctx->stream));
+  ctx->begin(K_CSNE_PASS);
+  hipError_t e = launch_csne_pass(cs, p->st.d, p->ncsne, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_csne_pass");
+  ctx->begin(K_CSNE_FIX);
+  e = launch_csne_fix(cs, p->st, p->lm, dDelta, dalpha_in, p->ncsne, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_csne_fix");
+  return 0;
+}
+
+// ... and what became of them: problems the tier declined in this step call leave it — factored by CholeskyQR2 / the
+// Householder tree from the caller's J (still valid: the lifetime rule of the tier), prepared again from the triangle —
+// and the step runs once more (*redo).
+int trf_csne_verdict(blsq_trf_plan* p, int ncs, bool* redo) {
+  blsq_ctx* ctx = p->ctx;
+  CsneState& cs = p->cs;
+  QrTree& t = p->tree;
+  int seq = 0;
+  HIPCHK(ctx, ctx->publish(cs.counts + 1, 1, ctx->pinned + 12, ctx->lm_ev[0], &seq));
+  HIPCHK(ctx, ctx->await(ctx->pinned + 12, ctx->lm_ev[0], seq));
+  const int nfail = ctx->pinned[12];
+  ctx->csne_steps += (unsigned long long)(ncs - nfail);
+  ctx->csne_declined += (unsigned long long)nfail;
+  if (nfail == 0) return 0;
+  *redo = true;
+  hipError_t e = launch_csne_reroute(cs, nfail, t.fb_list(), t.fb_mask(), t.path_rw(), ctx->stream);
+  if (e != hipSuccess) return ctx->fail(e, "launch_csne_reroute");
+  p->ncsne = ncs - nfail;
+  int rc = t.run_fallback(ctx, cs.J, cs.F, cs.ldJ, nfail);
+  if (rc) return rc;
+  ctx->begin(K_PREP);
+  e = launch_trf_prep(p->st, p->last_scale_mode, 0, t.fb_mask(), 1, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_trf_prep(csne redo)");
+  t.any_qr = true; p->use_qr = true;
+  p->gate_done = false; p->njac = -1;
+  return trf_finish(p);
 }
 
 }  // namespace
@@ -1573,6 +1743,8 @@ extern "C" int blsq_trf_plan_destroy(blsq_trf_plan* p) {
   p->o_info.release(); p->in_J.release(); p->in_f.release(); p->in_vec.release();
   p->in_scal.release();
   p->lm_sa.release(); p->lm_Xa.release(); p->lm_ints.release(); p->lm_sc.release();
+  p->cs_ints.release(); p->cs_pmin.release(); p->cs_eta.release(); p->cs_alpha.release(); p->cs_hp.release();
+  p->cs_vec.release(); p->cs_part.release();
   p->lm_ph.release(); p->aug_colinfo.release(); p->aug_hmax.release(); p->aug_lam.release(); p->aug_ym.release(); p->aug_r1.release(); p->aug_open.release(); p->aug_mask.release();
   delete p;
   return 0;
@@ -1636,9 +1808,12 @@ extern "C" int blsq_trf_step_dev(blsq_trf_plan* p, const double* dDelta, const d
   if (!dalpha_in) return ctx->bad(3, "alpha is NULL");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   // (pass 0 may run on the guessed state of an optimistic factor call; pass 1 only if the guess was wrong)
-  for (int pass = 0; pass < 2; ++pass) {
+  // (... and one more if a problem leaves the CSNE tier in this call: it is factored by the next tier, then the step again)
+  for (int pass = 0; pass < 4; ++pass) {
     int rc = trf_lm_rounds(p, dDelta, dalpha_in);
     if (rc) return rc;
+    const int ncs = p->ncsne;
+    if (ncs > 0 && (rc = trf_csne_correct(p, dDelta, dalpha_in))) return rc;
     ctx->begin(K_STEP);
     const PublishArgs pub = verdict_rides(p);
     hipError_t e = launch_trf_step(p->st, &p->lm, dDelta, dalpha_in, active_rtol, p->out,
@@ -1648,6 +1823,7 @@ extern "C" int blsq_trf_step_dev(blsq_trf_plan* p, const double* dDelta, const d
     p->lm_counts_clean = true;              // (the step kernel leaves the round counters zeroed)
     bool redo = false;
     if ((rc = trf_resolve(p, &redo))) return rc;
+    if (!redo && ncs > 0 && (rc = trf_csne_verdict(p, ncs, &redo))) return rc;
     if (!redo) break;
   }
   return 0;
@@ -1704,6 +1880,19 @@ extern "C" int blsq_trf_debug_cond(blsq_trf_plan* p, double* k2) {
   { int rc_ = trf_resolve(p, nullptr); if (rc_) return rc_; }
   HIPCHK(ctx, hipMemcpyAsync(k2, p->tree.gram_k2.p, sizeof(double) * p->B, hipMemcpyDeviceToHost,
                              ctx->stream));
+  return blsq_sync(ctx);
+}
+
+extern "C" int blsq_trf_debug_csne(blsq_trf_plan* p, int32_t* on_tier, double* eta) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  { int rc_ = trf_resolve(p, nullptr); if (rc_) return rc_; }
+  if (!p->csne_on) {
+    for (int b = 0; b < p->B; ++b) { if (on_tier) on_tier[b] = 0; if (eta) eta[b] = 0.0; }
+    return 0;
+  }
+  if (on_tier) HIPCHK(ctx, hipMemcpyAsync(on_tier, p->cs.flag, sizeof(int) * p->B, hipMemcpyDeviceToHost, ctx->stream));
+  if (eta) HIPCHK(ctx, hipMemcpyAsync(eta, p->cs.eta, sizeof(double) * p->B, hipMemcpyDeviceToHost, ctx->stream));
   return blsq_sync(ctx);
 }
 
@@ -2897,6 +3086,13 @@ extern "C" int blsq_debug_gram_stats(blsq_ctx* ctx, uint64_t* out2, int reset) {
   out2[0] = (uint64_t)ctx->gram_fast;
   out2[1] = (uint64_t)ctx->gram_fallback;
   if (reset) { ctx->gram_fast = 0; ctx->gram_fallback = 0; }
+  return 0;
+}
+
+extern "C" int blsq_debug_csne_stats(blsq_ctx* ctx, uint64_t out[3], int reset) {
+  if (!ctx) return -1;
+  if (out) { out[0] = ctx->csne_routed; out[1] = ctx->csne_steps; out[2] = ctx->csne_declined; }
+  if (reset) { ctx->csne_routed = 0; ctx->csne_steps = 0; ctx->csne_declined = 0; }
   return 0;
 }
 

@@ -157,6 +157,8 @@ struct GramCholArgs {
   // exceptions keeps the common case free of atomics: a thousand waves finishing together and adding to
   // one address cost 9 us.)
   int* unsettled;
+  double* pmin_out;       // optional [B] out: the smallest squared pivot of R' the factorisation met (the CSNE tier's
+                          // own floor is far below the gate's, csne_kernels.hip); not written by a shifted launch
 };
 // A problem stays on the normal-equations path only if the PROVEN bound K2 >= kappa_2(R'^T R') of its
 // equilibrated system is at most GRAM_K2_MAX (chol_kernels.hip, gram_cond_kernel).  Consequence used
@@ -219,6 +221,55 @@ hipError_t launch_cqr2_combine(const Cqr2Args& a, int count, const int* run, con
                                const double* R2, double* Rout, int* tree_mask, unsigned long long* accepted,
                                hipStream_t s);
 
+// ------------------------------------- CSNE tier (csne_kernels.hip) ----
+// Corrected semi-normal equations for the problems the conditioning certificate keeps off the normal-equations
+// path: their Gram-Cholesky factors are kept as PRECONDITIONERS, the cheap Newton iteration on phi(alpha) runs on
+// them as for any other problem and records every evaluation; ONE streaming pass over J then yields the residuals
+// of all recorded solves, an n-space kernel corrects phi / phi' to first order, replays the scalar iteration and
+// corrects the final step.
+constexpr int CSNE_MAXE = 8;             // evaluations of phi a problem may record (alpha = 0 and seven Newton rounds)
+#ifndef BLSQ_CSNE_K2_MAX
+#define BLSQ_CSNE_K2_MAX 2.0e11
+#endif
+constexpr double CSNE_K2_MAX = BLSQ_CSNE_K2_MAX;   // largest PROVEN kappa_2 of the equilibrated (computed) system the tier takes
+constexpr double CSNE_PIVOT_FLOOR = 1.0e-11;   // smallest squared pivot of its factor (> (N + 1) eps trace: proven PD)
+#ifndef BLSQ_CSNE_ETA_MAX
+#define BLSQ_CSNE_ETA_MAX 1.0e-7
+#endif
+constexpr double CSNE_ETA_MAX = BLSQ_CSNE_ETA_MAX;   // largest measured first-order correction it accepts (second order
+                                                     // ~ 1e2 eta^2; calibration builds: EXTRA_DEFS=-DBLSQ_CSNE_ETA_MAX=...)
+struct CsneState {
+  int B, m, n, ld;
+  const double* J; long strideJ; int ldJ;   // the caller's [J f] of the current factor (read by every step call)
+  const double* F; long strideF;
+  int* flag;              // [B] 1: on the tier
+  int* list;              // [B] their indices, ascending
+  int* counts;            // [4]: [0] list length, [1] problems whose acceptance failed in the last step call
+  int* fail_list;         // [B] ... and their indices
+  int* ne;                // [B]            (LmState::csne_ne)
+  double* ralpha;         // [B][CSNE_MAXE] (LmState::csne_alpha)
+  double* rvec;           // [B][CSNE_MAXE][3][ld] (LmState::csne_vec)
+  double* part;           // [list position][chunks][NE][ld + 8] partial J_h^T (J_h p~ + f) and |J_h w~|^2 of the row chunks
+  double* hp;             // [B][ld] out: H p_h (TrfState::csne_hp)
+  double* eta;            // [B] out: the largest first-order correction measured (diagnostics / acceptance)
+  int rows_per_wg, nchunk, NE;   // set by the host (csne_geometry: functions of m and of the batch's deepest recording)
+};
+void csne_geometry(int m, int* rows_per_wg, int* nchunk);
+bool csne_supported(int m, int n);
+struct LmState;
+struct TrfState;
+// which of the nfb problems in tree_list (the certificate's rejects; k2 / sel_mask: the bound launch_gram_gate has just
+// computed for them with CSNE_K2_MAX) the tier takes: flag, path, rank-gate outputs; tree_list / tree_mask / tree_count
+// keep the others; list / counts[0] = every flagged problem of the plan
+hipError_t launch_csne_select(const CsneState& cs, const LmState& lm, int nfb, int* tree_list, int* tree_mask,
+                              int* tree_count, int* path, const int* sel_mask, const double* k2, const double* pmin,
+                              const double* colinfo, hipStream_t s);
+hipError_t launch_csne_pass(const CsneState& cs, const double* dvec, int count, hipStream_t s);
+hipError_t launch_csne_fix(const CsneState& cs, const TrfState& st, const LmState& lm, const double* Delta,
+                           const double* alpha_in, int count, hipStream_t s);
+// the problems of fail_list leave the tier: flag 0, path n + 1, tree_mask n + 1, tree_list = fail_list
+hipError_t launch_csne_reroute(const CsneState& cs, int nfail, int* tree_list, int* tree_mask, int* path, hipStream_t s);
+
 // ------------------------------------------------------------- Jacobi -----
 // One-sided Jacobi on the ROWS of the n x (n+1) array [R | c] (row stride ld):
 // U^T [R | c] = [S V^T | U^T c].  In place.
@@ -254,6 +305,10 @@ struct TrfState {         // all device pointers, batch-major, vector stride ld
   double *s, *uf;                         // [B][ld]
   double *srange;                         // [B][2]
   double *g_norm, *theta;                 // [B]
+  // CSNE tier (csne_kernels.hip): flag[b] = 1 for a problem the certificate rejected whose step is corrected against J
+  // itself; hp = H p_h by the normal-equations identity (the step kernel's model products with p_h); nullptr: off
+  int* csne;                              // [B]
+  const double* csne_hp;                  // [B][ld]
 };
 // jac_scaling: 0 keep `scale`; 1 scale = 1/||J col|| (0 -> 1)  (trf.py:216-219);
 //              2 scale = min(scale, 1/||J col||)               (trf.py:239-242)
@@ -339,6 +394,12 @@ struct LmState {
   const double* hmax;     // optional [B] (GramCholArgs::hmax of the augmented factorisation)
   const double* lam;      // [B] Lambda (GramCholArgs::lam_out)
   double k2_max;          // the gate
+  // CSNE tier: evaluations of a flagged problem are RECORDED (p~, w~ = M~^-1 p~, z~ = M~^-1 w~ and alpha of every
+  // evaluation) for the correction stage; nullptr: off
+  const int* csne;        // [B]
+  int* csne_ne;           // [B] evaluations recorded in this step call (CSNE_MAXE + 1: overflow)
+  double* csne_alpha;     // [B][CSNE_MAXE]
+  double* csne_vec;       // [B][CSNE_MAXE][3][ld]
   int fused_gram;         // 1: problems with path[b] == 0 belong to lm_rounds_reg_kernel (N <= 80) — lm_start
                           // and the round kernels leave them alone (a problem's arithmetic must not depend
                           // on whether its batch also holds Householder-path problems)

@@ -152,6 +152,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
   if (bad) {                                            // uniform: hand the problem to the QR tree
     if (tid == 0 && a.fb_mask) {
       a.fb_mask[b] = a.n + 1; { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }   // (the tree factors ALL n + 1 columns)
+      if (a.pmin_out && !a.cert_shift) a.pmin_out[b] = 0.0;
       if (a.path_out) a.path_out[b] = a.n + 1;
       if (a.k2_out && !a.cert_shift) a.k2_out[b] = 0.0;
     }
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_chol_kernel(GramCholArgs a) {
   if (tid == 0 && a.fb_mask) {
     const double floor_ = a.pivot_floor > 0.0 ? a.pivot_floor : 1.0 / GRAM_K2_MAX;
     const bool fail = !(pminsh >= floor_);
+    if (a.pmin_out && !a.cert_shift) a.pmin_out[b] = pminsh;
     a.fb_mask[b] = fail ? a.n + 1 : 0;
     if (a.path_out) a.path_out[b] = fail ? a.n + 1 : 0;
     if (fail) { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
@@ -420,6 +422,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
   if (bad) {                                            // hand the problem to the QR tree
     if (tid == 0 && a.fb_mask) {
       a.fb_mask[b] = a.n + 1; { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }   // (the tree factors ALL n + 1 columns)
+      if (a.pmin_out && !a.cert_shift) a.pmin_out[b] = 0.0;
       if (a.path_out) a.path_out[b] = a.n + 1;
       if (a.k2_out && !a.cert_shift) a.k2_out[b] = 0.0;
     }
@@ -502,6 +505,7 @@ __global__ __launch_bounds__(REG_NT, 1) void gram_chol_reg_kernel(GramCholArgs a
   const double kmax = a.k2_max > 0.0 ? a.k2_max : GRAM_K2_MAX;
   const bool fail = !(pmin >= (a.pivot_floor > 0.0 ? a.pivot_floor : 1.0 / GRAM_K2_MAX));
   if (tid == 0 && a.fb_mask) {
+    if (a.pmin_out && !a.cert_shift) a.pmin_out[b] = pmin;
     a.fb_mask[b] = fail ? a.n + 1 : 0;
     if (a.path_out) a.path_out[b] = fail ? a.n + 1 : 0;
     if (fail) { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
@@ -1177,6 +1181,7 @@ __device__ __forceinline__ void chol_rl_body(const GramCholArgs& a, const int b,
   if (bad) {
     if (tid == 0 && a.fb_mask) {
       a.fb_mask[b] = a.n + 1; { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }   // (the tree factors ALL n + 1 columns)
+      if (a.pmin_out && !a.cert_shift) a.pmin_out[b] = 0.0;
       if (a.path_out) a.path_out[b] = a.n + 1;
       if (a.k2_out && !a.cert_shift) a.k2_out[b] = 0.0;
     }
@@ -1359,6 +1364,7 @@ __device__ __forceinline__ void chol_rl_body(const GramCholArgs& a, const int b,
   CST(stp && (w == 0 || w == 2), w == 0 ? 2 : 3, 18, 1);
   if (tid == 0 && a.fb_mask) {
     const bool fail = !(pminsh >= (a.pivot_floor > 0.0 ? a.pivot_floor : 1.0 / GRAM_K2_MAX));
+    if (a.pmin_out && !a.cert_shift) a.pmin_out[b] = pminsh;
     a.fb_mask[b] = fail ? a.n + 1 : 0;
     if (a.path_out) a.path_out[b] = fail ? a.n + 1 : 0;
     if (fail) { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
@@ -1568,6 +1574,7 @@ __device__ __forceinline__ void chol_rl2_body(const GramCholArgs& a, const int b
   if (__hip_atomic_load(&fl[FL_BAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {   // uniform: to the QR tree
     if (tid == 0 && a.fb_mask) {
       a.fb_mask[b] = a.n + 1; { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }   // (the tree factors ALL n + 1 columns)
+      if (a.pmin_out && !a.cert_shift) a.pmin_out[b] = 0.0;
       if (a.path_out) a.path_out[b] = a.n + 1;
       if (a.k2_out && !a.cert_shift) a.k2_out[b] = 0.0;
     }
@@ -1766,6 +1773,7 @@ __device__ __forceinline__ void chol_rl2_body(const GramCholArgs& a, const int b
   }
   if (tid == 0 && a.fb_mask) {
     const bool fail = !(pminsh >= (a.pivot_floor > 0.0 ? a.pivot_floor : 1.0 / GRAM_K2_MAX));
+    if (a.pmin_out && !a.cert_shift) a.pmin_out[b] = pminsh;
     a.fb_mask[b] = fail ? a.n + 1 : 0;
     if (a.path_out) a.path_out[b] = fail ? a.n + 1 : 0;
     if (fail) { const int fi_ = atomicAdd(a.fail_count, 1); if (a.fail_list) a.fail_list[fi_] = b; }
@@ -2490,7 +2498,7 @@ hipError_t launch_gram_cert_shift(const GramCholArgs& a_in, int B, hipStream_t s
   a.dsc = nullptr; a.colinfo = nullptr; a.rinv = nullptr; a.cert_done = nullptr; a.unsettled = nullptr;
   a.dog = GramCholArgs::DogFinish{}; a.lmfin = GramCholArgs::LmFinish{};
   a.batch_list = nullptr; a.count_dev = nullptr; a.skip_path = nullptr; a.diag_sqrt = nullptr;
-  a.qr_mask = nullptr; a.hmax = nullptr; a.lam_out = nullptr;
+  a.qr_mask = nullptr; a.hmax = nullptr; a.lam_out = nullptr; a.pmin_out = nullptr;
   a.expect = B;                                         // (left-looking kernel: most workgroups leave at once)
   return launch_gram_chol(a, B, s);
 }

@@ -1,0 +1,516 @@
+// CSNE tier: corrected semi-normal equations for the problems the conditioning certificate keeps off the
+// normal-equations path (kappa_2 of the equilibrated system above the gate), in MEMORY-bound passes over J
+// instead of the MFMA-bound second factorisations of the CholeskyQR2 tier / the Householder tree.
+//
+// What the reference computes for such a problem (trf.py:264-308, trust_region.py:111-150) is a chain of
+// solves with M(alpha) = J_h^T J_h + diag_h + alpha I:  p(alpha) = -M^-1 g_h,  phi = ||p|| - Delta,
+// phi' = -p^T M^-1 p / ||p||,  a safeguarded Newton iteration on alpha, the final p.  The Gram-Cholesky factor
+// the problem already has (X^T X = H~ = H + E, |E| ~ eps ||H||) solves a NEARBY problem: every cheap solve is
+// off by T = M~^-1 E, ||T|| ~ c eps kappa_2 =: rho << 1 up to kappa_2 ~ 1e10.  Instead of a better factor
+// (two more m n^2 passes) the tier corrects the solves (Bjorck 1987: corrected semi-normal equations):
+//
+//   1. the cheap iteration runs as for any normal-equations-path problem and RECORDS every evaluation k:
+//      alpha~_k, p~_k = -M~_k^-1 g_h, w~_k = M~_k^-1 p~_k, z~_k = M~_k^-1 w~_k          (lm_body.h)
+//   2. ONE streaming pass over J (csne_pass_kernel) forms, for all recorded evaluations at once,
+//      y_k = J_h^T (J_h p~_k + f)  and  b_k = ||J_h w~_k||^2 — the residuals of the recorded solves against J
+//      ITSELF, f inside the product so that a small residual J p + f is not lost against g = J^T f
+//   3. csne_fix_kernel (n-space): res_k = y_k + (diag_h + alpha~_k) p~_k, and to first order in rho
+//         ||p_k||^2      = ||p~_k||^2 - 2 w~_k . res_k
+//         p_k^T M^-1 p_k = 2 p~_k . w~_k - (b_k + w~_k (diag_h + alpha) w~_k) - 2 z~_k . res_k
+//      (errors O(rho eta), eta the measured size of these corrections), phi'' from the cheap vectors; the scalar
+//      Newton iteration of the reference is REPLAYED on the corrected phi, phi' (Taylor models around alpha~_k:
+//      the replayed alpha_k differ from them by O(rho)), same brackets, restarts and stop rule, so alpha and n_iter
+//      come out as the reference's; the final step is p~_K - M~_K^-1 res_K - w~_K eps + z~_K eps^2
+//      (eps = alpha_K - alpha~_K), one corrected solve with the factor of the last evaluation
+//   4. the step kernel takes every model product with p from the normal equations the corrected p satisfies,
+//      H p = -(c g_h + alpha p)  (c: the final rescaling), instead of from the factor (trf_kernels.hip).
+//
+// Acceptance: PROVEN — the factor ran to completion with squared pivots >= CSNE_PIVOT_FLOOR and the certificate's
+// bound on kappa_2 of the COMPUTED system is <= CSNE_K2_MAX (M~ is positive definite, lambda_min >= 1 / K2), the
+// rank gate of the reference holds by that bound; MEASURED on the problem itself — every first-order correction
+// applied (eta) must be <= CSNE_ETA_MAX: the neglected second-order terms are rho eta with rho ~ 1e1..1e2 eta.
+// The replay must end at the evaluation the cheap iteration ended at.  Anything else leaves the tier (CholeskyQR2 /
+// Householder tree, as before) — per problem, by the problem's own numbers.
+#include "gram_common.h"
+#include "tri_ops.h"
+#include "lm_body.h"
+
+namespace blsq {
+
+// row chunks of the pass: a function of m ALONE (a problem's partial sums, and so every bit of its result, do not
+// depend on the batch it shares a launch with)
+void csne_geometry(int m, int* rows_per_wg, int* nchunk) {
+  int rows = 512;
+  while ((m + rows - 1) / rows > 64) rows *= 2;
+  *rows_per_wg = rows;
+  *nchunk = (m + rows - 1) / rows;
+}
+bool csne_supported(int m, int n) { return n + 1 > 80 && n <= 256 && m >= n; }
+
+static constexpr int CS_NT = 256;
+static constexpr int CS_NW = CS_NT / WAVE;
+static constexpr int CS_RB = 4;          // rows per wave and batch
+
+__host__ __device__ inline long csne_part_stride(int NE, int ld) { return (long)NE * ld + 16; }
+__device__ __forceinline__ constexpr int cs_bitrev4(int i) {
+  return ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3);
+}
+
+// ---- the pass over J -------------------------------------------------------------------------------
+// grid (row chunks, listed problems) x 256 threads.  Lane l owns columns l + 64 cb; a wave takes four rows per
+// batch: per row and recorded evaluation e the two dot products  u = J_h[r] . p~_e + f_r,  t = J_h[r] . w~_e
+// (J_h = J D: the vectors are pre-multiplied by d), their 64-lane totals by transposed butterflies (wave_sum16),
+// then  y_e += u J[r]  (per lane: its columns) and  b_e += t^2.  J is read exactly once, straight into registers
+// (the next batch is requested before the current one is consumed); no LDS on the way.
+template <int NCB, int NE>
+__global__ __launch_bounds__(CS_NT, 1) void csne_pass_kernel(CsneState cs, const double* __restrict__ dvec) {
+  constexpr int NV = 2 * NE;                              // totals per row
+  constexpr int NTOT = CS_RB * NV;                        // totals per batch
+  constexpr int NBF = (NTOT + 15) / 16;                   // butterflies per batch
+  __shared__ double ysh[(CS_NW - 1) * NE * NCB * WAVE];
+  __shared__ double bsh[CS_NW * NBF * 16];
+  const int li = blockIdx.y, chunk = blockIdx.x;
+  const int b = cs.list[li];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = cs.n, ld = cs.ld;
+  const int r0 = chunk * cs.rows_per_wg;
+  const int r1 = (r0 + cs.rows_per_wg < cs.m) ? r0 + cs.rows_per_wg : cs.m;
+  const double* __restrict__ Jb = cs.J + (long)b * cs.strideJ;
+  const double* __restrict__ Fb = cs.F + (long)b * cs.strideF;
+  int ne = cs.ne[b];
+  if (ne > NE) ne = NE;                                   // (deeper recordings are declined by csne_fix_kernel)
+  const int vidx = wave_sum16_index(lane);                // the total this lane receives from a butterfly
+
+  // the recorded vectors of the lane's columns, pre-multiplied by d (J_h = J D); zero beyond n and beyond the
+  // problem's recording: columns n .. 64 NCB of J are loaded clamped and count for nothing
+  double V[NE][2][NCB];
+#pragma unroll
+  for (int e = 0; e < NE; ++e)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int col = lane + 64 * cb;
+        double v = 0.0;
+        if (e < ne && col < n)
+          v = dvec[(long)b * ld + col] * cs.rvec[(((long)b * CSNE_MAXE + e) * 3 + c) * ld + col];
+        V[e][c][cb] = v;
+      }
+  double y[NE][NCB];
+#pragma unroll
+  for (int e = 0; e < NE; ++e)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) y[e][cb] = 0.0;
+  double accB[NBF];
+#pragma unroll
+  for (int g = 0; g < NBF; ++g) accB[g] = 0.0;
+
+  const int nbatch = (r1 - r0 + CS_RB - 1) / CS_RB;
+  double jr[2][CS_RB][NCB], fr[2][NBF];
+  auto issue = [&](int bi, int slot) {
+    const int rb = r0 + bi * CS_RB;
+#pragma unroll
+    for (int r = 0; r < CS_RB; ++r) {
+      const int row = rb + r;
+      const int rc = row < r1 ? row : r1 - 1;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int col = lane + 64 * cb;
+        jr[slot][r][cb] = __builtin_nontemporal_load(Jb + (long)rc * cs.ldJ + (col < n ? col : n - 1));
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < NBF; ++g) {
+      const int row = rb + (16 * g + vidx) / NV;
+      fr[slot][g] = Fb[row < r1 ? row : r1 - 1];
+    }
+  };
+  auto consume = [&](int bi, int slot) {
+    const int rb = r0 + bi * CS_RB;
+    if (rb + CS_RB > r1) {                                 // (uniform; the last batch of a chunk only) rows beyond it: zero
+#pragma unroll
+      for (int r = 0; r < CS_RB; ++r)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+          if (rb + r >= r1) jr[slot][r][cb] = 0.0;
+#pragma unroll
+      for (int g = 0; g < NBF; ++g)
+        if (rb + (16 * g + vidx) / NV >= r1) fr[slot][g] = 0.0;
+    }
+    // one butterfly's sixteen totals at a time: their dot products, the butterfly, what the totals feed
+#pragma unroll
+    for (int g = 0; g < NBF; ++g) {
+      double v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int idx = 16 * g + i;
+        double acc = 0.0;
+        if (idx < NTOT) {
+          const int r = idx / NV, e = (idx % NV) / 2, c = idx % 2;
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) acc = fma(jr[slot][r][cb], V[e][c][cb], acc);
+        }
+        v[i] = acc;
+      }
+      wave_sum16(v);
+      const double tot = v[0];
+      const double uu = tot + fr[slot][g];                // (meaningful on the lanes of the u totals: bit 3 clear)
+      const double tt = dpp_mov<0x108>(tot);              // row_shl:8 — the t total of the same (row, evaluation)
+      accB[g] = fma(tt, tt, accB[g]);                     // (read from the lanes with bit 3 clear only)
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {                   // the u totals of this butterfly: broadcast and axpy
+        const int idx = 16 * g + i;
+        if (idx < NTOT) {
+          const int r = idx / NV, e = (idx % NV) / 2;
+          const double us = read_lane(uu, cs_bitrev4(i));
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) y[e][cb] = fma(us, jr[slot][r][cb], y[e][cb]);
+        }
+      }
+    }
+  };
+  // wave w takes batches w, w + 4, ...; one batch in flight behind the one being consumed
+  int bi = w;
+  if (bi < nbatch) issue(bi, 0);
+  int slot = 0;
+  for (; bi < nbatch; bi += CS_NW) {
+    const int nxt = bi + CS_NW;
+    if (slot == 0) {
+      if (nxt < nbatch) issue(nxt, 1);
+      consume(bi, 0);
+    } else {
+      if (nxt < nbatch) issue(nxt, 0);
+      consume(bi, 1);
+    }
+    slot ^= 1;
+  }
+  // the four waves' partial sums, added in wave order
+  if (w > 0) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) ysh[(((w - 1) * NE + e) * NCB + cb) * WAVE + lane] = y[e][cb];
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int g = 0; g < NBF; ++g) bsh[(w * NBF + g) * 16 + lane] = accB[g];
+  }
+  __syncthreads();
+  double* out = cs.part + ((long)li * cs.nchunk + chunk) * csne_part_stride(NE, ld);
+  if (w == 0) {
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        double t = y[e][cb];
+#pragma unroll
+        for (int q = 0; q < CS_NW - 1; ++q) t += ysh[((q * NE + e) * NCB + cb) * WAVE + lane];
+        const int col = lane + 64 * cb;
+        if (col < n) out[(long)e * ld + col] = t;
+      }
+  }
+  if (tid < NE) {                                         // b_e: the lanes of its t^2 sums, in a fixed order
+    double t = 0.0;
+    for (int q = 0; q < CS_NW; ++q)
+      for (int g = 0; g < NBF; ++g)
+        for (int l = 0; l < 8; ++l) {                     // lanes 0 .. 7 of a wave (bit 3 clear: the u totals' lanes)
+          const int idx = 16 * g + cs_bitrev4(l);
+          if (idx < NTOT && (idx % NV) / 2 == tid) t += bsh[(q * NBF + g) * 16 + l];
+        }
+    out[(long)NE * ld + tid] = t;
+  }
+}
+
+template <int NCB>
+static hipError_t csne_pass_launch(const CsneState& cs, const double* dvec, int count, hipStream_t s) {
+  const dim3 grid(cs.nchunk, count), block(CS_NT);
+  switch (cs.NE) {
+    case 1: hipLaunchKernelGGL((csne_pass_kernel<NCB, 1>), grid, block, 0, s, cs, dvec); break;
+    case 2: hipLaunchKernelGGL((csne_pass_kernel<NCB, 2>), grid, block, 0, s, cs, dvec); break;
+    case 3: hipLaunchKernelGGL((csne_pass_kernel<NCB, 3>), grid, block, 0, s, cs, dvec); break;
+    case 4: hipLaunchKernelGGL((csne_pass_kernel<NCB, 4>), grid, block, 0, s, cs, dvec); break;
+    case 5: hipLaunchKernelGGL((csne_pass_kernel<NCB, 5>), grid, block, 0, s, cs, dvec); break;
+    case 6: hipLaunchKernelGGL((csne_pass_kernel<NCB, 6>), grid, block, 0, s, cs, dvec); break;
+    case 7: hipLaunchKernelGGL((csne_pass_kernel<NCB, 7>), grid, block, 0, s, cs, dvec); break;
+    case 8: hipLaunchKernelGGL((csne_pass_kernel<NCB, 8>), grid, block, 0, s, cs, dvec); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_csne_pass(const CsneState& cs, const double* dvec, int count, hipStream_t s) {
+  if (count <= 0) return hipSuccess;
+  const int ncb = (cs.n + 63) / 64;
+  if (ncb <= 2) return csne_pass_launch<2>(cs, dvec, count, s);
+  if (ncb == 3) return csne_pass_launch<3>(cs, dvec, count, s);
+  if (ncb == 4) return csne_pass_launch<4>(cs, dvec, count, s);
+  return hipErrorInvalidValue;
+}
+
+// ---- the correction, in n-space -------------------------------------------------------------------
+// NSUM block totals at once: per-thread partials -> one transposed butterfly per wave -> the waves in order.
+// scr: CS_NW * 16 doubles of LDS.  Every thread gets all totals.  Fixed order.
+template <int NSUM>
+__device__ __forceinline__ void cs_block_sums(double (&part)[NSUM], double* scr) {
+  static_assert(NSUM <= 16, "one butterfly");
+  double v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = i < NSUM ? part[i] : 0.0;
+  wave_sum16(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();                                        // (scr may still be read from an earlier call)
+  if (lane < 16) scr[w * 16 + wave_sum16_index(lane)] = v[0];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NSUM; ++i) {
+    double t = 0.0;
+    for (int q = 0; q < TRI_NW; ++q) t += scr[q * 16 + i];
+    part[i] = t;
+  }
+}
+
+__global__ __launch_bounds__(TRI_NT) void csne_fix_kernel(CsneState cs, TrfState st, LmState lm,
+                                                          const double* Delta_in, const double* alpha_in) {
+  extern __shared__ double sh[];
+  __shared__ double red[32];
+  __shared__ double scr[TRI_NW * 16];
+  __shared__ double kphi[CSNE_MAXE], kdphi[CSNE_MAXE], kddphi[CSNE_MAXE], kalpha[CSNE_MAXE], keta[CSNE_MAXE];
+  const int li = blockIdx.x;
+  const int b = cs.list[li];
+  const int tid = threadIdx.x;
+  const int n = cs.n, ld = cs.ld;
+  const long vo = (long)b * ld;
+  double* res = sh;
+  double* pv = res + ld;
+  double* wv = pv + ld;
+  double* zv = wv + ld;
+  double* invd = zv + ld;
+  double* q = invd + ld;
+  double* pfbuf = q + ld;                                 // 2 x 16 x ld doubles: DMA staging of the solves
+  const double* dg = st.d + vo;
+  const double* gh = st.g_h + vo;
+  const double* dh = st.diag_h + vo;
+  const double Delta = Delta_in[b];
+  const int ne = cs.ne[b];
+  const int NE = cs.NE;
+  const long PS = csne_part_stride(NE, ld);
+  const double* part = cs.part + (long)li * cs.nchunk * PS;
+  bool fail = (ne < 1 || ne > CSNE_MAXE || ne > NE);      // (uniform)
+  // ||g_h|| with the operations of lm_start_body: the bracket's upper end is the cheap run's, bit for bit
+  for (int i = tid; i < n; i += TRI_NT) q[i] = gh[i];
+  __syncthreads();
+  const double gnorm = sqrt(tri_dot<TRI_NT>(q, q, n, red));
+  // residual of recorded evaluation k into `res`, its vectors into pv / wv / zv; the eight sums
+  auto load_eval = [&](int k, double (&sums)[8]) {
+    const double ak = cs.ralpha[(long)b * CSNE_MAXE + k];
+    const double* rec = cs.rvec + ((long)b * CSNE_MAXE + k) * 3 * ld;
+    double pp = 0.0, pw = 0.0, ww = 0.0, pz = 0.0, wr = 0.0, zr = 0.0, wdw = 0.0, rr = 0.0;
+    __syncthreads();
+    for (int j = tid; j < n; j += TRI_NT) {
+      double yj = 0.0;
+      for (int c = 0; c < cs.nchunk; ++c) yj += part[(long)c * PS + (long)k * ld + j];
+      const double pj = rec[j], wj = rec[ld + j], zj = rec[2 * ld + j];
+      const double sh_ = dh[j] + ak;
+      const double rj = fma(dg[j], yj, sh_ * pj);        // d_j (J^T u)_j + (diag_h + alpha) p~_j
+      res[j] = rj; pv[j] = pj; wv[j] = wj; zv[j] = zj;
+      pp = fma(pj, pj, pp); pw = fma(pj, wj, pw); ww = fma(wj, wj, ww); pz = fma(pj, zj, pz);
+      wr = fma(wj, rj, wr); zr = fma(zj, rj, zr); wdw = fma(sh_ * wj, wj, wdw); rr = fma(rj, rj, rr);
+    }
+    sums[0] = pp; sums[1] = pw; sums[2] = ww; sums[3] = pz; sums[4] = wr; sums[5] = zr; sums[6] = wdw; sums[7] = rr;
+    cs_block_sums<8>(sums, scr);
+  };
+  if (!fail) {
+    for (int k = 0; k < ne; ++k) {
+      double s8[8];
+      load_eval(k, s8);
+      const double pp = s8[0], pw = s8[1], ww = s8[2], pz = s8[3], wr = s8[4], zr = s8[5], wdw = s8[6];
+      double bk = 0.0;
+      for (int c = 0; c < cs.nchunk; ++c) bk += part[(long)c * PS + (long)NE * ld + k];
+      const double pn2 = pp - 2.0 * wr;                   // ||p||^2 to first order
+      const double pn = sqrt(pn2);
+      const double pMp = (2.0 * pw - (bk + wdw)) - 2.0 * zr;   // p^T M^-1 p to first order
+      const double e1 = fabs(2.0 * wr) / pp, e2 = fabs(pMp - pw) / fabs(pw);
+      if (tid == 0) {
+        kalpha[k] = cs.ralpha[(long)b * CSNE_MAXE + k];
+        kphi[k] = pn - Delta;
+        kdphi[k] = -pMp / pn;
+        kddphi[k] = (ww + 2.0 * pz) / pn - (pw * pw) / (pn * pn * pn);
+        keta[k] = e1 > e2 ? e1 : e2;
+      }
+      if (!(pn2 > 0.0) || !(pMp > 0.0) || !is_finite(pn2) || !is_finite(pMp)) fail = true;
+    }
+  }
+  __syncthreads();
+  // ---- replay of trust_region.py:111-150 on the corrected phi, phi' ----
+  int kf = 0, n_iter = 0;
+  double alpha = 0.0, eps = 0.0, phi_f = 0.0, eta = 0.0;
+  if (!fail) {
+    eta = keta[0];
+    if (kphi[0] <= 0.0) {                                 // ||p(0)|| <= Delta  (:116-117)
+      kf = 0; alpha = 0.0; n_iter = 0; phi_f = 0.0;
+    } else {
+      double lo = -kphi[0] / kdphi[0];                    // :121-123
+      double hi = gnorm / Delta;                          // :119
+      alpha = alpha_in[b];                                // :127-130 (full rank)
+      if (alpha < lo || alpha > hi) alpha = lm_restart(lo, hi);
+      int it = 0;
+      bool done = false;
+      for (int k = 1; !done; ++k) {
+        if (k >= ne) { fail = true; break; }              // the replay needs an evaluation the cheap run did not make
+        const double e = alpha - kalpha[k];
+        if (!(fabs(e) <= 1.0e-3 * fabs(kalpha[k]))) { fail = true; break; }   // (not the iterate the cheap run evaluated)
+        const double phi = kphi[k] + (kdphi[k] + 0.5 * kddphi[k] * e) * e;
+        const double dphi = kdphi[k] + kddphi[k] * e;
+        eta = keta[k] > eta ? keta[k] : eta;
+        if (fabs(phi) < 0.01 * Delta) {                   // :138-139
+          kf = k; eps = e; phi_f = phi; n_iter = it + 1; done = true;
+          break;
+        }
+        if (phi < 0.0) hi = alpha;                        // :141-142
+        const double ratio = phi / dphi;
+        const double cand = alpha - ratio;
+        lo = (cand > lo) ? cand : lo;                     // :145
+        alpha -= (phi + Delta) * ratio / Delta;           // :146
+        ++it;
+        if (it >= 10) { fail = true; break; }             // (ten rounds: beyond what the tier records)
+        if (alpha < lo || alpha > hi) alpha = lm_restart(lo, hi);   // :133-134 of the next pass
+      }
+    }
+    if (!fail && kf + 1 != ne) fail = true;               // the cheap run did not end where the replay ends
+  }
+  double dpn = 0.0;
+  if (!fail) {
+    // ---- the final step: one corrected solve with the factor of the last evaluation ----
+    double s8[8];
+    load_eval(kf, s8);
+    const double pp = s8[0];
+    const double* R = (kf == 0 ? lm.Raug : lm.Xa) + (long)b * ld * ld;
+    tri_invdiag<TRI_NT>(R, n, ld, invd);
+    for (int j = tid; j < n; j += TRI_NT) q[j] = -res[j];
+    __syncthreads();
+    tri_solve_upper_t_pf<TRI_NT>(R, n, ld, invd, q, pfbuf);
+    tri_solve_upper_pf<TRI_NT>(R, n, ld, invd, q, pfbuf);
+    double s2[2] = {0.0, 0.0};
+    for (int j = tid; j < n; j += TRI_NT) {
+      const double dj = q[j];
+      const double pj = (pv[j] + dj) - wv[j] * eps + zv[j] * (eps * eps);
+      res[j] = pj;
+      s2[0] = fma(pj, pj, s2[0]); s2[1] = fma(dj, dj, s2[1]);
+    }
+    cs_block_sums<2>(s2, scr);
+    const double pn = sqrt(s2[0]);
+    dpn = sqrt(s2[1] / pp);
+    eta = dpn > eta ? dpn : eta;
+    if (!(eta <= CSNE_ETA_MAX) || !is_finite(pn) || !(pn > 0.0)) fail = true;
+    if (!fail) {
+      const double c = (phi_f > 0.0) ? Delta / pn : 1.0;  // :149-150
+      for (int j = tid; j < n; j += TRI_NT) {
+        const double pj = res[j] * c;
+        lm.ph[vo + j] = pj;
+        cs.hp[vo + j] = -(c * gh[j] + alpha * pj);        // H p_h by the normal equations the corrected p satisfies
+      }
+      if (tid == 0) {
+        lm.sc[(long)b * 16 + SC_ALPHA] = alpha;
+        lm.st[(long)b * 4 + ST_NITER] = n_iter;
+      }
+    }
+  }
+  if (tid == 0) {
+    cs.eta[b] = fail ? -1.0 : eta;
+    if (fail) cs.fail_list[atomicAdd(cs.counts + 1, 1)] = b;
+  }
+}
+
+hipError_t launch_csne_fix(const CsneState& cs, const TrfState& st, const LmState& lm, const double* Delta,
+                           const double* alpha_in, int count, hipStream_t s) {
+  if (count <= 0) return hipSuccess;
+  const size_t lds = sizeof(double) * (6 + 32) * (size_t)cs.ld;
+  static std::atomic<size_t> granted[64];
+  hipError_t ge = gram_grant_lds(csne_fix_kernel, lds, granted);
+  if (ge != hipSuccess) return ge;
+  hipLaunchKernelGGL(csne_fix_kernel, dim3(count), dim3(TRI_NT), lds, s, cs, st, lm, Delta, alpha_in);
+  return hipGetLastError();
+}
+
+// ---- who is on the tier ---------------------------------------------------------------------------
+// order-preserving compaction by ONE workgroup of 256 threads: out[0 .. return) = the entries e of
+// get(0 .. count) with keep(e); in place allowed (the writes of a tile never pass its reads)
+template <class Get, class Keep>
+__device__ __forceinline__ int cs_compact(int count, int* out, Get get, Keep keep, int* scr) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int base = 0;
+  for (int t0 = 0; t0 < count; t0 += 256) {
+    const int i = t0 + tid;
+    const int e = i < count ? get(i) : 0;
+    const bool k = i < count && keep(e);
+    const unsigned long long bal = __ballot(k);
+    __syncthreads();
+    if (lane == 0) scr[w] = __popcll(bal);
+    __syncthreads();
+    int off = base;
+    for (int q = 0; q < w; ++q) off += scr[q];
+    if (k) out[off + __popcll(bal & ((1ull << lane) - 1ull))] = e;
+    base += scr[0] + scr[1] + scr[2] + scr[3];
+  }
+  __syncthreads();
+  return base;
+}
+
+__global__ __launch_bounds__(256) void csne_select_kernel(CsneState cs, LmState lm, int nfb, int* tree_list, int* tree_mask,
+                                                          int* tree_count, int* path, const int* sel_mask,
+                                                          const double* k2, const double* pmin, const double* colinfo) {
+  __shared__ int scr[4];
+  const int tid = threadIdx.x;
+  const int n = cs.n;
+  for (int i = tid; i < nfb; i += 256) {
+    const int b = tree_list[i];
+    const double kb = k2[b], mn = colinfo[2 * (long)b], sm = colinfo[2 * (long)b + 1];
+    bool ok = sel_mask[b] == 0 && kb > 0.0 && kb <= CSNE_K2_MAX && pmin[b] >= CSNE_PIVOT_FLOOR && lm.m >= n;
+    // the reference's rank test (trust_region.py:108-110) by the proven bound: s_min(R_aug)^2 >= min_j h_jj / K2
+    const double smin_lb = mn / sqrt(kb), smax_ub = sqrt(sm);
+    ok = ok && is_finite(sm) && sm > 0.0 && smin_lb > LM_GATE_MARGIN * LM_EPS * lm.m * smax_ub;
+    if (ok) {
+      cs.flag[b] = 1; path[b] = 0; tree_mask[b] = 0;
+      lm.fast[b] = 1; lm.ncols_jac[b] = 0;
+      lm.sc[(long)b * 16 + SC_SMAX] = smax_ub;
+      lm.sc[(long)b * 16 + SC_SMIN] = smin_lb;
+      lm.st[(long)b * 4 + ST_PHASE] = LM_IDLE;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  const int ntree = cs_compact(nfb, tree_list, [&](int i) { return tree_list[i]; },
+                               [&](int b) { return cs.flag[b] == 0; }, scr);
+  const int ncs = cs_compact(cs.B, cs.list, [&](int i) { return i; }, [&](int b) { return cs.flag[b] != 0; }, scr);
+  if (tid == 0) { *tree_count = ntree; cs.counts[0] = ncs; }
+}
+
+hipError_t launch_csne_select(const CsneState& cs, const LmState& lm, int nfb, int* tree_list, int* tree_mask,
+                              int* tree_count, int* path, const int* sel_mask, const double* k2, const double* pmin,
+                              const double* colinfo, hipStream_t s) {
+  hipLaunchKernelGGL(csne_select_kernel, dim3(1), dim3(256), 0, s, cs, lm, nfb, tree_list, tree_mask, tree_count, path,
+                     sel_mask, k2, pmin, colinfo);
+  return hipGetLastError();
+}
+
+// the problems whose acceptance failed in the last step call leave the tier for good (until the next factor call)
+__global__ __launch_bounds__(256) void csne_reroute_kernel(CsneState cs, int nfail, int* tree_list, int* tree_mask, int* path) {
+  __shared__ int scr[4];
+  const int tid = threadIdx.x;
+  // (nfail < 0: only the list is rebuilt from the flags — a masked factor call has refreshed some problems)
+  for (int b = tid; b < cs.B && nfail >= 0; b += 256) tree_mask[b] = 0;
+  __syncthreads();
+  for (int i = tid; i < nfail; i += 256) {
+    const int b = cs.fail_list[i];
+    cs.flag[b] = 0; path[b] = cs.n + 1; tree_mask[b] = cs.n + 1; tree_list[i] = b;
+  }
+  __threadfence_block();
+  __syncthreads();
+  const int ncs = cs_compact(cs.B, cs.list, [&](int i) { return i; }, [&](int b) { return cs.flag[b] != 0; }, scr);
+  if (tid == 0) cs.counts[0] = ncs;
+}
+hipError_t launch_csne_reroute(const CsneState& cs, int nfail, int* tree_list, int* tree_mask, int* path, hipStream_t s) {
+  hipLaunchKernelGGL(csne_reroute_kernel, dim3(1), dim3(256), 0, s, cs, nfail, tree_list, tree_mask, path);
+  return hipGetLastError();
+}
+
+}  // namespace blsq

@@ -26,6 +26,29 @@ __device__ __forceinline__ double lm_restart(double lo, double hi) {
   return (0.001 * hi > gm) ? 0.001 * hi : gm;
 }
 
+// CSNE tier (csne_kernels.hip): evaluation k of a flagged problem is RECORDED for the correction stage — p~ (in `p`),
+// w~ = M~^-1 p~ and z~ = M~^-1 w~ with M~ = R^T R the factor at hand, and alpha.  q: LDS scratch (destroyed).
+template <int NT>
+__device__ __forceinline__ void lm_csne_record(const LmState& lm, int b, int k, double alpha, const double* R,
+                                               const double* invd, const double* p, double* q, double* pfbuf) {
+  const int tid = threadIdx.x, n = lm.n, ld = lm.ld;
+  if (k >= CSNE_MAXE) {                                   // (uniform) deeper than the tier records: it will decline
+    if (tid == 0) lm.csne_ne[b] = CSNE_MAXE + 1;
+    return;
+  }
+  double* rec = lm.csne_vec + ((long)b * CSNE_MAXE + k) * 3 * ld;
+  for (int i = tid; i < n; i += NT) { const double v = p[i]; q[i] = v; rec[i] = v; }
+  __syncthreads();
+  tri_solve_upper_t_pf<NT>(R, n, ld, invd, q, pfbuf);
+  tri_solve_upper_pf<NT>(R, n, ld, invd, q, pfbuf);
+  for (int i = tid; i < n; i += NT) rec[ld + i] = q[i];
+  tri_solve_upper_t_pf<NT>(R, n, ld, invd, q, pfbuf);
+  tri_solve_upper_pf<NT>(R, n, ld, invd, q, pfbuf);
+  for (int i = tid; i < n; i += NT) rec[2 * ld + i] = q[i];
+  if (tid == 0) { lm.csne_alpha[(long)b * CSNE_MAXE + k] = alpha; lm.csne_ne[b] = k + 1; }
+  __syncthreads();
+}
+
 // Gauss-Newton step (alpha = 0) on R_aug, acceptance test, bracket initialisation (trust_region.py:111-130).
 // enqueue: append an iterating problem to evaluation list 0 (the lock-step loop); the fused kernel keeps it.
 // -> the problem's phase afterwards (LM_IDLE: nothing to iterate)
@@ -66,6 +89,7 @@ __device__ __forceinline__ int lm_start_body(const LmState& lm, int b, const dou
     lm.ph[(long)b * ld + i] = p[i];
   }
   __syncthreads();
+  if (lm.csne && lm.csne[b]) lm_csne_record<NT>(lm, b, 0, 0.0, R, invd, p, q, pfbuf);   // (uniform)
   if (pn <= Delta) {                                                      // trust_region.py:116-117
     if (tid == 0) {
       sc[SC_ALPHA] = 0.0; st[ST_NITER] = 0; st[ST_PHASE] = LM_IDLE; sc[SC_DELTA] = Delta;
@@ -128,6 +152,7 @@ __device__ __forceinline__ int lm_update_body(const LmState& lm, int b, double* 
     // loop exhausted (:132 ran 10 times without break): p at the UPDATED alpha, rescale
     // test on the STALE phi (:149)
     finished = true;
+    if (lm.csne && lm.csne[b] && tid == 0) lm.csne_ne[b] = CSNE_MAXE + 1;   // (ten rounds: beyond what the tier records)
   } else {
     for (int i = tid; i < n; i += NT) q[i] = p[i];
     __syncthreads();
@@ -135,6 +160,7 @@ __device__ __forceinline__ int lm_update_body(const LmState& lm, int b, double* 
     const double qq = tri_dot<NT>(q, q, n, red);
     phi = pn - Delta;
     dphi = -qq / pn;
+    if (lm.csne && lm.csne[b]) lm_csne_record<NT>(lm, b, it + 1, alpha, R, invd, p, q, pfbuf);   // (uniform)
     if (fabs(phi) < 0.01 * Delta) {                       // :138-139
       finished = true;
       n_iter = it + 1;

@@ -50,6 +50,7 @@ __global__ __launch_bounds__(TRI_NT) void lm_gate_kernel(LmState lm, int enable)
   extern __shared__ double sh[];
   __shared__ double red[32];
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (lm.csne && lm.csne[b]) return;                      // (CSNE tier: gated by its own proven bound, csne_select_kernel)
   const int n = lm.n, ld = lm.ld, N = n + 1;
   const double* R = lm.Raug + (long)b * ld * ld;
   double* v = sh;

@@ -25,6 +25,7 @@ __global__ __launch_bounds__(NS_NT) void trf_prep_kernel(TrfState st, int jac_sc
   const int b = blockIdx.x, tid = threadIdx.x;
   if (b == 0 && pk.zero && tid < pk.nzero) pk.zero[tid] = 0;
   if (sel && sel[b] <= 1) return;
+  if (st.csne && tid == 0) st.csne[b] = 0;               // (a problem prepared afresh is on the CSNE tier only if selected again)
   const int n = st.n, ld = st.ld;
   const double* Rt = st.Rt + (long)b * ld * ld;
   const double* Gk = from_gram ? st.Gk + (long)b * ld * ld : nullptr;
@@ -415,6 +416,12 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
   // after the SVD the rows s_i v_i^T — an orthogonal transformation of it), so every quadratic form
   // of the model, (J_h a).(J_h b) + a.diag_h.b, is (X a).(X b): the diag_h terms below drop out.
   const bool gp = st.path && st.path[b] == 0;
+  // CSNE tier (csne_kernels.hip): the factor X of such a problem is a preconditioner only — its products with the
+  // trust-region solution p would carry the Gram's error, relative to (X p)^2 of order eps kappa_2.  The corrected p
+  // satisfies the normal equations, so every product with it is taken from  H p = -(c g_h + alpha p)  (hp, written by
+  // csne_fix_kernel); products of vectors that are NOT in the small singular subspace still go through X.
+  const bool cs_ = gp && st.csne && st.csne[b] && lm_fast && lm_fast[b];
+  const double* hp = st.csne_hp + vo;
   const double* xg = st.x + vo;
   const double* dg = st.d + vo;
   const double* gh = st.g_h + vo;
@@ -559,9 +566,13 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
     const double f = (tt < 1.0) ? tt : 1.0;                  // min(theta*to_bound, 1)
     for (int j = tid; j < n; j += NS_NT) { ph[j] *= f; tmp[j] = dg[j]; }   // (d staged in LDS: tmp = p is done with)
     __syncthreads();
-    if (!gp) tri_matvec(Rh, tmp, n, ld, ph, up);
-    else model_mv(ph, up);
-    const double q2 = dot_dev(up, up, n, red);
+    double q2;
+    if (cs_) q2 = f * dot_dev(ph, hp, n, red);            // (f p)^T H (f p) = f (f p) . hp
+    else {
+      if (!gp) tri_matvec(Rh, tmp, n, ld, ph, up);
+      else model_mv(ph, up);
+      q2 = dot_dev(up, up, n, red);
+    }
     double dq = 0.0, lin = 0.0;
     for (int j = tid; j < n; j += NS_NT) {
       dq += dh[j] * (ph[j] * ph[j]);
@@ -580,8 +591,15 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
       double rj = ph[j];
       if (hit) rj *= -1.0;
       rh[j] = rj;                                            // r_h
+      if (cs_) ur[j] = hit ? ph[j] : 0.0;                    // the hit components of p_h (CSNE: X r_h = X p_h - 2 X p_hits)
     }
     __syncthreads();
+    double cs_pp = 0.0, cs_hp = 0.0, cs_rp = 0.0;            // p.Hp, p_hits.Hp, r.Hp  (unscaled p)
+    if (cs_) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      for (int j = tid; j < n; j += NS_NT) { a0 += ph[j] * hp[j]; a1 += ur[j] * hp[j]; a2 += rh[j] * hp[j]; }
+      cs_pp = block_sum(a0, red); cs_hp = block_sum(a1, red); cs_rp = block_sum(a2, red);
+    }
     for (int j = tid; j < n; j += NS_NT) {
       const double pj = tmp[j] * p_stride;                   // p *= p_stride
       ph[j] = ph[j] * p_stride;                              // p_h *= p_stride
@@ -620,21 +638,33 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
       for (int j = tid; j < n; j += NS_NT) { tmp[j] = dg[j]; tmp2[j] = gh[j]; }
       __syncthreads();
       if (!gp) tri_matvec3(Rh, tmp, n, ld, ph, up, need_r ? rh : nullptr, ur, tmp2, ug);
+      else if (cs_) tri_matvec3(X, nullptr, n, ld, ur, up, nullptr, nullptr, tmp2, ug);   // up = X p_hits
       else if (fast) tri_matvec3(X, nullptr, n, ld, ph, up, need_r ? rh : nullptr, ur, tmp2, ug);
       else full_matvec3(X, n, ld, ph, up, need_r ? rh : nullptr, ur, tmp2, ug);
+    } else if (cs_) {
+      model_mv(ur, up);                                      // up = X p_hits
     } else {
       model_mv(ph, up);
       if (need_r) model_mv(rh, ur);
+    }
+    // CSNE: the three quadratic forms of the branch from the identities (p_stride = s):
+    //   |X (s p)|^2 = s^2 p.Hp,   (X s p).(X r) = s r.Hp,   |X r|^2 = p.Hp - 4 p_hits.Hp + 4 |X p_hits|^2
+    double cs_q0 = 0.0, cs_uv = 0.0, cs_vv = 0.0;
+    if (cs_) {
+      const double hh = dot_dev(up, up, n, red);
+      cs_q0 = (p_stride * p_stride) * cs_pp;
+      cs_uv = p_stride * cs_rp;
+      cs_vv = (cs_pp - 4.0 * cs_hp) + 4.0 * hh;
     }
     SST(6);
     bool have_r = false;
     double r_t = 0.0;
     if (need_r) {
-      const double vv = dot_dev(ur, ur, n, red);
+      const double vv = cs_ ? cs_vv : dot_dev(ur, ur, n, red);
       const double sds = dot3_dev(rh, dh, rh, n, red);
       const double qa = gp ? 0.5 * vv : 0.5 * (vv + sds);
       double qb = dot_dev(gh, rh, n, red);
-      const double uv = dot_dev(up, ur, n, red);
+      const double uv = cs_ ? cs_uv : dot_dev(up, ur, n, red);
       const double s0ds = dot3_dev(ph, dh, rh, n, red);
       qb += gp ? uv : uv + s0ds;
       r_t = quad_min_dev(qa, qb, r_lo, r_hi);
@@ -679,6 +709,10 @@ __global__ __launch_bounds__(NS_NT) void trf_step_kernel(TrfState st, const int*
       q0 += a0 * a0; q1 += a1 * a1; q2 += a2 * a2;
     }
     q0 = block_sum(q0, red); q1 = block_sum(q1, red); q2 = block_sum(q2, red);
+    if (cs_) {                                               // (up / ur hold other things: the forms from the identities)
+      q0 = (theta * theta) * cs_q0;
+      q1 = have_r ? (cs_q0 + 2.0 * r_t * cs_uv) + (r_t * r_t) * cs_vv : q0;
+    }
     double d0 = 0.0, d1 = 0.0, d2 = 0.0, l0 = 0.0, l1 = 0.0, l2 = 0.0;
     for (int j = tid; j < n; j += NS_NT) {
       d0 += dh[j] * (ph[j] * ph[j]);  l0 += ph[j] * gh[j];

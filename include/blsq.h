@@ -237,6 +237,19 @@ int blsq_debug_cqr_stats(blsq_ctx* ctx, uint64_t out[2], int reset);
  * middle tier factored (second pass over J through the MFMA pipe, proven acceptance test)
  * instead of the Householder tree, since the last reset.  Synchronises the ctx stream. */
 int blsq_debug_cqr2_stats(blsq_ctx* ctx, uint64_t* out1, int reset);
+/* Diagnostics of the CSNE tier (corrected semi-normal equations, DESIGN.md 3.0d: a rejected problem of 80 <= n <= 256
+ * keeps its Gram-Cholesky factor as a preconditioner and every step-solve corrects the trust-region solution against J
+ * itself in ONE streaming pass; replaces what the reference gets from svd(J_augmented), trf.py:272-274 +
+ * trust_region.py:111-150, for such a problem): out[0] = problems factor calls routed to the tier, out[1] = step-solves
+ * it delivered, out[2] = step-solves it declined (measured correction above its bound: the problem went on to
+ * CholeskyQR2 / the Householder tree in that step call), since the last reset.
+ * LIFETIME RULE of the tier: while a plan holds problems on it (blsq_debug_csne_stats out[0] grows), blsq_trf_step_dev
+ * READS the dJ / df of the last blsq_trf_factor_dev: they must stay valid and unmodified until the next factor call on
+ * the plan (the reference's drivers keep J for exactly that long, trf.py:283-352).  BLSQ_CSNE=0 switches the tier off. */
+int blsq_debug_csne_stats(blsq_ctx* ctx, uint64_t out[3], int reset);
+/* ... per problem: on_tier[b] = 1 while problem b is on the tier; eta[b] = the largest first-order correction the last
+ * step call measured for it (the quantity its acceptance bounds: <= 1e-7), -1 where the tier declined.  Either may be NULL. */
+int blsq_trf_debug_csne(blsq_trf_plan* plan, int32_t* on_tier /*B*/, double* eta /*B*/);
 /* Diagnostics of the factorisation front end: out[0] = problems factored by the
  * normal-equations fast path (Gram + equilibrated Cholesky, conditioning-gated), out[1] =
  * problems the gate handed to the Householder TSQR tree, since the last reset. */

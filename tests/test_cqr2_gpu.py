@@ -10,6 +10,12 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-10
 
 
+@pytest.fixture(autouse=True)
+def _csne_off(monkeypatch):
+    """These tests pin the CholeskyQR2 tier itself: the CSNE tier in front of it (tests/test_csne_gpu.py) is off."""
+    monkeypatch.setenv("BLSQ_CSNE", "0")
+
+
 def rel(a, b):
     return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b)
 
