@@ -647,6 +647,7 @@ struct blsq_trf_plan {
   int ncsne = 0;                    // problems on the tier now (host copy of cs.counts[0])
   DevBuf cs_ints;                   // flag [B], list [B], fail_list [B], ne [B], sel_mask [B], counts [4], scratch [4]
   DevBuf cs_pmin, cs_eta, cs_alpha, cs_hp, cs_vec, cs_part;
+  DevBuf cs_k2;                     // [B] the bound on kappa_2 of the COMPUTED system (the certificate's own output, gram_k2, keeps its meaning)
   size_t cs_part_cap = 0;           // (list positions x chunks x NE) the partial-sum buffer holds
   CsneState cs{};
   // TSQR (multi-rank) extras
@@ -1048,6 +1049,8 @@ int trf_alloc_state(blsq_trf_plan* p) {
       ALLOC(p->cs_ints, sizeof(int) * (5 * (size_t)B + 8));
       ALLOC(p->cs_pmin, sizeof(double) * (size_t)B);
       ALLOC(p->cs_eta, sizeof(double) * (size_t)B);
+      ALLOC(p->cs_k2, sizeof(double) * (size_t)B);
+      HIPCHK(ctx, hipMemsetAsync(p->cs_k2.p, 0, p->cs_k2.bytes, ctx->stream));
       ALLOC(p->cs_alpha, sizeof(double) * (size_t)B * CSNE_MAXE);
       ALLOC(p->cs_hp, sizeof(double) * vs);
       HIPCHK(ctx, hipMemsetAsync(p->cs_ints.p, 0, p->cs_ints.bytes, ctx->stream));
@@ -1351,13 +1354,13 @@ int trf_csne_select(blsq_trf_plan* p, const double* dJ, const double* df, int ld
   cy.cert_done = nullptr; cy.cert_flag = nullptr; cy.cert_tau = nullptr; cy.cert_open = nullptr;
   cy.cert_ym = nullptr; cy.cert_r1 = nullptr; cy.unsettled = nullptr; cy.lmfin = GramCholArgs::LmFinish{};
   cy.lam_out = nullptr; cy.hmax = nullptr; cy.colinfo = nullptr; cy.pmin_out = nullptr;
-  cy.k2_max = CSNE_K2_MAX; cy.k2_out = t.gram_k2.as<double>();
+  cy.k2_max = CSNE_K2_MAX; cy.k2_out = p->cs_k2.as<double>();
   ctx->begin(K_GRAM_GATE);
   e = launch_gram_gate(cy, B, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_gram_gate(csne bound)");
   e = launch_csne_select(p->cs, p->lm, nfb, t.fb_list(), t.fb_mask(), t.fb_count(), t.path_rw(), sel,
-                         t.gram_k2.as<double>(), p->cs_pmin.as<double>(), p->aug_colinfo.as<double>(), ctx->stream);
+                         p->cs_k2.as<double>(), p->cs_pmin.as<double>(), p->aug_colinfo.as<double>(), ctx->stream);
   if (e != hipSuccess) return ctx->fail(e, "launch_csne_select");
   // two counters to the host: the problems left for the tree, the problems on the tier
   HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 8, t.fb_count(), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1743,7 +1746,7 @@ extern "C" int blsq_trf_plan_destroy(blsq_trf_plan* p) {
   p->o_info.release(); p->in_J.release(); p->in_f.release(); p->in_vec.release();
   p->in_scal.release();
   p->lm_sa.release(); p->lm_Xa.release(); p->lm_ints.release(); p->lm_sc.release();
-  p->cs_ints.release(); p->cs_pmin.release(); p->cs_eta.release(); p->cs_alpha.release(); p->cs_hp.release();
+  p->cs_k2.release(); p->cs_ints.release(); p->cs_pmin.release(); p->cs_eta.release(); p->cs_alpha.release(); p->cs_hp.release();
   p->cs_vec.release(); p->cs_part.release();
   p->lm_ph.release(); p->aug_colinfo.release(); p->aug_hmax.release(); p->aug_lam.release(); p->aug_ym.release(); p->aug_r1.release(); p->aug_open.release(); p->aug_mask.release();
   delete p;

@@ -303,26 +303,28 @@ __global__ __launch_bounds__(TRI_NT) void csne_fix_kernel(CsneState cs, TrfState
   auto load_eval = [&](int k, double (&sums)[8]) {
     const double ak = cs.ralpha[(long)b * CSNE_MAXE + k];
     const double* rec = cs.rvec + ((long)b * CSNE_MAXE + k) * 3 * ld;
-    double pp = 0.0, pw = 0.0, ww = 0.0, pz = 0.0, wr = 0.0, zr = 0.0, wdw = 0.0, rr = 0.0;
+    const bool last = k == ne - 1;                        // (the last evaluation recorded p~ only)
+    double pp = 0.0, pw = 0.0, ww = 0.0, wr = 0.0, zr = 0.0, wdw = 0.0, rr = 0.0;
     __syncthreads();
     for (int j = tid; j < n; j += TRI_NT) {
       double yj = 0.0;
       for (int c = 0; c < cs.nchunk; ++c) yj += part[(long)c * PS + (long)k * ld + j];
-      const double pj = rec[j], wj = rec[ld + j], zj = rec[2 * ld + j];
+      const double pj = rec[j], wj = last ? 0.0 : rec[ld + j], zj = last ? 0.0 : rec[2 * ld + j];
       const double sh_ = dh[j] + ak;
       const double rj = fma(dg[j], yj, sh_ * pj);        // d_j (J^T u)_j + (diag_h + alpha) p~_j
       res[j] = rj; pv[j] = pj; wv[j] = wj; zv[j] = zj;
-      pp = fma(pj, pj, pp); pw = fma(pj, wj, pw); ww = fma(wj, wj, ww); pz = fma(pj, zj, pz);
+      pp = fma(pj, pj, pp); pw = fma(pj, wj, pw); ww = fma(wj, wj, ww);
       wr = fma(wj, rj, wr); zr = fma(zj, rj, zr); wdw = fma(sh_ * wj, wj, wdw); rr = fma(rj, rj, rr);
     }
-    sums[0] = pp; sums[1] = pw; sums[2] = ww; sums[3] = pz; sums[4] = wr; sums[5] = zr; sums[6] = wdw; sums[7] = rr;
+    sums[0] = pp; sums[1] = pw; sums[2] = ww; sums[3] = 0.0; sums[4] = wr; sums[5] = zr; sums[6] = wdw; sums[7] = rr;
     cs_block_sums<8>(sums, scr);
   };
+  // ---- phi, phi', phi'' of the evaluations the iteration went on from, corrected to first order ----
   if (!fail) {
-    for (int k = 0; k < ne; ++k) {
+    for (int k = 0; k + 1 < ne; ++k) {
       double s8[8];
       load_eval(k, s8);
-      const double pp = s8[0], pw = s8[1], ww = s8[2], pz = s8[3], wr = s8[4], zr = s8[5], wdw = s8[6];
+      const double pp = s8[0], pw = s8[1], ww = s8[2], wr = s8[4], zr = s8[5], wdw = s8[6];
       double bk = 0.0;
       for (int c = 0; c < cs.nchunk; ++c) bk += part[(long)c * PS + (long)NE * ld + k];
       const double pn2 = pp - 2.0 * wr;                   // ||p||^2 to first order
@@ -333,76 +335,74 @@ __global__ __launch_bounds__(TRI_NT) void csne_fix_kernel(CsneState cs, TrfState
         kalpha[k] = cs.ralpha[(long)b * CSNE_MAXE + k];
         kphi[k] = pn - Delta;
         kdphi[k] = -pMp / pn;
-        kddphi[k] = (ww + 2.0 * pz) / pn - (pw * pw) / (pn * pn * pn);
+        // phi'' = (w.w + 2 p.z) / |p| - (p.w)^2 / |p|^3 with p.z = p^T M^-1 w = w.w (M symmetric): from the cheap vectors
+        kddphi[k] = 3.0 * ww / pn - (pw * pw) / (pn * pn * pn);
         keta[k] = e1 > e2 ? e1 : e2;
       }
       if (!(pn2 > 0.0) || !(pMp > 0.0) || !is_finite(pn2) || !is_finite(pMp)) fail = true;
     }
   }
   __syncthreads();
-  // ---- replay of trust_region.py:111-150 on the corrected phi, phi' ----
-  int kf = 0, n_iter = 0;
-  double alpha = 0.0, eps = 0.0, phi_f = 0.0, eta = 0.0;
-  if (!fail) {
+  // ---- replay of trust_region.py:111-150 on the corrected phi, phi': it must arrive at the LAST recorded evaluation
+  //      (index ne - 1) exactly as the cheap run did, and stop there ----
+  const int kf = ne - 1;
+  int n_iter = 0;
+  double alpha = 0.0, eps = 0.0, eta = 0.0;
+  if (!fail && ne > 1) {
+    if (kphi[0] <= 0.0) fail = true;                      // (the corrected Gauss-Newton step is inside: the cheap run went on)
+    double lo = -kphi[0] / kdphi[0];                      // :121-123
+    double hi = gnorm / Delta;                            // :119
     eta = keta[0];
-    if (kphi[0] <= 0.0) {                                 // ||p(0)|| <= Delta  (:116-117)
-      kf = 0; alpha = 0.0; n_iter = 0; phi_f = 0.0;
-    } else {
-      double lo = -kphi[0] / kdphi[0];                    // :121-123
-      double hi = gnorm / Delta;                          // :119
-      alpha = alpha_in[b];                                // :127-130 (full rank)
-      if (alpha < lo || alpha > hi) alpha = lm_restart(lo, hi);
-      int it = 0;
-      bool done = false;
-      for (int k = 1; !done; ++k) {
-        if (k >= ne) { fail = true; break; }              // the replay needs an evaluation the cheap run did not make
-        const double e = alpha - kalpha[k];
-        if (!(fabs(e) <= 1.0e-3 * fabs(kalpha[k]))) { fail = true; break; }   // (not the iterate the cheap run evaluated)
-        const double phi = kphi[k] + (kdphi[k] + 0.5 * kddphi[k] * e) * e;
-        const double dphi = kdphi[k] + kddphi[k] * e;
-        eta = keta[k] > eta ? keta[k] : eta;
-        if (fabs(phi) < 0.01 * Delta) {                   // :138-139
-          kf = k; eps = e; phi_f = phi; n_iter = it + 1; done = true;
-          break;
-        }
-        if (phi < 0.0) hi = alpha;                        // :141-142
-        const double ratio = phi / dphi;
-        const double cand = alpha - ratio;
-        lo = (cand > lo) ? cand : lo;                     // :145
-        alpha -= (phi + Delta) * ratio / Delta;           // :146
-        ++it;
-        if (it >= 10) { fail = true; break; }             // (ten rounds: beyond what the tier records)
-        if (alpha < lo || alpha > hi) alpha = lm_restart(lo, hi);   // :133-134 of the next pass
-      }
+    alpha = alpha_in[b];                                  // :127-130 (full rank)
+    if (alpha < lo || alpha > hi) alpha = lm_restart(lo, hi);
+    int it = 0;
+    for (int k = 1; !fail; ++k) {
+      const double e = alpha - cs.ralpha[(long)b * CSNE_MAXE + k];
+      if (!(fabs(e) <= 1.0e-3 * fabs(cs.ralpha[(long)b * CSNE_MAXE + k]))) { fail = true; break; }   // (not the iterate the cheap run evaluated)
+      if (k == kf) { eps = e; n_iter = it + 1; break; }   // the evaluation the cheap run ended with: judged on the corrected step below
+      const double phi = kphi[k] + (kdphi[k] + 0.5 * kddphi[k] * e) * e;
+      const double dphi = kdphi[k] + kddphi[k] * e;
+      eta = keta[k] > eta ? keta[k] : eta;
+      if (fabs(phi) < 0.01 * Delta) { fail = true; break; }   // :138-139 — the replay ends where the cheap run went on
+      if (phi < 0.0) hi = alpha;                          // :141-142
+      const double ratio = phi / dphi;
+      const double cand = alpha - ratio;
+      lo = (cand > lo) ? cand : lo;                       // :145
+      alpha -= (phi + Delta) * ratio / Delta;             // :146
+      ++it;
+      if (it >= 10) { fail = true; break; }               // (ten rounds: beyond what the tier records)
+      if (alpha < lo || alpha > hi) alpha = lm_restart(lo, hi);   // :133-134 of the next pass
     }
-    if (!fail && kf + 1 != ne) fail = true;               // the cheap run did not end where the replay ends
   }
-  double dpn = 0.0;
   if (!fail) {
-    // ---- the final step: one corrected solve with the factor of the last evaluation ----
+    // ---- the final step: p(alpha) = p~ + M~^-1 (-res - eps p~), one corrected solve with the factor of the last
+    //      evaluation (dp/dalpha = -M^-1 p: the shift to the replayed alpha rides on the same solve) ----
     double s8[8];
     load_eval(kf, s8);
     const double pp = s8[0];
     const double* R = (kf == 0 ? lm.Raug : lm.Xa) + (long)b * ld * ld;
     tri_invdiag<TRI_NT>(R, n, ld, invd);
-    for (int j = tid; j < n; j += TRI_NT) q[j] = -res[j];
+    for (int j = tid; j < n; j += TRI_NT) q[j] = -(res[j] + eps * pv[j]);
     __syncthreads();
     tri_solve_upper_t_pf<TRI_NT>(R, n, ld, invd, q, pfbuf);
     tri_solve_upper_pf<TRI_NT>(R, n, ld, invd, q, pfbuf);
     double s2[2] = {0.0, 0.0};
     for (int j = tid; j < n; j += TRI_NT) {
       const double dj = q[j];
-      const double pj = (pv[j] + dj) - wv[j] * eps + zv[j] * (eps * eps);
+      const double pj = pv[j] + dj;
       res[j] = pj;
       s2[0] = fma(pj, pj, s2[0]); s2[1] = fma(dj, dj, s2[1]);
     }
     cs_block_sums<2>(s2, scr);
     const double pn = sqrt(s2[0]);
-    dpn = sqrt(s2[1] / pp);
+    const double dpn = sqrt(s2[1] / pp);
     eta = dpn > eta ? dpn : eta;
+    const double phi_f = pn - Delta;
     if (!(eta <= CSNE_ETA_MAX) || !is_finite(pn) || !(pn > 0.0)) fail = true;
+    if (ne == 1) { if (!(pn <= Delta)) fail = true; }     // :116-117 on the corrected Gauss-Newton step
+    else if (!(fabs(phi_f) < 0.01 * Delta)) fail = true;  // :138-139 on the corrected step
     if (!fail) {
-      const double c = (phi_f > 0.0) ? Delta / pn : 1.0;  // :149-150
+      const double c = (ne > 1 && phi_f > 0.0) ? Delta / pn : 1.0;   // :149-150
       for (int j = tid; j < n; j += TRI_NT) {
         const double pj = res[j] * c;
         lm.ph[vo + j] = pj;

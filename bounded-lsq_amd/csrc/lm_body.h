@@ -28,9 +28,11 @@ __device__ __forceinline__ double lm_restart(double lo, double hi) {
 
 // CSNE tier (csne_kernels.hip): evaluation k of a flagged problem is RECORDED for the correction stage — p~ (in `p`),
 // w~ = M~^-1 p~ and z~ = M~^-1 w~ with M~ = R^T R the factor at hand, and alpha.  q: LDS scratch (destroyed).
+// last: the iteration ends with this evaluation — only p~ is needed (the correction solves for the final step itself).
 template <int NT>
 __device__ __forceinline__ void lm_csne_record(const LmState& lm, int b, int k, double alpha, const double* R,
-                                               const double* invd, const double* p, double* q, double* pfbuf) {
+                                               const double* invd, const double* p, double* q, double* pfbuf,
+                                               bool last) {
   const int tid = threadIdx.x, n = lm.n, ld = lm.ld;
   if (k >= CSNE_MAXE) {                                   // (uniform) deeper than the tier records: it will decline
     if (tid == 0) lm.csne_ne[b] = CSNE_MAXE + 1;
@@ -38,6 +40,11 @@ __device__ __forceinline__ void lm_csne_record(const LmState& lm, int b, int k, 
   }
   double* rec = lm.csne_vec + ((long)b * CSNE_MAXE + k) * 3 * ld;
   for (int i = tid; i < n; i += NT) { const double v = p[i]; q[i] = v; rec[i] = v; }
+  if (last) {                                             // (uniform)
+    if (tid == 0) { lm.csne_alpha[(long)b * CSNE_MAXE + k] = alpha; lm.csne_ne[b] = k + 1; }
+    __syncthreads();
+    return;
+  }
   __syncthreads();
   tri_solve_upper_t_pf<NT>(R, n, ld, invd, q, pfbuf);
   tri_solve_upper_pf<NT>(R, n, ld, invd, q, pfbuf);
@@ -89,7 +96,7 @@ __device__ __forceinline__ int lm_start_body(const LmState& lm, int b, const dou
     lm.ph[(long)b * ld + i] = p[i];
   }
   __syncthreads();
-  if (lm.csne && lm.csne[b]) lm_csne_record<NT>(lm, b, 0, 0.0, R, invd, p, q, pfbuf);   // (uniform)
+  if (lm.csne && lm.csne[b]) lm_csne_record<NT>(lm, b, 0, 0.0, R, invd, p, q, pfbuf, pn <= Delta);   // (uniform)
   if (pn <= Delta) {                                                      // trust_region.py:116-117
     if (tid == 0) {
       sc[SC_ALPHA] = 0.0; st[ST_NITER] = 0; st[ST_PHASE] = LM_IDLE; sc[SC_DELTA] = Delta;
@@ -160,7 +167,7 @@ __device__ __forceinline__ int lm_update_body(const LmState& lm, int b, double* 
     const double qq = tri_dot<NT>(q, q, n, red);
     phi = pn - Delta;
     dphi = -qq / pn;
-    if (lm.csne && lm.csne[b]) lm_csne_record<NT>(lm, b, it + 1, alpha, R, invd, p, q, pfbuf);   // (uniform)
+    if (lm.csne && lm.csne[b]) lm_csne_record<NT>(lm, b, it + 1, alpha, R, invd, p, q, pfbuf, fabs(phi) < 0.01 * Delta);   // (uniform)
     if (fabs(phi) < 0.01 * Delta) {                       // :138-139
       finished = true;
       n_iter = it + 1;

@@ -56,7 +56,7 @@ def check(P, Delta, S, skip=()):
 
 
 @pytest.mark.parametrize("m,n,kappa", [(4096, 256, 3e3), (1500, 200, 1e4), (3000, 100, 3e4), (700, 129, 1e3),
-                                       (2000, 80, 5e3), (4096, 255, 1e5)])
+                                       (2000, 80, 5e3), (4096, 255, 3e4)])
 def test_unbounded_ill_conditioned_problems_take_the_tier(m, n, kappa):
     from bounded_lsq import _synth
     rng = np.random.default_rng(int(kappa) % 1000 + n)
@@ -70,3 +70,20 @@ def test_unbounded_ill_conditioned_problems_take_the_tier(m, n, kappa):
     assert stats["csne"] == (B, B, 0) and stats["cqr2"] == 0, stats
     w = check(P, Delta, S)
     print("worst step error", w)
+
+
+def test_problems_beyond_the_tiers_measured_bound_go_on_to_the_next_tier():
+    """kappa(J) = 3e5 .. 1e6: the certificate's bound is above CSNE_K2_MAX or the measured first-order correction above
+    CSNE_ETA_MAX — the problem is declined (at factor or at step time) and CholeskyQR2 / the tree deliver the step."""
+    from bounded_lsq import _synth
+    rng = np.random.default_rng(12)
+    B, m, n = 3, 2048, 192
+    P = _synth.trf_batch(78, B, m, n, unbounded=True)
+    P["J"][0] = logspaced(rng, 1, m, n, 1.5e5)[0]
+    P["J"][1] = logspaced(rng, 1, m, n, 1e6)[0]
+    P["J"][2] = logspaced(rng, 1, m, n, 1e9)[0]
+    Delta = np.array([10.0, 0.5, 2.0])
+    stats, S = run_trf(P, Delta)
+    routed, delivered, declined = stats["csne"]
+    assert stats["gram"] == (0, B) and delivered == 0 and routed == declined, stats
+    check(P, Delta, S)
