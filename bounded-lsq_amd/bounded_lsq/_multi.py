@@ -86,7 +86,10 @@ def exchange_id_tcp(rank, world, addr, port, make_id, timeout=120.0):
                 sk.sendall(struct.pack("<I", rank))
                 head = _recv_exact(sk, 4)
                 return _recv_exact(sk, struct.unpack("<I", head)[0])
-        except (ConnectionRefusedError, socket.timeout):   # server not up yet / slow: try again
+        except (ConnectionError, socket.timeout):          # server not up yet / slow, or it dropped this connection
+            # (rank 0 drops a connection on purpose when its read times out, on a duplicate and when its send
+            #  fails — "that rank will come again": refused, reset, aborted, broken pipe and the ConnectionError
+            #  of _recv_exact are all retried until the deadline)
             if time.time() > deadline:
                 raise
             time.sleep(0.05)

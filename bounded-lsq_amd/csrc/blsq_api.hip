@@ -40,16 +40,21 @@ inline bool merge_fits(int n) { return 2 * ((n + 15) / 16) <= QR_MAX_TILES; }
 
 }  // namespace
 
-// Device counters -> host without a blit: ONE lane stores [v0, v1, v2, seq] as a single 16-byte write into a
-// pinned slot the host polls for `seq`.  (A hipMemcpyAsync of 12 bytes is a blit kernel of 4 us and a signal the
+// Device counters -> host without a blit: ONE lane stores [v0, v1, v2] into a pinned (coherent) slot, fences, and
+// RELEASES the sequence number the host polls for with an acquire load (publish_ints, blsq_kernels.h).  (A hipMemcpyAsync of 12 bytes is a blit kernel of 4 us and a signal the
 // next dispatch waits 6 - 9 us behind — `tools/trace_gaps.py` — four times per step-solve call of the headline
 // batch, once in the middle of a 0.17 ms step of the 512 x 64 batches.)
 __global__ void publish_ints_kernel(const int* __restrict__ src, int n, int* dst, int seq) {
   if (threadIdx.x != 0) return;
-  int4 v;
-  v.x = n > 0 ? src[0] : 0; v.y = n > 1 ? src[1] : 0; v.z = n > 2 ? src[2] : 0; v.w = seq;
-  *reinterpret_cast<int4*>(dst) = v;
-  __threadfence_system();
+  publish_ints(PublishArgs{src, n, dst, seq});
+}
+
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield" ::: "memory");
+#endif
 }
 
 struct blsq_ctx {
@@ -111,7 +116,7 @@ struct blsq_ctx {
         if (q == hipSuccess) return __atomic_load_n(slot + 3, __ATOMIC_ACQUIRE) == expect ? hipSuccess : hipErrorUnknown;
         if (q != hipErrorNotReady) return q;
       }
-      __builtin_ia32_pause();
+      cpu_relax();
     }
   }
   int bad(int argidx, const char* what) {
@@ -756,7 +761,7 @@ extern "C" int blsq_ctx_create(int device_id, blsq_ctx** out) {
   if (e != hipSuccess) { delete c; return (int)e; }
   e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
   if (e != hipSuccess) { hipStreamDestroy(c->stream); delete c; return (int)e; }
-  e = hipHostMalloc((void**)&c->pinned, 128 * sizeof(int), hipHostMallocDefault);
+  e = hipHostMalloc((void**)&c->pinned, 128 * sizeof(int), hipHostMallocCoherent);
   if (e != hipSuccess) { hipStreamDestroy(c->stream); delete c; return (int)e; }
   memset(c->pinned, 0, 128 * sizeof(int));
   { const char* pe = getenv("BLSQ_PUBLISH"); c->pub_direct = !(pe && pe[0] == '0'); }
@@ -1722,7 +1727,7 @@ extern "C" int blsq_trf_plan_create(blsq_ctx* ctx, int B, int m, int n, blsq_trf
   if (rc == 0) {
     const char* oe = getenv("BLSQ_OPTIMISTIC");
     p->optimistic = !(oe && oe[0] == '0');
-    hipError_t e = hipHostMalloc((void**)&p->pend_pin, 4 * sizeof(int), hipHostMallocDefault);
+    hipError_t e = hipHostMalloc((void**)&p->pend_pin, 4 * sizeof(int), hipHostMallocCoherent);
     if (e == hipSuccess) memset(p->pend_pin, 0, 4 * sizeof(int));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->pend_ev, hipEventDisableTiming);
     if (e != hipSuccess) rc = ctx->fail(e, "optimistic-verdict resources");
@@ -2563,7 +2568,7 @@ extern "C" int blsq_dogbox_plan_create(blsq_ctx* ctx, int B, int m, int n,
   if (rc == 0) {
     const char* oe = getenv("BLSQ_OPTIMISTIC");
     p->optimistic = !(oe && oe[0] == '0');
-    hipError_t e = hipHostMalloc((void**)&p->pend_pin, 4 * sizeof(int), hipHostMallocDefault);
+    hipError_t e = hipHostMalloc((void**)&p->pend_pin, 4 * sizeof(int), hipHostMallocCoherent);
     if (e == hipSuccess) memset(p->pend_pin, 0, 4 * sizeof(int));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->pend_ev, hipEventDisableTiming);
     if (e != hipSuccess) rc = ctx->fail(e, "optimistic-verdict resources");

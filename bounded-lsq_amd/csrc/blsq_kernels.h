@@ -338,15 +338,18 @@ struct TrfStepOut {       // device pointers
 // for the problems that still need the stacked QR, 0 for the rest (path / sel as the QR launch would see them)
 hipError_t launch_trf_aug_trivial(const TrfState& st, const int* path, int* mask, const int* sel, hipStream_t s);
 struct LmState;
-// Counters the host is waiting for, stored by the FIRST lane of a step kernel before anything else: [src[0 .. n), seq]
-// as one 16-byte write into the pinned slot dst (blsq_ctx::publish; dst == nullptr: nothing to publish).
+// Counters the host is waiting for, stored by the FIRST lane of a step kernel before anything else: src[0 .. n) into
+// the pinned slot dst (blsq_ctx::publish; dst == nullptr: nothing to publish), a system-scope fence, then the sequence
+// number as a system-scope RELEASE store — the host's acquire load of dst[3] orders its reads of dst[0 .. 2] behind
+// it, whatever width the payload store was given and however the fabric delivers it.
 struct PublishArgs { const int* src; int n; int* dst; int seq; };
 __device__ __forceinline__ void publish_ints(const PublishArgs& pub) {
   if (!pub.dst) return;
-  int4 v;
-  v.x = pub.n > 0 ? pub.src[0] : 0; v.y = pub.n > 1 ? pub.src[1] : 0; v.z = pub.n > 2 ? pub.src[2] : 0; v.w = pub.seq;
-  *reinterpret_cast<int4*>(pub.dst) = v;
+  pub.dst[0] = pub.n > 0 ? pub.src[0] : 0;
+  pub.dst[1] = pub.n > 1 ? pub.src[1] : 0;
+  pub.dst[2] = pub.n > 2 ? pub.src[2] : 0;
   __threadfence_system();
+  __hip_atomic_store(pub.dst + 3, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 hipError_t launch_trf_step(const TrfState& st, const LmState* lm, const double* Delta,
                            const double* alpha_in, double active_rtol,

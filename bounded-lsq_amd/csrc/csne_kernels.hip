@@ -49,7 +49,10 @@ bool csne_supported(int m, int n) { return n + 1 > 80 && n <= 256 && m >= n; }
 
 static constexpr int CS_NT = 256;
 static constexpr int CS_NW = CS_NT / WAVE;
-static constexpr int CS_RB = 4;          // rows per wave and batch
+#ifndef BLSQ_CS_RB
+#define BLSQ_CS_RB 4
+#endif
+static constexpr int CS_RB = BLSQ_CS_RB; // rows per wave and batch
 
 __host__ __device__ inline long csne_part_stride(int NE, int ld) { return (long)NE * ld + 16; }
 __device__ __forceinline__ constexpr int cs_bitrev4(int i) {

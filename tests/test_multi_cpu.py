@@ -216,3 +216,40 @@ def test_stand_in_collectives_world3_host_mode(tmp_path):
 
 def test_stand_in_refuses_mismatched_collectives(tmp_path):
     _run_stub_world(tmp_path, 2, "mismatch")
+
+
+def test_id_client_retries_when_the_server_drops_its_connection():
+    """Rank 0 drops a connection on purpose (read time-out, duplicate, failed send) and expects the rank to come
+    again: the client must survive a closed / reset connection and fetch the id on a later attempt."""
+    import socket
+    import struct
+    import threading
+    from bounded_lsq._multi import exchange_id_tcp
+    payload = bytes(range(128))
+    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    srv.bind(("127.0.0.1", 0))
+    port = srv.getsockname()[1]
+    srv.listen(4)
+    seen = []
+
+    def serve():
+        # first connection: read the rank, then close without an answer; second: close at once (reset while the
+        # client sends); third: the id
+        for attempt in range(3):
+            conn, _ = srv.accept()
+            with conn:
+                if attempt == 0:
+                    conn.recv(4)
+                elif attempt == 1:
+                    conn.setsockopt(socket.SOL_SOCKET, socket.SO_LINGER, struct.pack("ii", 1, 0))
+                else:
+                    who = struct.unpack("<I", conn.recv(4))[0]
+                    seen.append(who)
+                    conn.sendall(struct.pack("<I", len(payload)) + payload)
+        srv.close()
+    th = threading.Thread(target=serve, daemon=True)
+    th.start()
+    got = exchange_id_tcp(1, 2, "127.0.0.1", port, lambda: b"", timeout=20.0)
+    th.join(5.0)
+    assert got == payload and seen == [1]

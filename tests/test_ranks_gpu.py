@@ -83,10 +83,21 @@ def _run(tmp_path, case, world=2, env_rank=None, timeout=600):
                                        str(tmp_path)], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     recs = []
-    for r, p in enumerate(procs):
-        out, _ = p.communicate(timeout=timeout)
-        assert p.returncode == 0, "rank %d:\n%s" % (r, out[-3000:])
-        recs.append(json.load(open(tmp_path / ("rec%d.json" % r))))
+    try:
+        for r, p in enumerate(procs):
+            out, _ = p.communicate(timeout=timeout)
+            assert p.returncode == 0, "rank %d:\n%s" % (r, out[-3000:])
+            recs.append(json.load(open(tmp_path / ("rec%d.json" % r))))
+    finally:
+        # a failed or timed-out rank must not leave the others sitting in the stand-in collective's socket
+        # time-outs with their row blocks on the GPU: every child still running is killed (its own PID) and reaped
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+            try:
+                p.communicate(timeout=30)
+            except Exception:                                  # noqa: BLE001
+                pass
     return recs
 
 
