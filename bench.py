@@ -18,6 +18,13 @@ inner step) for every problem of the per-GPU batch, inputs resident in HBM.
     c4         TRF, 512 x 64, 1024 problems per GPU  (configs[3]: 8192 over 8 GPUs)
     c5         TRF, one tall problem, 250 000 x 128 rows PER RANK (configs[4]: 2 000 000 x 128 over
                8 GPUs), blsq_tsqr_factor_dev: local Gram + ncclAllReduce over RCCL
+`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset) starts the N ranks itself — as a
+child `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` before this process
+has touched the GPU — and relays rank 0's line and a non-zero exit code of any rank.
+`roofline` prices a dominant MFMA / streaming kernel (gram, qr_leaf, csne_pass) with the work of its own algorithm; where
+the dominant slot is a latency-bound n-space kernel (the 512 x 64 shapes, one problem) it carries the WHOLE STEP's
+fractions instead (`scope: whole_step`): algorithmic bytes / ms_per_step against HBM, the Gram's flops / ms_per_step
+against the FP64 MFMA peak — figures the committed kernel stats reproduce.
 Every config prints the same JSON shape with its own SURVEY 8(d) bytes / flops.  The default (c2)
 line also carries, at N = 1: `side_configs` (the other configs' rates, same process, short runs),
 `householder_only` (the same workload with the normal-equations front end off), `h2d_inclusive`
@@ -27,6 +34,7 @@ line also carries, at N = 1: `side_configs` (the other configs' rates, same proc
 import argparse
 import json
 import os
+import subprocess
 import sys
 import threading
 import time
@@ -289,7 +297,7 @@ class Bench:
     """Device-resident inputs + the step closure of one config on one ctx."""
 
     def __init__(self, name, ctx, rank, world, batch=None, m=None, n=None, comm_ready=False,
-                 mutate=None):
+                 mutate=None, alt_mutate=None):
         from bounded_lsq import TrfStepSolver, DogboxStepSolver, _synth
         cfg = dict(CONFIGS[name])
         if batch:
@@ -327,9 +335,20 @@ class Bench:
         self.d = {k: ctx.to_device(self.P[k]) for k in keys}
         self.dDelta = ctx.to_device(self.Delta)
         self.dAlpha = ctx.to_device(np.zeros(B))
+        # a SECOND input set on the same plan (TRF only): step() then alternates between the two, so what the
+        # optimistic device API guessed from the last call ("every problem on the fast path") fails every other call
+        self.d2 = None
+        self.calls = 0
+        if alt_mutate is not None and kind == "trf":
+            self.P2 = _synth.trf_batch(30_000 + rank * B, B, m, n)
+            alt_mutate(self.P2)
+            self.d2 = {k: ctx.to_device(self.P2[k]) for k in keys}
 
     def step(self):
         d, s = self.d, self.sol
+        if self.d2 is not None:
+            d = self.d2 if (self.calls & 1) else self.d
+            self.calls += 1
         if self.kind == "dogbox":
             s.factor_dev(d["J"], d["f"], d["x"], d["lb"], d["ub"], d["scale"], d["on_bound"])
             s.step_dev(self.dDelta)
@@ -348,7 +367,7 @@ class Bench:
 
     def close(self):
         self.sol.close()
-        for p in list(self.d.values()) + [self.dDelta, self.dAlpha]:
+        for p in list(self.d.values()) + list((self.d2 or {}).values()) + [self.dDelta, self.dAlpha]:
             self.ctx.free(p)
 
     # ---- parity spot check against the oracle (rank 0) ----
@@ -440,39 +459,59 @@ def record(bench, cfg_name, elapsed, steps, warmup, world, probe):
     # kernel m N (N + 1) flops over 8 m N bytes, the Householder leaf 2 r N^2 - 2/3 N^3.  SURVEY
     # 8(d)'s per-solve figure (an SVD-based count of the whole step-solve) is larger than what
     # either kernel executes and is reported beside it, never as `achieved`.
-    if dom == "gram":
-        own_f, own_b = gram_flops(m, n), gram_bytes(m, n)
-    elif dom == "qr_leaf":
-        own_f, own_b = leaf_flops(m, n), 8.0 * m * (n + 1)
-    else:
-        own_f, own_b = float(alg_flops(akind, m, n)), float(alg_bytes(akind, m, n))
-    balance = PEAK_FP64_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
-    bound = "mfma" if own_f / own_b > balance else "hbm"
-    ach_tf = own_f * B / (dom_ms * 1e-3) / 1e12
-    ach_gbs = own_b * B / (dom_ms * 1e-3) / 1e9
+    nprob = 1 if kind == "tsqr" else B                           # problems per launch on this GPU
+    ws_gbs = alg_bytes(akind, m, n) * nprob / (ms_per_step * 1e-3) / 1e9          # whole step: SURVEY 8(d) bytes
+    ws_tf = gram_flops(m, n) * nprob / (ms_per_step * 1e-3) / 1e12                # ... and the Gram's own flops
     traffic, tsrc = measured_traffic(cfg_name, dom, m, n, B)
-    roof = {
-        "bound": bound,
-        "achieved": ach_tf if bound == "mfma" else ach_gbs,
-        "peak": PEAK_FP64_TFLOPS if bound == "mfma" else PEAK_HBM_GBS,
-        "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-        "frac": (ach_tf / PEAK_FP64_TFLOPS) if bound == "mfma" else (ach_gbs / PEAK_HBM_GBS),
+    common = {
         "traffic": traffic, "traffic_source": tsrc,
         "peak_source": "nominal (AMD spec: FP64 matrix = vector 78.6 TFLOP/s; HBM3E 8 TB/s)",
         "kernel": dom, "kernel_ms_per_step": per_step_ms[dom],
-        "kernel_flops_per_solve": own_f, "kernel_bytes_per_solve": own_b,
-        "kernel_tflops": ach_tf, "kernel_hbm_gbs": ach_gbs,
         "survey_flops_per_solve": alg_flops(akind, m, n),
         "survey_bytes_per_solve": alg_bytes(akind, m, n),
-        "whole_step_hbm_gbs": alg_bytes(akind, m, n) * B / (ms_per_step * 1e-3) / 1e9,
-        "whole_step_hbm_frac_of_8TBs": alg_bytes(akind, m, n) * B / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS,
+        "whole_step_hbm_gbs": ws_gbs, "whole_step_hbm_frac_of_8TBs": ws_gbs / PEAK_HBM_GBS,
+        "whole_step_mfma_tflops_gram_flops": ws_tf, "whole_step_mfma_frac_gram_flops": ws_tf / PEAK_FP64_TFLOPS,
     }
-    if probe:
-        roof["peak_measured"] = probe
-        if bound == "mfma" and probe.get("mfma_f64_tflops"):
-            roof["frac_of_measured_peak"] = ach_tf / probe["mfma_f64_tflops"]
-        if bound == "hbm" and probe.get("hbm_copy_gbs"):
-            roof["frac_of_measured_peak"] = ach_gbs / probe["hbm_copy_gbs"]
+    own = {"gram": (gram_flops(m, n), gram_bytes(m, n)),
+           "qr_leaf": (leaf_flops(m, n), 8.0 * m * (n + 1)),
+           # the CSNE pass streams J once: 8 m n bytes, 2 m n flops per recorded vector (not priced: memory-bound)
+           "csne_pass": (4.0 * m * n, 8.0 * m * (n + 1))}.get(dom)
+    if own is not None:
+        own_f, own_b = own
+        balance = PEAK_FP64_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+        bound = "mfma" if own_f / own_b > balance else "hbm"
+        ach_tf = own_f * nprob / (dom_ms * 1e-3) / 1e12
+        ach_gbs = own_b * nprob / (dom_ms * 1e-3) / 1e9
+        roof = dict(common, **{
+            "scope": "kernel", "bound": bound,
+            "achieved": ach_tf if bound == "mfma" else ach_gbs,
+            "peak": PEAK_FP64_TFLOPS if bound == "mfma" else PEAK_HBM_GBS,
+            "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+            "frac": (ach_tf / PEAK_FP64_TFLOPS) if bound == "mfma" else (ach_gbs / PEAK_HBM_GBS),
+            "kernel_flops_per_solve": own_f, "kernel_bytes_per_solve": own_b,
+            "kernel_tflops": ach_tf, "kernel_hbm_gbs": ach_gbs})
+        if probe:
+            roof["peak_measured"] = probe
+            if bound == "mfma" and probe.get("mfma_f64_tflops"):
+                roof["frac_of_measured_peak"] = ach_tf / probe["mfma_f64_tflops"]
+            if bound == "hbm" and probe.get("hbm_copy_gbs"):
+                roof["frac_of_measured_peak"] = ach_gbs / probe["hbm_copy_gbs"]
+    else:
+        # The dominant slot is a latency-bound n-space kernel (one wave or workgroup per problem): no roofline of
+        # its own is claimed.  The line carries the WHOLE STEP against both rooflines — algorithmic bytes and the
+        # Gram's own flops over ms_per_step — and reports the one it is closer to; the kernel is named, not priced.
+        hb, mf = ws_gbs / PEAK_HBM_GBS, ws_tf / PEAK_FP64_TFLOPS
+        bound = "hbm" if hb >= mf else "mfma"
+        roof = dict(common, **{
+            "scope": "whole_step", "bound": bound,
+            "achieved": ws_gbs if bound == "hbm" else ws_tf,
+            "peak": PEAK_HBM_GBS if bound == "hbm" else PEAK_FP64_TFLOPS,
+            "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+            "frac": hb if bound == "hbm" else mf,
+            "note": "dominant slot `%s` is latency-bound (one problem's dependent chain): whole-step fractions, "
+                    "SURVEY 8(d) bytes x problems / ms_per_step and Gram flops x problems / ms_per_step" % dom})
+        if probe:
+            roof["peak_measured"] = probe
     gs = ctx.gram_stats()
     metric = ("dogbox" if kind == "dogbox" else "TRF") + " step-solves/sec (batched m x n dense Jacobian)"
     return {
@@ -482,7 +521,9 @@ def record(bench, cfg_name, elapsed, steps, warmup, world, probe):
         "config": {"workload": "%s, %d problem%s per GPU, %s, inputs resident in HBM" % (
                        CONFIGS[cfg_name]["label"] if (m, n) == (CONFIGS[cfg_name]["m"], CONFIGS[cfg_name]["n"])
                        else "%s step-solve, m=%d n=%d" % (akind, m, n), B, "" if B == 1 else "s",
-                       "Delta = 0.02" if kind == "dogbox" else "Delta mix 10/0.5 (reflective/feasible)"),
+                       ("Delta = 0.02" if kind == "dogbox" else "Delta mix 10/0.5 (reflective/feasible)")
+                       + ("; two input sets alternate between calls" if bench.d2 is not None else
+                          "; the same inputs every step (best case of the optimistic device API: its guess always holds)")),
                    "name": cfg_name, "m": m, "n": n, "batch_per_gpu": B,
                    "sharding": ("by rows: %d rows per rank, one ncclAllReduce of the Gram per factor call"
                                 % m) if kind == "tsqr" else "by problem, no collective"},
@@ -507,8 +548,9 @@ def side_run(name, ctx, steps, warmup, probe, **kw):
     rf = r["roofline"]
     return {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"],
             "ms_per_step": r["ms_per_step"], "steps": steps,
-            "roofline": {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel",
-                                            "kernel_ms_per_step", "whole_step_hbm_frac_of_8TBs")},
+            "roofline": {k: rf[k] for k in ("scope", "bound", "achieved", "peak", "unit", "frac", "kernel",
+                                            "kernel_ms_per_step", "whole_step_hbm_frac_of_8TBs",
+                                            "whole_step_mfma_frac_gram_flops")},
             "mfma_ceiling_frac_survey": r["value"] * rf["survey_flops_per_solve"] / (PEAK_FP64_TFLOPS * 1e12),
             "kernels_ms_per_step": {k: round(v, 4) for k, v in r["kernels_ms_per_step"].items() if v > 0},
             "parity": par}
@@ -549,10 +591,31 @@ def main():
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-pointer (PCIe-inclusive) leg")
     ap.add_argument("--no-probe", action="store_true", help="skip the measured-peak probes")
     ap.add_argument("--check", type=int, default=2, help="problems checked against the oracle")
-    ap.add_argument("--min-time", type=float, default=1.0,
-                    help="shortest timed region in seconds: a shorter --steps region is repeated as one region of "
-                         "r x steps steps (reported as `steps`, with `steps_requested`); 0: exactly --steps")
+    ap.add_argument("--min-time", type=float, default=None,
+                    help="shortest timed region in seconds (default: 5 for the headline config, 1 otherwise): a shorter "
+                         "--steps region is repeated as one region of r x steps steps (reported as `steps`, with "
+                         "`steps_requested`); 0: exactly --steps")
+    ap.add_argument("--cpu-child", type=int, default=None, help=argparse.SUPPRESS)   # (internal: the CPU leg's process)
     args = ap.parse_args()
+    if args.cpu_child is not None:
+        # the CPU leg, in a process of its own that never touches the GPU (its pools fork freely)
+        from bounded_lsq import _synth
+        Bc = max(1, args.cpu_child)
+        Pc = _synth.trf_batch(10_000, min(Bc, 64), 4096, 256)       # a sample of the same seeded batch
+        print(json.dumps(cpu_baseline(Pc, make_deltas("trf", min(Bc, 64)))), flush=True)
+        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # No launcher around us: start the N ranks ourselves, as a CHILD (this process has not touched the GPU and
+        # never will), relay rank 0's line and the launcher's exit code (non-zero if any rank failed).
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.run(cmd, env=env).returncode)
     name = args.config
     default_steps = {"c2": 250, "c2-single": 500, "c3": 400, "c4": 300, "c5": 400}[name]
     steps = args.steps if args.steps is not None else default_steps
@@ -562,14 +625,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     main_line = name == "c2" and not (args.m or args.n)
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu and main_line:
-        from bounded_lsq import _synth
-        Bc = args.batch or CONFIGS["c2"]["batch"]
-        Pc = _synth.trf_batch(10_000, min(Bc, 64), 4096, 256)      # a sample of the same seeded batch
-        cpu = cpu_baseline(Pc, make_deltas("trf", min(Bc, 64)))    # before any GPU initialisation (fork)
-        del Pc
+    if args.min_time is None:
+        args.min_time = 5.0 if main_line else 1.0
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d rank(s): reporting n_gpus = %d"
+              % (args.gpus, world, world), file=sys.stderr)
+    cpu = None                                               # (the CPU leg runs LAST, in a child: see below)
 
     dist = None
     backend = os.environ.get("BLSQ_DIST_BACKEND", "nccl")     # "gloo": rehearsal on one GPU
@@ -641,9 +702,18 @@ def main():
             probe = {"error": str(exc)[:200]}
 
     comm_ready = False
-    if name == "c5" and world > 1:
-        ctx.comm_init(world, rank, bcast_comm_id())
-        comm_ready = True
+    comm_error = None
+    if world > 1:
+        # every N > 1 run brings up the library's own RCCL communicator (the tall problem needs it; the batch configs
+        # do not — no data-path collective — but the line then shows which librccl the ranks resolved and that it
+        # spans them all)
+        try:
+            ctx.comm_init(world, rank, bcast_comm_id())
+            comm_ready = True
+        except Exception as exc:                               # noqa: BLE001
+            if name == "c5":
+                raise
+            comm_error = "%s: %s" % (type(exc).__name__, str(exc)[:200])
     bench = Bench(name, ctx, rank, world, batch=args.batch, m=args.m, n=args.n, comm_ready=comm_ready)
     steps_requested = steps
     own_elapsed, steps = time_steps(bench, steps, warmup, fence, args.min_time, max_over_ranks)
@@ -657,6 +727,8 @@ def main():
                            "note": "each rank's own clock over the same fenced region; `value` uses the max"}
         if bench.kind == "tsqr" or comm_ready:
             out["rccl"] = ctx.comm_info()
+        elif comm_error:
+            out["rccl"] = {"error": comm_error}
     parity = bench.parity(args.check) if (rank == 0 and args.check > 0) else None
 
     extras = {}
@@ -683,6 +755,21 @@ def main():
             for key, mut in (("mixed_conditioning", mut_mixed), ("mixed_conditioning_unbounded", mut_mixed_unbounded),
                              ("certificate_rejected", mut_all_rejected)):
                 extras[key] = conditioning_leg(key, mut, ctx, name, args.batch, steps_requested, args.check)
+            # The headline's inputs repeat: what the optimistic device API guesses from the last call always holds.
+            # Here two input sets ALTERNATE on one plan — the headline batch and the unbounded mixed-conditioning one —
+            # so the guess "every problem on the fast path" fails every other call (repair + the step once more).
+            ba = Bench(name, ctx, 0, 1, batch=args.batch, alt_mutate=mut_mixed_unbounded)
+            try:
+                ka = 2 * max(2, min(steps_requested, 20) // 2)
+                ea, ka = time_steps(ba, ka, 2, ctx.sync)
+                extras["alternating_conditioning"] = {
+                    "value": B * ka / ea, "unit": "step-solves/s", "ms_per_step": 1e3 * ea / ka, "steps": ka,
+                    "kernels_ms_per_step": {k: round(v, 4) for k, v in profile_table(ba).items() if v > 0},
+                    "note": "even calls: the headline batch; odd calls: kappa(J) log-uniform over [1, 1e4], no bounds "
+                            "(its rejected problems on the CSNE tier) — same plan, the optimistic verdict of the device "
+                            "API wrong at every second call; the mean of the two batches' costs plus the repairs"}
+            finally:
+                ba.close()
         if not args.no_h2d:
             # numpy in, numpy out through blsq_trf_factor / blsq_trf_step: the 8 MiB Jacobian of every
             # problem crosses PCIe inside the call ("including and excluding H2D of J")
@@ -765,15 +852,12 @@ def main():
                     side_hung = True
                     break
             extras["side_configs"] = side
-        # (last: its numpy callbacks wake the BLAS thread pool, whose workers then spin for tens of milliseconds on
-        #  the box's CPU share — measured: a latency-bound side leg that follows at once, c2-single, ran at HALF speed)
-        if not args.no_h2d and not side_hung:
-            front_end_leg()
     if world > 1 and main_line and not args.no_side:
         # the tall problem of config 5 over ALL ranks (250 000 rows each): the library's own RCCL
         # communicator, Gram all-reduce inside blsq_tsqr_factor_dev.  A side figure: guarded, timed out.
         def c5_leg():
-            ctx.comm_init(world, rank, bcast_comm_id())
+            if not comm_ready:
+                ctx.comm_init(world, rank, bcast_comm_id())
             b5 = Bench("c5", ctx, rank, world, comm_ready=True)
             try:
                 k5 = 100
@@ -809,6 +893,26 @@ def main():
             # this ctx (a helper thread may still sit in the stuck collective), no teardown, no re-exec.
             os._exit(3)
 
+    if rank == 0 and world == 1 and not args.no_cpu and main_line and not side_hung:
+        # The CPU leg LAST, after every GPU leg (so that the GPU work of this run is contiguous), and in a child
+        # process of its own: this one has initialised the GPU and must not fork worker pools.
+        try:
+            Bc = args.batch or CONFIGS["c2"]["batch"]
+            cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", str(Bc)],
+                                capture_output=True, text=True, timeout=600)
+            cpu = json.loads(cp.stdout.strip().splitlines()[-1]) if cp.returncode == 0 else \
+                {"error": (cp.stderr or cp.stdout)[-300:]}
+            if cpu is not None and "value" not in cpu:
+                extras["cpu_baseline_error"] = cpu
+                cpu = None
+        except Exception as exc:                               # noqa: BLE001
+            extras["cpu_baseline_error"] = str(exc)[:300]
+            cpu = None
+    if world == 1 and main_line and not args.no_h2d and not side_hung:
+        # (the very last leg: its numpy callbacks wake the BLAS thread pool, whose workers then spin for tens of
+        #  milliseconds on the box's CPU share — measured: a latency-bound side leg that followed at once ran at HALF
+        #  speed, and the CPU leg's sixteen workers lost a fifth of theirs)
+        front_end_leg()
     if rank == 0:
         out.update(extras)
         out["cpu_baseline"] = cpu
@@ -819,11 +923,13 @@ def main():
         digest = {}
         for k, v in (extras.get("side_configs") or {}).items():
             if isinstance(v, dict) and "value" in v:
+                # (third entry: the roofline fraction — of the dominant MFMA / streaming kernel, or of the whole step
+                #  where the dominant slot is latency-bound: `roofline.scope` says which)
                 digest[k] = [round(v["value"], 1), round(v["ms_per_step"], 4), round(v["roofline"]["frac"], 3)]
             else:
                 digest[k] = v
         for k in ("householder_only", "certificate_rejected", "mixed_conditioning", "mixed_conditioning_unbounded",
-                  "h2d_inclusive"):
+                  "alternating_conditioning", "h2d_inclusive"):
             if k in extras:
                 digest[k] = [round(extras[k]["value"], 1), round(extras[k]["ms_per_step"], 4), None]
         if "c5_tsqr" in extras and isinstance(extras["c5_tsqr"], dict) and "value" in extras["c5_tsqr"]:
