@@ -156,9 +156,43 @@ def test_fuzz_sweep_of_ill_conditioned_problems():
         print("fuzz (ill-conditioned): %d problems, paths (Gram, tree) %s, %d beyond 1e-10 and excused by the "
               "oracle's own sensitivity, worst accepted error %.2e"
               % (len(recs), paths, excused, max([r[0] for r in recs if not r[7]] + [0.0])))
-        assert excused <= 0.5 * len(recs), (excused, len(recs))
+        for r in recs:
+            if r[7]:                                        # every excused case, by name
+                print("  excused: err %.2e  %s B=%d %dx%d  paths %s" % (r[0], r[1], r[2], r[3], r[4], r[6]))
+        assert excused <= 0.05 * len(recs), (excused, len(recs))
     finally:
         ctx.close()
+
+
+def test_known_hard_dogbox_case_1548x61():
+    """The one case of five long sweeps (tools/fuzz_long.py, ~1480 problems; profiles/r03x_fuzz_long.txt) that came out
+    beyond the bar without an excuse: dogbox, 1548 x 61, prescribed kappa(J) = 1e5.2 times column scalings 10^+-3 —
+    cond(J) = 1.1e10 — on the Householder tree (the certificate rejects it on a pivot).  Pinned by name, with the figure
+    that explains it: the ORACLE's own step moves by ~4e-11 .. 1e-10 when every entry of J moves by one ulp (twelve
+    random sign patterns here, three in the sweep), i.e. the reference's arithmetic does not define this step to 1e-10.
+    Asserted: masks bit-exact; error below 2e-10 and within 5x the oracle's own movement."""
+    import bounded_lsq as bl
+    from bounded_lsq import _abi
+    rng = np.random.default_rng(12)                         # the sweep's generator: case 7 of seed 12, log10 kappa in (2, 6)
+    for _ in range(8):
+        kind, P, Delta = draw_case(rng, log_kappa=(2.0, 6.0))
+    B, m, n = P["J"].shape
+    assert (kind, B, m, n) == ("dogbox", 2, 1548, 61)
+    cond = float(np.linalg.cond(P["J"][0]))
+    assert 5e9 < cond < 2e10, cond
+    ctx = _abi.Context(0)
+    sol = bl.DogboxStepSolver(B, m, n, ctx=ctx)
+    sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"], P["on_bound"])
+    S = sol.step(Delta)
+    sol.close(); ctx.close()
+    So, mask = oracle_step(kind, P, 0, float(Delta[0]))
+    e = np.linalg.norm(S.step[0] - So.step) / np.linalg.norm(So.step)
+    move, mask_stable = oracle_sensitivity(kind, P, 0, float(Delta[0]), So, mask, np.random.default_rng(13), trials=12)
+    print("dogbox 1548 x 61, cond(J) = %.2e: step error %.3e; the oracle moves by %.3e under one-ulp changes of J"
+          % (cond, e, move))
+    assert np.array_equal(S.on_bound_new[0], mask) and mask_stable
+    assert e < 2e-10 and e <= 5.0 * move, (e, move)
+    assert move > 2e-11, move                               # (the explanation itself: if this fails the case needs a new one)
 
 
 if __name__ == "__main__":

@@ -158,3 +158,57 @@ def test_tall_problems_at_the_edge_of_the_gate():
     print("tall problems near the gate on the fast path: %d, largest c = error / (eps kappa_2) = %.3f" % (near, cmax))
     assert near >= 3, near
     assert cmax < 0.2, cmax
+
+
+def test_two_million_rows_at_the_edge_of_the_tightened_gate():
+    """BASELINE config 5 as written — ONE 2 000 000 x 128 problem — where the gate is tightest: the Gram accumulates
+    2 000 000 products per entry (1954 row chunks of 1024), gram_k2_max(m) = 1.5e5 instead of 2.5e5.  Equicorrelated
+    columns with the TRUE kappa_2 of the equilibrated J^T J at 0.24 and 0.7 of that gate (unbounded: the system solved
+    is J^T J itself): the first must be on the fast path (the certificate is sharp to within its factor four), and
+    whatever path either takes, the step is within 1e-10 of the oracle (gesdd on the whole matrix, trf.py:272);
+    c = error / (eps kappa_2) of a fast-path problem must stay below the calibrated 0.2."""
+    import bounded_lsq as bl
+    from bounded_lsq import _abi
+    from oracle import blsq_oracle as orc
+    m, n = 2_000_000, 128
+    kmax = _k2_max_of(m)
+    assert 1.4e5 < kmax < 1.6e5, kmax
+    rng = np.random.default_rng(2026)
+    eps = np.finfo(float).eps
+    ctx = _abi.Context(0)
+    sol = bl.TrfStepSolver(1, m, n, ctx=ctx)
+    x = rng.uniform(-1.0, 1.0, n)
+    lb = np.full(n, -np.inf); ub = np.full(n, np.inf)
+    cmax = 0.0
+    for frac in (0.24, 0.7):
+        rho = 1.0 - n / (frac * kmax)
+        J = np.sqrt(1 - rho) * rng.standard_normal((m, n))
+        J += np.sqrt(rho) * rng.standard_normal((m, 1))
+        f = rng.standard_normal(m)
+        G = J.T @ J
+        dsc = 1.0 / np.sqrt(np.diag(G))
+        ev = np.linalg.eigvalsh(G * dsc[:, None] * dsc[None, :])
+        true_k2 = ev[-1] / ev[0]                                 # (to ~1e-10 relative: eps kappa_2)
+        ctx.gram_stats(reset=True)
+        sol.factor(J[None], f[None], x[None], lb[None], ub[None], np.ones((1, n)))
+        fast = ctx.gram_stats() == (1, 0)
+        k2 = float(sol.debug_cond()[0])
+        assert k2 == 0 or not np.isfinite(k2) or k2 >= true_k2 * (1 - 1e-6), (frac, k2, true_k2)
+        if true_k2 <= kmax / 4:
+            assert fast, (frac, true_k2, k2)
+        F = orc.trf_factor(J, f, x, lb, ub, np.ones(n))          # (the host's LAPACK on 2 000 128 x 128: ~20 s)
+        pg = np.linalg.norm(orc.trf_step(F, 1e300, 0.0).step)
+        for Delta in (0.5 * pg, 1e300):
+            So = orc.trf_step(F, Delta, 0.0)
+            S = sol.step(np.array([Delta]), np.array([0.0]))
+            e = rel(S.step[0], So.step)
+            assert e < RTOL, (frac, true_k2, fast, Delta, e)
+            assert int(S.n_iter[0]) == So.n_iter
+            if fast:
+                cmax = max(cmax, e / (eps * true_k2))
+        print("2e6 rows: true kappa_2 %.3e = %.2f of the gate %.3e, K2 %.3e, %s, step error %.2e"
+              % (true_k2, true_k2 / kmax, kmax, k2, "fast path" if fast else "rejected", e))
+        del J, F
+    sol.close(); ctx.close()
+    print("2e6 rows: largest c = error / (eps kappa_2) on the fast path = %.3f" % cmax)
+    assert cmax < 0.2, cmax
