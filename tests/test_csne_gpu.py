@@ -87,3 +87,116 @@ def test_problems_beyond_the_tiers_measured_bound_go_on_to_the_next_tier():
     routed, delivered, declined = stats["csne"]
     assert stats["gram"] == (0, B) and delivered == 0 and routed == declined, stats
     check(P, Delta, S)
+
+
+def test_bounded_problems_on_the_tier_take_the_reflective_branch():
+    """Rejected problems WITH bounds (upper bounds only, so that the Coleman-Li block leaves the variables with g > 0
+    unregularised): a large radius sends x + p out of the box — find_reflected_step / find_gradient_step
+    (trf.py:105-170) and the model comparison run on the corrected p, every product with p taken from the normal
+    equations (H p = -(c g_h + alpha p)) instead of the factor.  hits, branch, choice and the step as the oracle's."""
+    import bounded_lsq as bl
+    from bounded_lsq import _abi, _synth
+    from oracle import blsq_oracle as orc
+    rng = np.random.default_rng(31)
+    B, m, n = 12, 1536, 144
+    P = _synth.trf_batch(91, B, m, n)
+    P["J"] = logspaced(rng, B, m, n, 2e4)
+    P["lb"][:] = -np.inf
+    P["ub"] = P["x"] + rng.uniform(0.5, 3.0, (B, n))
+    Delta = np.where(np.arange(B) % 3 == 0, 300.0, np.where(np.arange(B) % 3 == 1, 30.0, 3.0))
+    ctx = _abi.Context(0)
+    sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
+    ctx.csne_stats(reset=True)
+    sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+    S = sol.step(Delta, np.zeros(B))
+    on, eta = sol.debug_csne()
+    D = sol.fetch_step()
+    sol.close(); ctx.close()
+    refl = 0
+    for b in range(B):
+        _, So = orc.trf_step_solve(P["J"][b], P["f"][b], P["x"][b], P["lb"][b], P["ub"][b], P["scale"][b],
+                                   Delta[b], 0.0)
+        assert rel(S.step[b], So.step) < RTOL, (b, on[b], rel(S.step[b], So.step))
+        np.testing.assert_array_equal(S.hits[b], So.hits)
+        assert int(S.n_iter[b]) == So.n_iter and int(S.branch[b]) == So.branch
+        assert int(D.choice[b]) == So.choice
+        assert abs(S.predicted_reduction[b] - So.predicted_reduction) <= 1e-9 * abs(So.predicted_reduction), b
+        refl += int(on[b] == 1 and So.branch == 1)
+    print("bounded: on the tier", int(on.sum()), "of", B, "- reflective among them", refl, "- largest eta", eta.max())
+    assert on.sum() >= B // 2 and refl >= 3, (on, refl)
+
+
+@pytest.mark.parametrize("noise", [1e-9, 1e-3, 1.0])
+def test_small_and_large_residual_problems(noise):
+    """f = -J x* + noise: from a nearly consistent system (||J p + f|| << ||f||: the pass forms J^T (J p + f) with f
+    INSIDE the product, so the small residual is not lost against g = J^T f) to the large-residual one."""
+    from bounded_lsq import _synth
+    rng = np.random.default_rng(5)
+    B, m, n = 4, 2048, 128
+    P = _synth.trf_batch(63, B, m, n, unbounded=True)
+    P["J"] = logspaced(rng, B, m, n, 1e4)
+    xs = rng.standard_normal((B, n))
+    P["f"] = -np.einsum("bmn,bn->bm", P["J"], xs) + noise * rng.standard_normal((B, m))
+    pg = [np.linalg.norm(np.linalg.lstsq(P["J"][b], -P["f"][b], rcond=None)[0]) for b in range(B)]
+    Delta = np.array([2.0 * pg[0], 0.7 * pg[1], 0.1 * pg[2], 1e-3 * pg[3]])
+    stats, S = run_trf(P, Delta)
+    assert stats["csne"][0] == B and stats["csne"][2] == 0, stats
+    check(P, Delta, S)
+
+
+def test_a_problems_bits_do_not_depend_on_its_batch():
+    """The tier is chosen per problem by the problem's own numbers, the pass sums a problem's rows in chunks that are a
+    function of m alone and the depth of the recording (the NE of the pass kernel) only adds zero vectors: a problem
+    alone, in another order, or beside well-conditioned and deeper-iterating neighbours gives the same bits."""
+    from bounded_lsq import _synth
+    rng = np.random.default_rng(9)
+    B, m, n = 8, 2048, 160
+    P = _synth.trf_batch(5, B, m, n)
+    for b, kap in ((1, 2e3), (2, 3e4), (5, 8e3), (6, 1e6)):
+        P["J"][b] = logspaced(rng, 1, m, n, kap)[0]
+        P["lb"][b] = -np.inf; P["ub"][b] = np.inf
+    Delta = np.array([10.0, 0.5, 0.05, 2.0, 1.0, 1e4, 0.3, 0.7])
+    stats, S = run_trf(P, Delta)
+    assert stats["gram"] == (4, 4) and stats["csne"][0] == 3 and stats["csne"][2] == 0, stats
+    check(P, Delta, S)
+    order = np.array([5, 2, 1])
+    Q = {k: v[order].copy() for k, v in P.items()}
+    stats2, S2 = run_trf(Q, Delta[order])
+    assert stats2["csne"] == (3, 3, 0), stats2
+    for i, b in enumerate(order):
+        assert np.array_equal(S2.step[i], S.step[b]) and S2.alpha[i] == S.alpha[b]
+    one = {k: v[2:3].copy() for k, v in P.items()}
+    _, S1 = run_trf(one, Delta[2:3])
+    assert np.array_equal(S1.step[0], S.step[2])
+
+
+def test_inner_iterations_carry_alpha_and_need_no_new_factorisation():
+    """trf.py:283-331: the inner loop calls solve_lsq_trust_region again with a smaller Delta and the carried alpha
+    (initial_alpha inside the bracket: no restart) — step calls on the SAME factor; the pass reads the caller's J again."""
+    import bounded_lsq as bl
+    from bounded_lsq import _abi, _synth
+    from oracle import blsq_oracle as orc
+    rng = np.random.default_rng(77)
+    B, m, n = 3, 3000, 200
+    P = _synth.trf_batch(13, B, m, n, unbounded=True)
+    P["J"] = logspaced(rng, B, m, n, 6e3)
+    ctx = _abi.Context(0)
+    sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
+    ctx.csne_stats(reset=True)
+    sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+    Fo = [orc.trf_factor(P["J"][b], P["f"][b], P["x"][b], P["lb"][b], P["ub"][b], P["scale"][b]) for b in range(B)]
+    Delta = np.array([5.0, 1.0, 0.2])
+    alpha = np.zeros(B)
+    for it in range(4):
+        S = sol.step(Delta, alpha)
+        for b in range(B):
+            So = orc.trf_step(Fo[b], float(Delta[b]), float(alpha[b]))
+            assert rel(S.step[b], So.step) < RTOL, (it, b, rel(S.step[b], So.step))
+            assert int(S.n_iter[b]) == So.n_iter
+            assert abs(S.alpha[b] - So.alpha) <= 1e-9 * abs(So.alpha)
+        # the rejected-step update of trf.py:326-328
+        Dn = 0.25 * S.step_h_norm
+        alpha = S.alpha * Delta / Dn
+        Delta = Dn
+    assert ctx.csne_stats() == (B, 4 * B, 0)
+    sol.close(); ctx.close()
