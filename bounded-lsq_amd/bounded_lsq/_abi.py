@@ -75,6 +75,11 @@ SIGNATURES = {
     "blsq_debug_cqr_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
     "blsq_debug_gram_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
     "blsq_debug_cqr2_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
+    "blsq_option_count": (C.c_int, []),
+    "blsq_option_info": (C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_char_p)]),
+    "blsq_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_double]),
+    "blsq_ctx_get_option": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_double)]),
     "blsq_debug_csne_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
     "blsq_trf_debug_csne": (C.c_int, [vp, vp, vp]),
     "blsq_debug_probe": (C.c_int, [vp, C.c_int, C.c_int, c_double_p]),
@@ -239,6 +244,30 @@ class Context:
         out = (C.c_uint64 * 1)()
         self.check(self.lib.blsq_debug_cqr2_stats(self.h, out, 1 if reset else 0), "cqr2_stats")
         return int(out[0])
+
+    # ---- the option table (csrc/blsq_options.cpp) -----------------------------------------------
+    def set_option(self, name, value):
+        """One switch of THIS ctx (`name`: the table's key or its environment variable).  Route switches take effect for
+        plans created afterwards."""
+        self.check(self.lib.blsq_ctx_set_option(self.h, str(name).encode(), float(value)), "blsq_ctx_set_option")
+
+    def get_option(self, name):
+        v = C.c_double(0.0)
+        rc = self.lib.blsq_ctx_get_option(self.h, str(name).encode(), C.byref(v))
+        if rc != 0:
+            raise KeyError(name)
+        return float(v.value)
+
+    def options(self):
+        """-> list of dict(name, env, default, value, doc): every switch of the library and its value on this ctx."""
+        out = []
+        for i in range(self.lib.blsq_option_count()):
+            nm, ev, doc = C.c_char_p(), C.c_char_p(), C.c_char_p()
+            df = C.c_double(0.0)
+            self.lib.blsq_option_info(i, C.byref(nm), C.byref(ev), C.byref(df), C.byref(doc))
+            out.append({"name": nm.value.decode(), "env": ev.value.decode(), "default": float(df.value),
+                        "value": self.get_option(nm.value.decode()), "doc": doc.value.decode()})
+        return out
 
     def csne_stats(self, reset=False):
         """-> (problems routed to the CSNE tier by factor calls, step-solves it delivered, step-solves it declined)."""

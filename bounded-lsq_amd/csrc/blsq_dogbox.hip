@@ -1,0 +1,486 @@
+// C-ABI entry points (include/blsq.h): the dogbox plans — factor / step / fetch.
+#include "blsq_host.h"
+
+// =============================================================== dogbox ====
+namespace blsq_host {
+
+int dog_alloc_state(blsq_dogbox_plan* p) {
+  blsq_ctx* ctx = p->ctx;
+  const int B = p->B, ld = p->ld;
+  const size_t mat = (size_t)ld * ld;
+  const size_t vs = (size_t)B * ld;
+#define ALLOC(buf, bytes)                                               \
+  do {                                                                  \
+    hipError_t e__ = (buf).alloc(bytes);                                \
+    if (e__ != hipSuccess) return ctx->fail(e__, "hipMalloc(" #buf ")"); \
+  } while (0)
+  ALLOC(p->S, sizeof(double) * B * mat);
+  ALLOC(p->X, sizeof(double) * B * mat);
+  ALLOC(p->vecs, sizeof(double) * vs * 10);
+  ALLOC(p->ivecs, sizeof(int) * (vs + B));
+  ALLOC(p->scal2, sizeof(double) * (size_t)B * 4);
+  ALLOC(p->sweeps, sizeof(int) * (size_t)B);
+  ALLOC(p->active, vs);
+  ALLOC(p->onb, sizeof(long long) * vs);
+  ALLOC(p->o_vec, sizeof(double) * vs * 2);
+  ALLOC(p->o_onb, sizeof(long long) * vs);
+  ALLOC(p->o_scal, sizeof(double) * (size_t)B * 4);
+  ALLOC(p->o_info, sizeof(int) * (size_t)B * 4);
+  ALLOC(p->in_scal, sizeof(double) * (size_t)B);
+  ALLOC(p->gate_ints, sizeof(int) * 3 * (size_t)B);
+  ALLOC(p->colinfo, sizeof(double) * 2 * (size_t)B);
+  p->svdfree_enable = ctx->opt.i(OPT_NO_SVDFREE) == 1 ? 0 : 1;
+  HIPCHK(ctx, hipMemsetAsync(p->gate_ints.p, 0, p->gate_ints.bytes, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(p->S.p, 0, p->S.bytes, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(p->X.p, 0, p->X.bytes, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(p->vecs.p, 0, p->vecs.bytes, ctx->stream));
+  double* v = p->vecs.as<double>();
+  DogState& st = p->st;
+  st.B = B; st.m = p->m; st.n = p->n; st.ld = ld;
+  st.S = p->S.as<double>(); st.X = p->X.as<double>();
+  st.x = v; st.lb = v + vs; st.ub = v + 2 * vs; st.scale = v + 3 * vs; st.g = v + 4 * vs;
+  st.s = v + 5 * vs; st.uf = v + 6 * vs; st.newton = v + 7 * vs; st.cauchy = v + 8 * vs;
+  st.scale_in = v + 9 * vs;
+  st.on_bound = p->onb.as<long long>();
+  st.free_idx = p->ivecs.as<int>(); st.ncols = p->ivecs.as<int>() + vs;
+  st.srange = p->scal2.as<double>(); st.g_norm = p->scal2.as<double>() + 2 * (size_t)B;
+  st.active = p->active.as<unsigned char>();
+  p->out.step = p->o_vec.as<double>(); p->out.x_new = p->o_vec.as<double>() + vs;
+  p->out.on_bound_new = p->o_onb.as<long long>();
+  p->out.scal = p->o_scal.as<double>(); p->out.info = p->o_info.as<int>();
+  return 0;
+#undef ALLOC
+}
+
+int dog_put(blsq_dogbox_plan* p, const double* x, const double* lb, const double* ub,
+            const double* scale, const int64_t* on_bound, hipMemcpyKind kind, bool zero_counts = false) {
+  blsq_ctx* ctx = p->ctx;
+  int rc;
+  if (kind == hipMemcpyDeviceToDevice) {
+    PackVecs pv{{x, lb, ub, scale, on_bound}, {p->st.x, p->st.lb, p->st.ub, p->st.scale, p->st.on_bound},
+                (zero_counts && p->tree.gram) ? p->tree.fb_count() : nullptr, 3};
+    p->pack_pend = false;
+    if (zero_counts && p->tree.gram && ctx->fuse_pack()) {   // (the Gram stage's prep launch does it: dog_factor_core)
+      p->pack_pv = pv; p->pack_pend = true;
+      p->tree.fb_zeroed = true;
+      return 0;
+    }
+    hipError_t e = launch_pack_vecs(pv, p->n, p->ld, p->B, ctx->stream);
+    if (e != hipSuccess) return ctx->fail(e, "launch_pack_vecs");
+    p->tree.fb_zeroed = zero_counts && p->tree.gram;
+    return 0;
+  }
+  if ((rc = put_vec(ctx, p->st.x, p->ld, x, p->n, p->B, kind))) return rc;
+  if ((rc = put_vec(ctx, p->st.lb, p->ld, lb, p->n, p->B, kind))) return rc;
+  if ((rc = put_vec(ctx, p->st.ub, p->ld, ub, p->n, p->B, kind))) return rc;
+  if ((rc = put_vec(ctx, p->st.scale, p->ld, scale, p->n, p->B, kind))) return rc;
+  HIPCHK(ctx, hipMemcpy2DAsync(p->st.on_bound, sizeof(long long) * p->ld, on_bound,
+                               sizeof(long long) * p->n, sizeof(long long) * p->n, p->B, kind,
+                               ctx->stream));
+  return 0;
+}
+
+// the free-column QR (Householder-path problems), rank gate + Newton step, SVD for the rest
+int dog_finish(blsq_dogbox_plan* p, const int* path, bool any_qr, bool any_gram) {
+  blsq_ctx* ctx = p->ctx;
+  hipError_t e;
+  if (any_qr) {
+    QrArgs q = p->tree.base_args();
+    q.A = p->st.S; q.strideA = (long)p->ld * p->ld; q.ldA = p->ld; q.rowsA = p->n;
+    q.F = nullptr; q.strideF = 0; q.ncols_dev = p->st.ncols;
+    q.require_path = path;
+    q.rows_per_leaf = p->ld; q.RP = p->ld;
+    q.Rout = p->st.X;
+    ctx->begin(K_QR_AUG);
+    e = launch_qr(q, 1, p->B, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_qr(free block)");
+  }
+  int* gfast = p->gate_ints.as<int>();
+  int* gmask = gfast + p->B;
+  p->st.fast = gfast;
+  if (!p->gate_done) {
+    ctx->begin(K_LM_GATE);
+    e = launch_dog_gate_solve(p->st, gfast, gmask, p->svdfree_enable, path,
+                              (path && any_gram) ? p->colinfo.as<double>() : nullptr, nullptr, nullptr, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_dog_gate_solve");
+    p->njac = -1;
+  }
+  p->gate_done = false;
+  if (p->njac != 0) {
+    JacobiArgs ja{};
+    ja.X = p->st.X; ja.strideX = (long)p->ld * p->ld; ja.ld = p->ld; ja.ncols_dev = gmask;
+    ja.N = p->n + 1; ja.s = p->st.s; ja.uf = p->st.uf; ja.srange = p->st.srange;
+    ja.sweeps = p->sweeps.as<int>(); ja.max_sweeps = 40;
+    ctx->begin(K_JACOBI);
+    e = launch_jacobi(ja, p->B, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_jacobi");
+  }
+  ctx->begin(K_STEP);
+  e = launch_dog_solve(p->st, gfast, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_dog_solve");
+  return 0;
+}
+
+// a triangle [R c] of [J f] for every problem (front end off)
+int dog_after_triangle(blsq_dogbox_plan* p, int scale_mode) {
+  blsq_ctx* ctx = p->ctx;
+  p->st.Rt = p->tree.Rfinal(); p->st.Gk = nullptr; p->st.path = nullptr;
+  p->tree.path_valid = false; p->tree.any_gram = false; p->tree.any_qr = true;
+  p->gate_done = false;
+  ctx->begin(K_PREP);
+  hipError_t e = launch_dog_prep(p->st, scale_mode, 0, nullptr, 0, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_dog_prep");
+  return dog_finish(p, nullptr, true, false);
+}
+
+GramCholArgs dog_chol_args(blsq_dogbox_plan* p, const int* mask) {
+  QrTree& t = p->tree;
+  GramCholArgs c{};
+  c.opt = &p->ctx->opt;
+  c.Gsrc = t.gram_keep.as<double>(); c.G = p->st.X; c.NPAD = p->ld; c.n = p->n;
+  c.ncols_dev = p->st.ncols; c.gather = p->st.free_idx; c.stride_vec = p->ld;
+  c.mask = mask; c.fb_mask = t.fb_mask(); c.fail_count = t.fb_count(); c.path_out = t.path_rw();
+  c.fail_list = t.fb_list();
+  c.dsc = t.gram_dsc.as<double>();
+  c.rinv = t.gram_rinv.as<double>(); c.ywork = t.gram_ywork.as<double>(); c.k2_out = t.gram_k2.as<double>();
+  c.cert_done = t.gram_cert.as<int>();
+  c.k2_max = t.k2_max; c.pivot_floor = 1.0 / t.k2_max;
+  c.cert_flag = t.gram_cflag.as<int>(); c.cert_tau = t.gram_ctau.as<double>();
+  c.colinfo = p->colinfo.as<double>();
+  if (p->ld <= 80) {                        // (the register-resident kernel also finishes the gate / Newton / Cauchy work)
+    int* gf_ = p->gate_ints.as<int>();
+    c.dog.g = p->st.g; c.dog.newton = p->st.newton; c.dog.cauchy = p->st.cauchy;
+    c.dog.fast = gf_; c.dog.ncols_jac = gf_ + p->B; c.dog.done = gf_ + 2 * (size_t)p->B;
+    c.unsettled = t.fb_count() + 2;
+    c.dog.m = p->m; c.dog.enable = p->svdfree_enable;
+  }
+  return c;
+}
+
+// the second half of the certificate + rank gate + Newton / Cauchy steps of the problems the Cholesky
+// kernel has not settled itself (counters: fb_count()[0] problems that leave the path, [1] that need the SVD)
+int dog_gate_tail(blsq_dogbox_plan* p, const GramCholArgs& c) {
+  blsq_ctx* ctx = p->ctx;
+  QrTree& t = p->tree;
+  ctx->begin(K_GRAM_GATE);
+  hipError_t e = launch_gram_gate(c, p->B, ctx->stream);
+  if (e == hipSuccess) e = launch_gram_cert_shift(c, p->B, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_gram_gate");
+  int* gfast = p->gate_ints.as<int>();
+  p->st.fast = gfast;
+  ctx->begin(K_LM_GATE);
+  e = launch_dog_gate_solve(p->st, gfast, gfast + p->B, p->svdfree_enable, t.path_rw(),
+                            p->colinfo.as<double>(), t.fb_count() + 1, c.dog.g ? c.dog.done : nullptr, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_dog_gate_solve");
+  return 0;
+}
+
+// The whole factor call from device-resident [J f].  Normal-equations path (as TRF): g and the
+// column norms from the Gram, the triangle of [J[:, free] | f] as the Cholesky factor of the gathered
+// principal sub-matrix G[free ++ rhs, free ++ rhs], and the conditioning gate applied to THAT factor
+// — the system lstsq(J_free, -f) is solved from (dogbox.py:197).  No triangle of J is formed; a problem
+// the gate rejects goes through the Householder tree and is prepared again from its triangle.
+int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int ldJ, int scale_mode,
+                    const int* mask, bool may_defer) {
+  blsq_ctx* ctx = p->ctx;
+  QrTree& t = p->tree;
+  int rc;
+  if ((rc = verdict_drop(p))) return rc;
+  if (!t.gram) {
+    if ((rc = t.run_levels(ctx, dJ, df, ldJ, mask))) return rc;
+    return dog_after_triangle(p, scale_mode);
+  }
+  if ((rc = t.run_gram_only(ctx, dJ, df, ldJ, mask, false))) return rc;
+  if (!t.fb_zeroed) HIPCHK(ctx, hipMemsetAsync(t.fb_count(), 0, 3 * sizeof(int), ctx->stream));
+  t.fb_zeroed = false;
+  p->st.Rt = t.Rfinal(); p->st.Gk = t.gram_keep.as<double>(); p->st.path = t.path_rw();
+  const PackVecs* pk = nullptr;
+  { int rc_ = take_pack(p, mask, &pk); if (rc_) return rc_; }
+  ctx->begin(K_PREP);
+  hipError_t e = launch_dog_prep(p->st, scale_mode, 1, mask, 0, ctx->stream, pk);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_dog_prep(gram)");
+  const GramCholArgs c = dog_chol_args(p, mask);
+  ctx->begin(K_AUG_CHOL);
+  e = launch_gram_chol(c, p->B, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(free block)");
+  const bool defer = may_defer && p->optimistic && p->guess_ok && p->svdfree_enable && !mask && p->pend_pin &&
+                     p->pend_ev;
+  // second guess (N <= 80): the Cholesky kernel settles EVERY problem itself, as it did in the last call —
+  // then the certificate, gate and solve launches would all be empty and are not enqueued at all
+  const bool skip_tail = defer && p->guess_settled && c.dog.g != nullptr;
+  p->st.fast = p->gate_ints.as<int>();
+  if (!skip_tail && (rc = dog_gate_tail(p, c))) return rc;
+  int nfb = 0;
+  if (defer) {                              // guess: nobody leaves the path, nobody needs the SVD (dog_resolve checks)
+    if ((rc = verdict_arm(p, skip_tail, dJ, df, ldJ, scale_mode))) return rc;
+  } else {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 1, t.fb_count(), 3 * sizeof(int), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    nfb = ctx->pinned[1];
+    p->gate_done = (nfb == 0);
+    p->njac = p->gate_done ? ctx->pinned[2] : -1;
+    if (!mask) { p->guess_ok = (nfb == 0 && p->njac == 0); p->guess_settled = (c.unsettled && ctx->pinned[3] == 0); }
+  }
+  t.note_paths(ctx, nfb, mask != nullptr);
+  if (skip_tail) { p->gate_done = false; return 0; }
+  if (nfb > 0) {
+    if ((rc = t.run_fallback(ctx, dJ, df, ldJ, nfb))) return rc;
+    ctx->begin(K_PREP);
+    e = launch_dog_prep(p->st, scale_mode, 0, t.fb_mask(), 1, ctx->stream);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_dog_prep(redo)");
+  }
+  return dog_finish(p, t.path_rw(), t.any_qr, t.any_gram);
+}
+
+// the verdict of an optimistic dogbox factor call (as trf_resolve)
+int dog_resolve(blsq_dogbox_plan* p, bool* redo) {
+  return verdict_resolve(
+      p, redo, [&]() { return dog_gate_tail(p, dog_chol_args(p, nullptr)); },
+      [&](int nfb) {
+        blsq_ctx* ctx = p->ctx;
+        QrTree& t = p->tree;
+        if (nfb > 0) {
+          int rc = t.run_fallback(ctx, p->pend_dJ, p->pend_df, p->pend_ldJ, nfb);
+          if (rc) return rc;
+          ctx->begin(K_PREP);
+          hipError_t e = launch_dog_prep(p->st, p->pend_scale_mode, 0, t.fb_mask(), 1, ctx->stream);
+          ctx->end();
+          if (e != hipSuccess) return ctx->fail(e, "launch_dog_prep(redo)");
+        }
+        return dog_finish(p, t.path_rw(), t.any_qr, t.any_gram);
+      });
+}
+
+}  // namespace blsq_host
+
+extern "C" int blsq_dogbox_plan_create(blsq_ctx* ctx, int B, int m, int n,
+                                       blsq_dogbox_plan** out) {
+  if (!ctx) return -1;
+  if (!out) return ctx->bad(5, "out is NULL");
+  *out = nullptr;
+  if (B <= 0) return ctx->bad(2, "B must be positive");
+  if (m <= 0) return ctx->bad(3, "m must be positive");
+  if (n <= 0) return ctx->bad(4, "n must be positive");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  blsq_dogbox_plan* p = new blsq_dogbox_plan();
+  p->ctx = ctx; p->B = B; p->m = m; p->n = n;
+  int rc = p->tree.build(ctx, B, m, n, (size_t)B * round_up(n + 1, 16));
+  if (rc == 0) { p->ld = p->tree.NPAD; rc = dog_alloc_state(p); }
+  if (rc == 0) {
+    p->optimistic = ctx->opt.on(OPT_OPTIMISTIC);
+    hipError_t e = hipHostMalloc((void**)&p->pend_pin, 4 * sizeof(int), hipHostMallocCoherent);
+    if (e == hipSuccess) memset(p->pend_pin, 0, 4 * sizeof(int));
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->pend_ev, hipEventDisableTiming);
+    if (e != hipSuccess) rc = ctx->fail(e, "optimistic-verdict resources");
+  }
+  if (rc != 0) { blsq_dogbox_plan_destroy(p); return rc; }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->dog_plans.push_back(p);
+  *out = p;
+  return 0;
+}
+
+extern "C" int blsq_dogbox_plan_destroy(blsq_dogbox_plan* p) {
+  if (!p) return -1;
+  hipStreamSynchronize(p->ctx->stream);
+  { auto& v = p->ctx->dog_plans; v.erase(std::remove(v.begin(), v.end(), p), v.end()); }
+  if (p->pend_pin) hipHostFree(p->pend_pin);
+  if (p->pend_ev) hipEventDestroy(p->pend_ev);
+  p->tree.release();
+  p->S.release(); p->X.release(); p->vecs.release(); p->ivecs.release(); p->scal2.release();
+  p->sweeps.release(); p->active.release(); p->onb.release(); p->o_vec.release();
+  p->o_onb.release(); p->o_scal.release(); p->o_info.release(); p->in_J.release();
+  p->in_f.release(); p->in_vec.release(); p->in_scal.release(); p->gate_ints.release(); p->colinfo.release();
+  delete p;
+  return 0;
+}
+
+extern "C" int blsq_dogbox_factor_dev(blsq_dogbox_plan* p, const double* dJ, const double* df,
+                                      const double* dx, const double* dlb, const double* dub,
+                                      double* dscale_io, int scale_mode,
+                                      const int64_t* don_bound) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!dJ) return ctx->bad(2, "J is NULL");
+  if (!df) return ctx->bad(3, "f is NULL");
+  if (!dx || !dlb || !dub) return ctx->bad(4, "x/lb/ub is NULL");
+  if (!dscale_io) return ctx->bad(7, "scale is NULL");
+  if (scale_mode < 0 || scale_mode > 2) return ctx->bad(8, "scale_mode");
+  if (!don_bound) return ctx->bad(9, "on_bound is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = verdict_published(p);               // (a verdict nobody read: its counters leave before they are cleared)
+  if (rc) return rc;
+  rc = dog_put(p, dx, dlb, dub, dscale_io, don_bound, hipMemcpyDeviceToDevice, true);
+  if (rc) return rc;
+  p->pend_scale_io = dscale_io;
+  if ((rc = dog_factor_core(p, dJ, df, p->n, scale_mode, nullptr, true))) return rc;
+  if (scale_mode != BLSQ_SCALE_GIVEN) {
+    HIPCHK(ctx, hipMemcpy2DAsync(dscale_io, sizeof(double) * p->n, p->st.scale,
+                                 sizeof(double) * p->ld, sizeof(double) * p->n, p->B,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  return 0;
+}
+
+extern "C" int blsq_dogbox_step_dev(blsq_dogbox_plan* p, const double* dDelta) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!dDelta) return ctx->bad(2, "Delta is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  for (int pass = 0; pass < 2; ++pass) {    // (pass 1 only after a wrong optimistic guess)
+    ctx->begin(K_STEP);
+    const PublishArgs pub = verdict_rides(p);
+    hipError_t e = launch_dog_step(p->st, dDelta, p->out, ctx->stream, &pub);
+    ctx->end();
+    if (e != hipSuccess) return ctx->fail(e, "launch_dog_step");
+    bool redo = false;
+    int rc = dog_resolve(p, &redo);
+    if (rc) return rc;
+    if (!redo) break;
+  }
+  return 0;
+}
+
+extern "C" int blsq_dogbox_fetch_factor(blsq_dogbox_plan* p, double* g, uint8_t* active_set,
+                                        double* g_norm, int32_t* all_active, double* scale,
+                                        double* newton_full, double* cauchy_full) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  const int B = p->B, n = p->n, ld = p->ld;
+  int rc;
+  if ((rc = dog_resolve(p, nullptr))) return rc;
+  if ((rc = get_vec(ctx, g, n, p->st.g, ld, B))) return rc;
+  if ((rc = get_vec(ctx, scale, n, p->st.scale, ld, B))) return rc;
+  if ((rc = get_vec(ctx, (unsigned char*)active_set, n, p->st.active, ld, B))) return rc;
+  if (g_norm) HIPCHK(ctx, hipMemcpyAsync(g_norm, p->st.g_norm, sizeof(double) * B,
+                                         hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<int> nc(B), fidx;
+  HIPCHK(ctx, hipMemcpyAsync(nc.data(), p->st.ncols, sizeof(int) * B, hipMemcpyDeviceToHost,
+                             ctx->stream));
+  std::vector<double> nw, ca;
+  if (newton_full || cauchy_full) {
+    fidx.resize((size_t)B * ld); nw.resize((size_t)B * ld); ca.resize((size_t)B * ld);
+    HIPCHK(ctx, hipMemcpyAsync(fidx.data(), p->st.free_idx, sizeof(int) * fidx.size(),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(nw.data(), p->st.newton, sizeof(double) * nw.size(),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ca.data(), p->st.cauchy, sizeof(double) * ca.size(),
+                               hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if ((rc = blsq_sync(ctx))) return rc;
+  for (int b = 0; b < B; ++b) {
+    if (all_active) all_active[b] = (nc[b] == 0) ? 1 : 0;
+    if (newton_full || cauchy_full) {
+      for (int j = 0; j < n; ++j) {
+        if (newton_full) newton_full[(size_t)b * n + j] = 0.0;
+        if (cauchy_full) cauchy_full[(size_t)b * n + j] = 0.0;
+      }
+      for (int q = 0; q + 1 < nc[b]; ++q) {
+        const int j = fidx[(size_t)b * ld + q];
+        if (newton_full) newton_full[(size_t)b * n + j] = nw[(size_t)b * ld + q];
+        if (cauchy_full) cauchy_full[(size_t)b * n + j] = ca[(size_t)b * ld + q];
+      }
+    }
+  }
+  return 0;
+}
+
+extern "C" int blsq_dogbox_debug_cond(blsq_dogbox_plan* p, double* k2) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!k2) return ctx->bad(2, "k2 is NULL");
+  if (!p->tree.gram) { for (int b = 0; b < p->B; ++b) k2[b] = 0.0; return 0; }
+  { int rc_ = dog_resolve(p, nullptr); if (rc_) return rc_; }
+  HIPCHK(ctx, hipMemcpyAsync(k2, p->tree.gram_k2.p, sizeof(double) * p->B, hipMemcpyDeviceToHost,
+                             ctx->stream));
+  return blsq_sync(ctx);
+}
+
+extern "C" int blsq_dogbox_fetch_step(blsq_dogbox_plan* p, double* step, double* x_new,
+                                      int64_t* on_bound_new, uint8_t* tr_hit,
+                                      double* predicted_reduction, double* step_scaled_norm,
+                                      uint8_t* fallback, int32_t* status) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  const int B = p->B, n = p->n, ld = p->ld;
+  int rc;
+  if ((rc = get_vec(ctx, step, n, p->out.step, ld, B))) return rc;
+  if ((rc = get_vec(ctx, x_new, n, p->out.x_new, ld, B))) return rc;
+  if ((rc = get_vec(ctx, (long long*)on_bound_new, n, p->out.on_bound_new, ld, B))) return rc;
+  std::vector<double> sc((size_t)B * 4);
+  std::vector<int> inf((size_t)B * 4);
+  HIPCHK(ctx, hipMemcpyAsync(sc.data(), p->out.scal, sizeof(double) * sc.size(),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(inf.data(), p->out.info, sizeof(int) * inf.size(),
+                             hipMemcpyDeviceToHost, ctx->stream));
+  if ((rc = blsq_sync(ctx))) return rc;
+  for (int b = 0; b < B; ++b) {
+    if (predicted_reduction) predicted_reduction[b] = sc[4 * b + 0];
+    if (step_scaled_norm) step_scaled_norm[b] = sc[4 * b + 1];
+    if (tr_hit) tr_hit[b] = (uint8_t)inf[4 * b + 0];
+    if (fallback) fallback[b] = (uint8_t)inf[4 * b + 1];
+    if (status) status[b] = inf[4 * b + 3];
+  }
+  return 0;
+}
+
+extern "C" int blsq_dogbox_factor(blsq_dogbox_plan* p, const double* J, const double* f,
+                                  const double* x, const double* lb, const double* ub,
+                                  double* scale_io, int scale_mode, const int64_t* on_bound,
+                                  double* g, uint8_t* active_set, double* g_norm,
+                                  int32_t* all_active) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!J) return ctx->bad(2, "J is NULL");
+  if (!f) return ctx->bad(3, "f is NULL");
+  if (!x || !lb || !ub) return ctx->bad(4, "x/lb/ub is NULL");
+  if (!scale_io) return ctx->bad(7, "scale is NULL");
+  if (scale_mode < 0 || scale_mode > 2) return ctx->bad(8, "scale_mode");
+  if (!on_bound) return ctx->bad(9, "on_bound is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t jb = sizeof(double) * (size_t)p->B * p->m * p->n;
+  const size_t fb = sizeof(double) * (size_t)p->B * p->m;
+  if (!p->in_J.p || !p->in_f.p) {       // lazily, and again if an earlier attempt failed half way
+    hipError_t e = p->in_J.p ? hipSuccess : p->in_J.alloc(jb);
+    if (e != hipSuccess) return ctx->fail(e, "hipMalloc(J staging)");
+    e = p->in_f.p ? hipSuccess : p->in_f.alloc(fb);
+    if (e != hipSuccess) return ctx->fail(e, "hipMalloc(f staging)");
+  }
+  HIPCHK(ctx, hipMemcpyAsync(p->in_J.p, J, jb, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(p->in_f.p, f, fb, hipMemcpyHostToDevice, ctx->stream));
+  int rc = dog_put(p, x, lb, ub, scale_io, on_bound, hipMemcpyHostToDevice);
+  if (rc) return rc;
+  if ((rc = dog_factor_core(p, p->in_J.as<double>(), p->in_f.as<double>(), p->n, scale_mode, nullptr)))
+    return rc;
+  return blsq_dogbox_fetch_factor(p, g, active_set, g_norm, all_active,
+                                  scale_mode != BLSQ_SCALE_GIVEN ? scale_io : nullptr, nullptr,
+                                  nullptr);
+}
+
+extern "C" int blsq_dogbox_step(blsq_dogbox_plan* p, const double* Delta, double* step,
+                                double* x_new, int64_t* on_bound_new, uint8_t* tr_hit,
+                                double* predicted_reduction, double* step_scaled_norm,
+                                uint8_t* fallback, int32_t* status) {
+  if (!p) return -1;
+  blsq_ctx* ctx = p->ctx;
+  if (!Delta) return ctx->bad(2, "Delta is NULL");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  double* dD = p->in_scal.as<double>();
+  HIPCHK(ctx, hipMemcpyAsync(dD, Delta, sizeof(double) * p->B, hipMemcpyHostToDevice, ctx->stream));
+  int rc = blsq_dogbox_step_dev(p, dD);
+  if (rc) return rc;
+  return blsq_dogbox_fetch_step(p, step, x_new, on_bound_new, tr_hit, predicted_reduction,
+                                step_scaled_norm, fallback, status);
+}
+

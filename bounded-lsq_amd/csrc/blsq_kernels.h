@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "blsq_options.h"
+
 namespace blsq {
 
 // ---------------------------------------------------------------- QR ------
@@ -38,6 +40,7 @@ struct QrArgs {
   double* dbg;            // diagnostic stamps (nullptr in the product)
   int stack_rows;         // >0: source is a stack of upper-triangular blocks of this many rows
   int cqr;                // 1: Cholesky-QR + Householder-reconstruction panels (set by launch_qr)
+  const Options* opt;     // host only: the ctx's switches (nullptr: the table's defaults)
 };
 // The kernel stages at most QR_MAX_TILES 16-row tiles per workgroup: all RP/16 tiles of a
 // dense source, G * ceil((N-1)/16) of a stack of G triangular blocks (qr_panel.hip).
@@ -68,6 +71,7 @@ struct GramArgs {
   int rows_per_chunk;     // set by launch_gram
   int rhs_valu;           // set by launch_gram: J^T f / f^T f accumulated by the vector ALUs
   double* Gscr;           // set by launch_gram (pair mode): the chunk-partials buffer, used as scratch
+  const Options* opt;     // host only: the ctx's switches (nullptr: the table's defaults)
 };
 struct GramCholArgs {
   const double* Gsrc;     // [B][NPAD*NPAD] Gram (upper tile blocks); may alias G (in place)
@@ -159,6 +163,7 @@ struct GramCholArgs {
   int* unsettled;
   double* pmin_out;       // optional [B] out: the smallest squared pivot of R' the factorisation met (the CSNE tier's
                           // own floor is far below the gate's, csne_kernels.hip); not written by a shifted launch
+  const Options* opt;     // host only: the ctx's switches (nullptr: the table's defaults)
 };
 // A problem stays on the normal-equations path only if the PROVEN bound K2 >= kappa_2(R'^T R') of its
 // equilibrated system is at most GRAM_K2_MAX (chol_kernels.hip, gram_cond_kernel).  Consequence used
@@ -179,7 +184,7 @@ constexpr double GRAM_CERT_PIVOT_FLOOR = 1.0e-9;
 // accumulated in row chunks (rows_per_chunk terms in the MFMA accumulator, then nchunks partial sums), so
 // their rounding error grows like a(m) = sqrt(rows_per_chunk) + sqrt(nchunks); the error constant of
 // DESIGN.md 3.0 was calibrated at m = 4096 (a = 46.7) and the gate is tightened by a(4096) / a(m) beyond.
-double gram_k2_max(long long m_total);
+double gram_k2_max(long long m_total, double tighter = 0.0);   // tighter > 0: the gate if it is below the calibrated one
 bool gram_supported(int m, int n);
 int gram_chunks(int B, int m);
 // Gfinal / fused (optional): where the reduced Gram belongs; *fused = true means the launch produced it

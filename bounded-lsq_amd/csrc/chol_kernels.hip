@@ -2399,7 +2399,7 @@ __global__ __launch_bounds__(GR_NT, 4) void gram_cond_kernel(GramCholArgs a) {
   }
 }
 
-double gram_k2_max(long long m_total) {
+double gram_k2_max(long long m_total, double tighter) {
   auto acc = [](double m) {
     const double chunk = m > 131072.0 ? 1024.0 : 2048.0;           // (gram_chunks: a function of m alone)
     const double rows = m < chunk ? m : chunk;
@@ -2407,8 +2407,7 @@ double gram_k2_max(long long m_total) {
   };
   const double f = acc(4096.0) / acc((double)(m_total > 1 ? m_total : 1));
   double k = GRAM_K2_MAX * (f < 1.0 ? f : 1.0);
-  const char* env = getenv("BLSQ_GRAM_K2_MAX");                    // may only tighten the gate
-  if (env && env[0]) { const double v = atof(env); if (v > 0.0 && v < k) k = v; }
+  if (tighter > 0.0 && tighter < k) k = tighter;                   // (option gram_k2_max: may only tighten the gate)
   return k;
 }
 
@@ -2426,8 +2425,7 @@ hipError_t launch_gram_chol(const GramCholArgs& a_in, int B, hipStream_t s) {
   const size_t per = sizeof(double) * (4 * (size_t)a.NPAD + 512);
   if (a.NPAD <= 80) {                                   // one wave per problem, eight per workgroup
     // (register-resident right-looking kernel; BLSQ_CHOL_REG = 0: the left-looking one-wave kernel)
-    const char* rge = getenv("BLSQ_CHOL_REG");
-    if (rge && rge[0] == '0') {
+    if (!options_or_default(a.opt).on(OPT_CHOL_REG)) {
       // (this kernel has no finish blocks: nothing is settled, nobody is done)
       hipError_t me = hipSuccess;
       if (a.unsettled) me = hipMemsetD32Async((hipDeviceptr_t)a.unsettled, 1, 1, s);
@@ -2450,11 +2448,9 @@ hipError_t launch_gram_chol(const GramCholArgs& a_in, int B, hipStream_t s) {
     // (512 problems: two generations, 0.241 against 0.262 ms).  BLSQ_CHOL_RL = 0 / 1 forces either;
     // BLSQ_CHOL_RL2 = 0 selects the barrier-synchronous right-looking kernel (<= 256 problems: 0.187 ms).
     // All three agree bit for bit (same operands, same order), so the choice is speed only.
-    const char* rle = getenv("BLSQ_CHOL_RL");          // (read per launch: tests compare the kernels)
-    const int rl_env = rle ? (rle[0] == '0' ? 0 : 1) : -1;
-    const bool rl = rl_env >= 0 ? rl_env != 0 : true;
-    const char* r2e = getenv("BLSQ_CHOL_RL2");         // 0: the barrier-synchronous right-looking kernel
-    const bool rl2 = rl && !(r2e && r2e[0] == '0');
+    const Options& opt = options_or_default(a.opt);    // (per launch: tests compare the kernels)
+    const bool rl = opt.i(OPT_CHOL_RL) != 0;           // (-1 / 1: right-looking)
+    const bool rl2 = rl && opt.on(OPT_CHOL_RL2);       // 0: the barrier-synchronous right-looking kernel
     if (a.cert_ym && !rl2) {                            // (only the flag-driven kernel has a share in stage 0)
       hipError_t me = hipMemsetAsync(a.cert_ym, 0, sizeof(double) * (size_t)B, s);
       if (me != hipSuccess) return me;
@@ -2510,8 +2506,7 @@ hipError_t launch_gram_gate(const GramCholArgs& a_in, int B, hipStream_t s, bool
   // stage 0 (N > 80; the register-resident factor kernel of the small shapes carries its own first bound):
   // BLSQ_CERT0 = 0 switches it off
   if (a.NPAD > 80 && a.cert_done && a.dsc) {
-    const char* ce = getenv("BLSQ_CERT0");
-    if (!(ce && ce[0] == '0')) {
+    if (options_or_default(a.opt).on(OPT_CERT0)) {
       const size_t lds0 = sizeof(double) * (4 + 32 + 1) * (size_t)a.NPAD;
       static std::atomic<size_t> granted[64];
       hipError_t ge = gram_grant_lds(gram_cert0_kernel, lds0, granted);

@@ -924,13 +924,13 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s, d
   // per wave between a cold start and an eight-way reduction, and one workgroup fills the CU: 1024
   // problems of 512 x 64 pass in four lock-step generations.  On two waves, four workgroups share the CU
   // and drift apart: 96 -> 78 us.  BLSQ_GRAM_DIRECT_NW = 2 | 4 | 8 forces one.
-  const char* dnw_e = getenv("BLSQ_GRAM_DIRECT_NW");
+  const Options& opt = options_or_default(a.opt);
+  const int dnw_o = opt.i(OPT_GRAM_DIRECT_NW);
   const int rows_wg = a.m < a.rows_per_chunk ? a.m : a.rows_per_chunk;
   // (up to 128 rows eight waves need a single round of loads: nothing to drift, lowest latency)
-  const int direct_nw = dnw_e ? atoi(dnw_e) : (rows_wg <= 128 ? 8 : rows_wg <= 512 ? 2 : rows_wg <= 1024 ? 4 : 8);
+  const int direct_nw = dnw_o > 0 ? dnw_o : (rows_wg <= 128 ? 8 : rows_wg <= 512 ? 2 : rows_wg <= 1024 ? 4 : 8);
   {
-    const char* env = getenv("BLSQ_GRAM_DIRECT_MAX_NT");     // tuning / tests: 0 disables
-    const int dmax = env ? atoi(env) : 4;                      // measured: direct wins up to 4 column tiles
+    const int dmax = opt.i(OPT_GRAM_DIRECT_MAX_NT);            // tuning / tests: 0 disables; measured: direct wins up to 4 column tiles
     // n a multiple of 16: the tiles cover J^T J only (n / 16 column tiles), the rhs column is
     // accumulated from the same fragments (n = 64: 10 tiles instead of 15, and still no LDS staging)
     if (a.rhs_valu && NTJ <= dmax) {
@@ -951,8 +951,7 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s, d
   {
     // 8 column tiles of J^T J (n = 113 .. 128): the k-split static-tile kernel, for EVERY batch size
     // (its summation order defines the result for these widths).  BLSQ_GRAM8 = 0: the generic kernel.
-    const char* g8e = getenv("BLSQ_GRAM8");
-    if (NTJ == 8 && !(g8e && g8e[0] == '0')) {
+    if (NTJ == 8 && opt.on(OPT_GRAM8)) {
       const size_t need = sizeof(double) * 4 * 9 * 256;          // partial tiles of the odd k-steps
       const size_t l8 = lds > need ? lds : need;
       if (a.rhs_valu) {
@@ -973,8 +972,7 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s, d
   // tile groups: enough workgroups to occupy the CUs when the batch is small (results identical)
   int tg = 1;
   {
-    const char* tge = getenv("BLSQ_GRAM_TILE_GROUPS");    // (tests compare splits bit for bit)
-    const int tenv = tge ? atoi(tge) : 0;
+    const int tenv = opt.i(OPT_GRAM_TILE_GROUPS);        // (tests compare splits bit for bit)
     const long wgs = (long)chunks * B;
     // (only when the row chunks alone leave most CUs idle: every group re-reads the rows)
     tg = tenv > 0 ? tenv : (wgs <= 64 ? (int)((256 + wgs - 1) / wgs) : 1);
@@ -991,14 +989,12 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s, d
   {
     // 16 column tiles of J^T J (n = 241 .. 256) and one workgroup per row chunk: the kernel with
     // static tile rows per wave (BLSQ_GRAM16 = 0 keeps the generic one: tests compare the two)
-    const char* g16e = getenv("BLSQ_GRAM16");
-    const int g16_env = g16e ? atoi(g16e) : 1;
+    const int g16_env = opt.i(OPT_GRAM16);
     if (NTJ == 16 && tg == 1 && g16_env != 0 && a.m >= 1) {
       // two row chunks and enough problems to fill the device with one workgroup each: both chunks by
       // the same workgroup, summed in the kernel straight into the final slot (bit-identical to the
       // reduction pass: BLSQ_GRAM_PAIR = 0 keeps that)
-      const char* pe = getenv("BLSQ_GRAM_PAIR");
-      const bool pair = Gfinal && chunks == 2 && B >= 256 && !(pe && pe[0] == '0');
+      const bool pair = Gfinal && chunks == 2 && B >= 256 && opt.on(OPT_GRAM_PAIR);
       if (pair) { a.Gscr = a.G; a.G = Gfinal; if (fused) *fused = true; }
       const dim3 grid(pair ? 1 : chunks, B, 1);
 #define BLSQ_GRAM16(RHS_, PAIR_)                                                              \

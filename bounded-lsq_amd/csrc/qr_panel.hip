@@ -990,9 +990,7 @@ hipError_t launch_qr(const QrArgs& q_in, int nleaf, int B, hipStream_t st) {
   QrArgs q = q_in;
   q.dbg = g_qr_dbg;
   {
-    static int cqr = -1;
-    if (cqr < 0) { const char* e = getenv("BLSQ_QR_CQR"); cqr = (e && e[0] == '0') ? 0 : 1; }
-    q.cqr = cqr;
+    q.cqr = options_or_default(q.opt).on(OPT_QR_CQR) ? 1 : 0;
   }
   if (g_qr_dbg) g_qr_dbg += (size_t)nleaf * B * 8;   // successive launches append
   // a stack the interleaved staging cannot express is factored as a dense source

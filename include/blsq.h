@@ -52,6 +52,17 @@ int blsq_ctx_destroy(blsq_ctx* ctx);
 const char* blsq_last_error(const blsq_ctx* ctx);
 int blsq_sync(blsq_ctx* ctx);
 
+/* Run-time switches: ONE table inside the library (csrc/blsq_options.cpp; INTEGRATION.md lists it).  A ctx reads every
+ * switch ONCE, at blsq_ctx_create, from the environment variable the table names; afterwards only blsq_ctx_set_option
+ * changes it, for that ctx alone.  Route switches (gram, cqr2, csne, optimistic, no_svdfree, svdfree_min_n, gram_k2_max)
+ * take effect for plans created afterwards, the others at the next call.  `name` is the table's key or its environment
+ * variable's name.  No switch loosens a proven gate (gram_k2_max can only tighten).  blsq_option_info: i in
+ * [0, blsq_option_count()). */
+int blsq_option_count(void);
+int blsq_option_info(int i, const char** name, const char** env, double* default_value, const char** doc);
+int blsq_ctx_set_option(blsq_ctx* ctx, const char* name, double value);
+int blsq_ctx_get_option(const blsq_ctx* ctx, const char* name, double* value);
+
 /* device memory helpers (so hosts need not bind the HIP runtime themselves) */
 int blsq_dev_malloc(blsq_ctx* ctx, size_t bytes, void** dptr);
 int blsq_dev_free(blsq_ctx* ctx, void* dptr);
@@ -106,8 +117,8 @@ int blsq_trf_step(blsq_trf_plan* plan, const double* Delta /*B*/, double* alpha_
  * plan, or by blsq_sync(ctx), which resolves every pending verdict of the ctx (so does blsq_dev_free and
  * blsq_memcpy_h2d: memory handed back to, or overwritten through, the library is never read afterwards).
  * After blsq_sync nothing of the caller's J / f is read again.  A second *_factor_dev on the plan drops
- * the first one's verdict (it is still read for the path statistics).  Environment BLSQ_OPTIMISTIC=0:
- * the factor call waits itself and the rule is void. */
+ * the first one's verdict (it is still read for the path statistics).  Option `optimistic` = 0 (environment
+ * BLSQ_OPTIMISTIC=0 at blsq_ctx_create): the factor call waits itself and the rule is void. */
 int blsq_trf_factor_dev(blsq_trf_plan* plan, const double* dJ, const double* df,
                         const double* dx, const double* dlb, const double* dub,
                         double* dscale_io, int scale_mode);

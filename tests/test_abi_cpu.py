@@ -117,3 +117,31 @@ def test_unknown_negative_status_raises_value_error_not_key_error():
     with pytest.raises(ValueError, match="`s` is zero"):
         raise_step_errors(np.array([-1]))
     raise_step_errors(np.array([0, 1, 3]))                   # termination codes: nothing raised
+
+
+def test_option_table_is_documented():
+    """Every switch of the library's option table (blsq_option_info needs no GPU) appears in INTEGRATION.md with its
+    environment variable, and no getenv("BLSQ_...") is left in the sources outside the table and the RCCL loader."""
+    import ctypes as C
+    import glob
+    import re
+    from bounded_lsq import _abi
+    lib = _abi.load()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    n = lib.blsq_option_count()
+    assert n >= 26
+    for i in range(n):
+        nm, ev, dc = C.c_char_p(), C.c_char_p(), C.c_char_p()
+        df = C.c_double()
+        assert lib.blsq_option_info(i, C.byref(nm), C.byref(ev), C.byref(df), C.byref(dc)) == 0
+        assert "`%s`" % nm.value.decode() in doc and "`%s`" % ev.value.decode() in doc, nm.value
+        assert ev.value.decode() == "BLSQ_" + nm.value.decode().upper()
+    assert lib.blsq_option_info(n, None, None, None, None) != 0
+    left = []
+    for path in glob.glob(os.path.join(ROOT, "bounded-lsq_amd", "csrc", "*")):
+        if not path.endswith((".hip", ".h", ".cpp")) or path.endswith("blsq_options.cpp"):
+            continue
+        for m in re.finditer(r'getenv\("(BLSQ_[A-Z0-9_]+)"\)', open(path).read()):
+            if m.group(1) != "BLSQ_RCCL_PATH":
+                left.append((os.path.basename(path), m.group(1)))
+    assert not left, left

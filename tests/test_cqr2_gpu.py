@@ -11,9 +11,9 @@ RTOL = 1e-10
 
 
 @pytest.fixture(autouse=True)
-def _csne_off(monkeypatch):
+def _csne_off(monkeypatch, blsq_opt):
     """These tests pin the CholeskyQR2 tier itself: the CSNE tier in front of it (tests/test_csne_gpu.py) is off."""
-    monkeypatch.setenv("BLSQ_CSNE", "0")
+    blsq_opt("BLSQ_CSNE", "0")
 
 
 def rel(a, b):
@@ -67,7 +67,7 @@ def test_unbounded_ill_conditioned_problems(m, n, kappa, expect):
         assert int(S.n_iter[b]) == So.n_iter and int(S.branch[b]) == So.branch
 
 
-def test_mixed_batch_every_problem_on_its_own_path(monkeypatch):
+def test_mixed_batch_every_problem_on_its_own_path(monkeypatch, blsq_opt):
     """Well-conditioned (normal equations), ill-conditioned (CholeskyQR2), beyond its range (tree) and rank-deficient
     (tree + Jacobi SVD) problems in ONE batch; a problem's bits do not depend on what else the batch holds."""
     from bounded_lsq import _synth
@@ -100,7 +100,7 @@ def test_mixed_batch_every_problem_on_its_own_path(monkeypatch):
     for i, b in enumerate(order):
         assert np.array_equal(S2.step[i], S.step[b])
     # ... and with the tier switched off the tree gives the same step to far below the bar
-    monkeypatch.setenv("BLSQ_CQR2", "0")
+    blsq_opt("BLSQ_CQR2", "0")
     (f3, r3, c3), S3 = run_trf(P, Delta)
     assert (f3, r3, c3) == (3, 5, 0)
     for b in (1, 2, 5):
@@ -178,7 +178,7 @@ def _mixed_unbounded(seed, B, m, n, kappas):
     return P
 
 
-def test_newton_systems_of_rejected_problems_from_the_gram(monkeypatch):
+def test_newton_systems_of_rejected_problems_from_the_gram(monkeypatch, blsq_opt):
     """A problem off the normal-equations path still has its Newton systems H + alpha I factored by Cholesky of
     the modified Gram wherever alpha makes them PROVABLY well conditioned ((Lambda + 1)(h_max + alpha) / alpha
     below the gate, LmState::hmax) — the stacked QR of [R_aug; sqrt(alpha) I] only below that alpha.  Same
@@ -190,7 +190,7 @@ def test_newton_systems_of_rejected_problems_from_the_gram(monkeypatch):
     Delta = np.array([0.5, 0.5, 10.0, 0.2, 3.0, 0.05])
     outs = {}
     for flag in ("1", "0"):
-        monkeypatch.setenv("BLSQ_LM_CHOL_QRPATH", flag)
+        blsq_opt("BLSQ_LM_CHOL_QRPATH", flag)
         outs[flag] = run_trf(P, Delta)
     (s1, S1), (s0, S0) = outs["1"], outs["0"]
     assert s1 == s0 and s1[1] >= 3
@@ -204,13 +204,13 @@ def test_newton_systems_of_rejected_problems_from_the_gram(monkeypatch):
         assert abs(S1.alpha[b] - S0.alpha[b]) <= 1e-9 * abs(S0.alpha[b])
 
 
-def test_unbounded_problems_skip_the_stacked_qr_of_the_augmentation(monkeypatch):
+def test_unbounded_problems_skip_the_stacked_qr_of_the_augmentation(monkeypatch, blsq_opt):
     """E = 0 (no finite bound in any descent direction): [R D | c] IS the triangle of [R D | c; E | 0]
     (trf.py:264-270) — written by a copy instead of a QR; a half-bounded problem in the same batch still
     takes the QR.  Both against the oracle, front end off so that every problem has a triangle."""
     from bounded_lsq import _synth
     from oracle import blsq_oracle as orc
-    monkeypatch.setenv("BLSQ_GRAM", "0")
+    blsq_opt("BLSQ_GRAM", "0")
     B, m, n = 4, 900, 100
     P = _synth.trf_batch(12, B, m, n)
     for b in (0, 2):
@@ -228,7 +228,7 @@ def test_unbounded_problems_skip_the_stacked_qr_of_the_augmentation(monkeypatch)
 
 
 @pytest.mark.parametrize("pinned", [False, True])
-def test_host_pointer_api_sub_batches_and_pinned_buffers(pinned, monkeypatch):
+def test_host_pointer_api_sub_batches_and_pinned_buffers(pinned, monkeypatch, blsq_opt):
     """blsq_trf_factor copies [J f] in sub-batches of problems on a copy stream, the Gram of one sub-batch under
     the copy of the next (by default for page-locked buffers of blsq_host_alloc; BLSQ_H2D_PIPE = 1 / 0 forces it
     on / off, pageable numpy arrays included).  Every variant gives the same bits."""
@@ -239,7 +239,7 @@ def test_host_pointer_api_sub_batches_and_pinned_buffers(pinned, monkeypatch):
     Delta = np.where(np.arange(B) % 2 == 0, 10.0, 0.5)
     outs = []
     for pipe in ("1", "0"):
-        monkeypatch.setenv("BLSQ_H2D_PIPE", pipe)
+        blsq_opt("BLSQ_H2D_PIPE", pipe)
         ctx = _abi.Context(0)
         sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
         J, f = P["J"], P["f"]

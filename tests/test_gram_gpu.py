@@ -305,9 +305,9 @@ def test_dogbox_uses_the_same_front_end(bl):
     assert stats == (0, B)
 
 
-def test_env_switch_disables_the_fast_path(bl, monkeypatch):
+def test_env_switch_disables_the_fast_path(bl, monkeypatch, blsq_opt):
     from bounded_lsq import _synth
-    monkeypatch.setenv("BLSQ_GRAM", "0")
+    blsq_opt("BLSQ_GRAM", "0")
     P = _synth.trf_batch(5, 3, 400, 32)
     stats, _ = _check(bl, P, np.full(3, 0.9))
     assert stats == (0, 0)                              # the front end never ran
@@ -321,7 +321,7 @@ def test_single_tall_problem_row_chunks(bl):
     assert stats == (1, 0)
 
 
-def test_badly_scaled_columns_are_equilibrated(bl, monkeypatch):
+def test_badly_scaled_columns_are_equilibrated(bl, monkeypatch, blsq_opt):
     """Column norms spread over many orders of magnitude: the equilibrated Gram is as well
     conditioned as the normalised columns, so the fast path is taken and is as accurate as the
     Householder tree.  (At a spread of 1e+-6, cond(J) ~ 1e11, the reference's own SVD answer moves
@@ -338,7 +338,7 @@ def test_badly_scaled_columns_are_equilibrated(bl, monkeypatch):
     P["J"] = J0 * 10.0 ** rng.uniform(-6, 6, size=(B, 1, n))
     steps = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("BLSQ_GRAM", mode)
+        blsq_opt("BLSQ_GRAM", mode)
         ctx = _abi.Context(0)
         sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
         ctx.gram_stats(reset=True)
@@ -350,7 +350,7 @@ def test_badly_scaled_columns_are_equilibrated(bl, monkeypatch):
         assert rel(steps["1"][b], steps["0"][b]) < 1e-11
 
 
-def test_tile_groups_do_not_change_a_single_bit(bl, monkeypatch):
+def test_tile_groups_do_not_change_a_single_bit(bl, monkeypatch, blsq_opt):
     """Small batches split the Gram's tiles over several workgroups; every tile still accumulates
     the same k-steps in the same order, so the whole step is bitwise the same for any split."""
     from bounded_lsq import _synth, _abi
@@ -359,7 +359,7 @@ def test_tile_groups_do_not_change_a_single_bit(bl, monkeypatch):
         Delta = np.full(B, 0.7)
         outs = []
         for tg in ("1", "3", "8"):
-            monkeypatch.setenv("BLSQ_GRAM_TILE_GROUPS", tg)
+            blsq_opt("BLSQ_GRAM_TILE_GROUPS", tg)
             ctx = _abi.Context(0)
             sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
             ctx.gram_stats(reset=True)
@@ -370,7 +370,7 @@ def test_tile_groups_do_not_change_a_single_bit(bl, monkeypatch):
         assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
-def test_static_tile_row_kernel_matches_the_generic_one_bit_for_bit(bl, monkeypatch):
+def test_static_tile_row_kernel_matches_the_generic_one_bit_for_bit(bl, monkeypatch, blsq_opt):
     """n = 241 .. 256 (16 column tiles) with one workgroup per row chunk runs gram16_kernel (static
     tile rows per wave, shared operand fragments); every tile still accumulates the same k-steps in
     the same order and the rhs column is summed in the same order as in the generic kernel, so the
@@ -382,8 +382,8 @@ def test_static_tile_row_kernel_matches_the_generic_one_bit_for_bit(bl, monkeypa
         Delta = np.full(B, 0.7)
         outs = []
         for g16, tg in (("1", "1"), ("0", "1"), ("1", "4")):
-            monkeypatch.setenv("BLSQ_GRAM16", g16)
-            monkeypatch.setenv("BLSQ_GRAM_TILE_GROUPS", tg)
+            blsq_opt("BLSQ_GRAM16", g16)
+            blsq_opt("BLSQ_GRAM_TILE_GROUPS", tg)
             ctx = _abi.Context(0)
             sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
             ctx.gram_stats(reset=True)
@@ -416,7 +416,7 @@ def test_every_kernel_dispatch_boundary(bl, n):
 
 
 @pytest.mark.parametrize("n", [6, 16, 48, 64, 79])
-def test_newton_rounds_in_one_launch(bl, monkeypatch, n):
+def test_newton_rounds_in_one_launch(bl, monkeypatch, n, blsq_opt):
     """N <= 80: the Gauss-Newton step, the bracket and every Newton round of a normal-equations-path
     problem run inside ONE launch (lm_rounds_reg_kernel).  Against the round-by-round kernels
     (BLSQ_LM_FUSED = 0): the same iteration counts, alpha and step to rounding — and bit for bit the
@@ -428,7 +428,7 @@ def test_newton_rounds_in_one_launch(bl, monkeypatch, n):
     Delta = np.array([0.5, 0.05, 5.0, 0.2, 0.01, 1.0])
 
     def run(PP, DD, fused):
-        monkeypatch.setenv("BLSQ_LM_FUSED", fused)
+        blsq_opt("BLSQ_LM_FUSED", fused)
         ctx = _abi.Context(0)
         sol = bl.TrfStepSolver(len(DD), m, n, ctx=ctx)
         ctx.gram_stats(reset=True)
@@ -459,7 +459,7 @@ def test_newton_rounds_in_one_launch(bl, monkeypatch, n):
 
 @pytest.mark.parametrize("scale_mode", [0, 1])
 @pytest.mark.parametrize("shape", [(700, 64), (1500, 200)])
-def test_optimistic_verdict_of_the_device_api(bl, monkeypatch, shape, scale_mode):
+def test_optimistic_verdict_of_the_device_api(bl, monkeypatch, shape, scale_mode, blsq_opt):
     """blsq_trf_factor_dev does not wait for the gate's counters: it guesses "everybody stays on the
     normal-equations path, nobody needs the SVD", blsq_trf_step_dev enqueues its kernels on that guess
     and only then reads the verdict — a wrong guess runs the fallback stage and the step once more.
@@ -479,7 +479,7 @@ def test_optimistic_verdict_of_the_device_api(bl, monkeypatch, shape, scale_mode
     for P, expect_fb in ((good, 0), (mixed, 2)):
         outs = []
         for opt in ("1", "0"):
-            monkeypatch.setenv("BLSQ_OPTIMISTIC", opt)
+            blsq_opt("BLSQ_OPTIMISTIC", opt)
             ctx = _abi.Context(0)
             sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
             d = {k: ctx.to_device(P[k]) for k in ("J", "f", "x", "lb", "ub", "scale")}
@@ -567,7 +567,7 @@ def test_a_dropped_verdict_is_still_counted(bl):
     ctx.close()
 
 
-def test_optimistic_verdict_of_the_dogbox_device_api(bl, monkeypatch):
+def test_optimistic_verdict_of_the_dogbox_device_api(bl, monkeypatch, blsq_opt):
     """blsq_dogbox_factor_dev / blsq_dogbox_step_dev: the same optimistic scheme as TRF — right guess,
     wrong guess (a problem that fails the certificate) and the synchronous mode give the same bits."""
     from bounded_lsq import _synth, _abi
@@ -580,7 +580,7 @@ def test_optimistic_verdict_of_the_dogbox_device_api(bl, monkeypatch):
     for P, expect_fb in ((good, 0), (mixed, 1)):
         outs = []
         for opt in ("1", "0"):
-            monkeypatch.setenv("BLSQ_OPTIMISTIC", opt)
+            blsq_opt("BLSQ_OPTIMISTIC", opt)
             ctx = _abi.Context(0)
             sol = bl.DogboxStepSolver(B, m, n, ctx=ctx)
             d = {k: ctx.to_device(P[k]) for k in ("J", "f", "x", "lb", "ub", "scale", "on_bound")}
@@ -601,7 +601,7 @@ def test_optimistic_verdict_of_the_dogbox_device_api(bl, monkeypatch):
 
 
 @pytest.mark.parametrize("solver", ["trf", "dogbox"])
-def test_counter_and_vector_routes_of_the_device_api_give_the_same_bits(bl, monkeypatch, solver):
+def test_counter_and_vector_routes_of_the_device_api_give_the_same_bits(bl, monkeypatch, solver, blsq_opt):
     """Two routes of the device-resident calls that change no arithmetic: the verdict / Newton-round counters reach
     the host through a one-lane kernel and a polled pinned slot (BLSQ_PUBLISH = 0: hipMemcpyAsync + event), and the
     caller's x / lb / ub / scale / on_bound are packed into the state layout by the prep launch (BLSQ_FUSE_PACK = 0:
@@ -627,9 +627,9 @@ def test_counter_and_vector_routes_of_the_device_api_give_the_same_bits(bl, monk
         outs = []
         for publish, fuse, ride in (("1", "1", "1"), ("0", "1", "1"), ("1", "0", "1"), ("0", "0", "1"), ("1", "1", "0"),
                                     ("1", "0", "0")):
-            monkeypatch.setenv("BLSQ_PUBLISH", publish)
-            monkeypatch.setenv("BLSQ_FUSE_PACK", fuse)
-            monkeypatch.setenv("BLSQ_PUBLISH_RIDE", ride)
+            blsq_opt("BLSQ_PUBLISH", publish)
+            blsq_opt("BLSQ_FUSE_PACK", fuse)
+            blsq_opt("BLSQ_PUBLISH_RIDE", ride)
             ctx = _abi.Context(0)
             sol = (bl.TrfStepSolver if solver == "trf" else bl.DogboxStepSolver)(B, m, n, ctx=ctx)
             d = {k: ctx.to_device(P[k]) for k in keys}
@@ -654,7 +654,7 @@ def test_counter_and_vector_routes_of_the_device_api_give_the_same_bits(bl, monk
                 assert np.array_equal(x1, x0)
 
 
-def test_direct_kernel_wave_counts(bl, monkeypatch):
+def test_direct_kernel_wave_counts(bl, monkeypatch, blsq_opt):
     """Narrow problems (at most four column tiles): the direct Gram kernel runs two, four or eight
     waves per workgroup by the row count (about 256 rows per wave; BLSQ_GRAM_DIRECT_NW forces one).
     The wave count fixes the summation order, nothing else: every choice gives g = J^T f to rounding and
@@ -668,7 +668,7 @@ def test_direct_kernel_wave_counts(bl, monkeypatch):
             if nw == "default":
                 monkeypatch.delenv("BLSQ_GRAM_DIRECT_NW", raising=False)
             else:
-                monkeypatch.setenv("BLSQ_GRAM_DIRECT_NW", nw)
+                blsq_opt("BLSQ_GRAM_DIRECT_NW", nw)
             ctx = _abi.Context(0)
             sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
             sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
@@ -743,7 +743,7 @@ def test_round_loop_follows_the_round_count_of_the_last_call(bl):
 
 
 @pytest.mark.parametrize("shape", [(700, 64), (900, 150)])
-def test_second_guess_of_the_trf_device_api(bl, monkeypatch, shape):
+def test_second_guess_of_the_trf_device_api(bl, monkeypatch, shape, blsq_opt):
     """TRF: after a call in which the Cholesky kernel (N <= 80; N > 80: stage 0 of the certificate, which is still
     launched) settled every problem (first certificate bound + the rank gate's column-norm bound), the remaining
     certificate and gate launches of the next call are not enqueued.  Guess holds / fails softly (a column of norm
@@ -767,8 +767,8 @@ def test_second_guess_of_the_trf_device_api(bl, monkeypatch, shape):
     for scale_mode in (0, 1):
         runs = []
         for opt, settle in (("1", "1"), ("0", "1"), ("1", "0")):
-            monkeypatch.setenv("BLSQ_OPTIMISTIC", opt)
-            monkeypatch.setenv("BLSQ_SETTLE0", settle)
+            blsq_opt("BLSQ_OPTIMISTIC", opt)
+            blsq_opt("BLSQ_SETTLE0", settle)
             ctx = _abi.Context(0)
             sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
             dD, dA = ctx.to_device(Delta), ctx.to_device(np.zeros(B))
@@ -790,7 +790,7 @@ def test_second_guess_of_the_trf_device_api(bl, monkeypatch, shape):
                     assert np.array_equal(x1, x0, equal_nan=True), (scale_mode, call)
 
 
-def test_second_guess_of_the_dogbox_device_api(bl, monkeypatch):
+def test_second_guess_of_the_dogbox_device_api(bl, monkeypatch, blsq_opt):
     """N <= 80: once a call has seen EVERY problem settled inside the Cholesky kernel (certified by the
     first bound, Cauchy and Newton steps written there), the next call does not enqueue the certificate /
     gate / solve launches at all and checks the settled counter when it resolves.  A sequence of calls
@@ -811,7 +811,7 @@ def test_second_guess_of_the_dogbox_device_api(bl, monkeypatch):
     Delta = np.full(B, 0.05)
     runs = []
     for opt in ("1", "0"):
-        monkeypatch.setenv("BLSQ_OPTIMISTIC", opt)
+        blsq_opt("BLSQ_OPTIMISTIC", opt)
         ctx = _abi.Context(0)
         sol = bl.DogboxStepSolver(B, m, n, ctx=ctx)
         dD = ctx.to_device(Delta)
@@ -832,7 +832,7 @@ def test_second_guess_of_the_dogbox_device_api(bl, monkeypatch):
             assert np.array_equal(x1, x0, equal_nan=True), call
 
 
-def test_chunk_pairs_summed_in_the_kernel_match_the_reduction_pass(bl, monkeypatch):
+def test_chunk_pairs_summed_in_the_kernel_match_the_reduction_pass(bl, monkeypatch, blsq_opt):
     """Two row chunks (2048 < m <= 4096), 16 column tiles and at least 256 problems: one workgroup
     takes both chunks and adds them in the kernel, (0 + P0) + P1 — what the separate reduction pass
     computes from the two partial Grams (BLSQ_GRAM_PAIR = 0 keeps that pass).  Bit for bit, so a
@@ -845,7 +845,7 @@ def test_chunk_pairs_summed_in_the_kernel_match_the_reduction_pass(bl, monkeypat
         Delta = np.full(B, 0.7)
         outs = []
         for pair in ("1", "0"):
-            monkeypatch.setenv("BLSQ_GRAM_PAIR", pair)
+            blsq_opt("BLSQ_GRAM_PAIR", pair)
             ctx = _abi.Context(0)
             sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
             ctx.gram_stats(reset=True)
@@ -860,7 +860,7 @@ def test_chunk_pairs_summed_in_the_kernel_match_the_reduction_pass(bl, monkeypat
             assert rel(outs[0][1][b], P["J"][b].T @ P["f"][b]) < 1e-13
 
 
-def test_both_cholesky_kernels_agree_bit_for_bit(bl, monkeypatch):
+def test_both_cholesky_kernels_agree_bit_for_bit(bl, monkeypatch, blsq_opt):
     """N > 80: launches of at most 256 problems use the right-looking register kernel (flag-driven schedule;
     BLSQ_CHOL_RL2 = 0: the barrier-synchronous one), larger ones the
     left-looking one (BLSQ_CHOL_RL forces either).  All apply the same operands in the same order —
@@ -873,8 +873,8 @@ def test_both_cholesky_kernels_agree_bit_for_bit(bl, monkeypatch):
         P = _synth.trf_batch(70 + n, B, m, n) if kind == "trf" else _synth.dogbox_batch(70 + n, B, m, n)
         outs = []
         for rl, rl2 in (("0", "1"), ("1", "1"), ("1", "0")):       # left-looking, flag-driven, barrier-synchronous
-            monkeypatch.setenv("BLSQ_CHOL_RL", rl)
-            monkeypatch.setenv("BLSQ_CHOL_RL2", rl2)
+            blsq_opt("BLSQ_CHOL_RL", rl)
+            blsq_opt("BLSQ_CHOL_RL2", rl2)
             ctx = _abi.Context(0)
             got = []
             if kind == "trf":
@@ -895,7 +895,7 @@ def test_both_cholesky_kernels_agree_bit_for_bit(bl, monkeypatch):
             assert np.array_equal(x0, x1) and np.array_equal(x0, x2)
 
 
-def test_k_split_kernel_for_eight_column_tiles(bl, monkeypatch):
+def test_k_split_kernel_for_eight_column_tiles(bl, monkeypatch, blsq_opt):
     """n = 113 .. 128 (8 column tiles) runs gram8_kernel for EVERY batch size: static tile rows per
     wave, the k-steps of a row chunk split between two wave groups whose partial tiles are added in
     a fixed order.  That order differs from the generic kernel's (BLSQ_GRAM8 = 0), so the two agree
@@ -907,8 +907,8 @@ def test_k_split_kernel_for_eight_column_tiles(bl, monkeypatch):
         Delta = np.full(B, 0.7)
 
         def run(idx, g8="1", tg=None):
-            monkeypatch.setenv("BLSQ_GRAM8", g8)
-            if tg: monkeypatch.setenv("BLSQ_GRAM_TILE_GROUPS", tg)
+            blsq_opt("BLSQ_GRAM8", g8)
+            if tg: blsq_opt("BLSQ_GRAM_TILE_GROUPS", tg)
             else: monkeypatch.delenv("BLSQ_GRAM_TILE_GROUPS", raising=False)
             ctx = _abi.Context(0)
             sol = bl.TrfStepSolver(len(idx), m, n, ctx=ctx)
@@ -945,7 +945,7 @@ def test_bounded_problems_are_gated_on_the_augmented_system(bl, rho):
     assert worst < 1e-11
 
 
-def test_stage_zero_of_the_certificate_changes_no_verdict(bl, monkeypatch):
+def test_stage_zero_of_the_certificate_changes_no_verdict(bl, monkeypatch, blsq_opt):
     """Stage 0 (comparison-matrix bound: two triangular solves instead of the explicit inverse) only SETTLES
     well-conditioned problems early; with it switched off (BLSQ_CERT0 = 0) the later stages reach the same
     verdicts, and every step comes out bit for bit the same.  Its bound is a bound: K2 >= the true kappa_2."""
@@ -960,7 +960,7 @@ def test_stage_zero_of_the_certificate_changes_no_verdict(bl, monkeypatch):
     Delta = np.full(B, 0.7)
     outs = []
     for flag in ("1", "0"):
-        monkeypatch.setenv("BLSQ_CERT0", flag)
+        blsq_opt("BLSQ_CERT0", flag)
         ctx = _abi.Context(0)
         sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
         ctx.gram_stats(reset=True)
@@ -978,7 +978,7 @@ def test_stage_zero_of_the_certificate_changes_no_verdict(bl, monkeypatch):
     _certificate_holds(P, k0, s0)
 
 
-def test_flag_driven_cholesky_is_race_free_under_repetition(bl, monkeypatch):
+def test_flag_driven_cholesky_is_race_free_under_repetition(bl, monkeypatch, blsq_opt):
     """The right-looking Cholesky kernel hands tiles between its waves through LDS flags and counters, without
     workgroup barriers.  A missed hand-over would show as different bits: every shape (6 ... 17 tile columns, one
     problem ... more problems than CUs, gathered sub-matrices of dogbox) is factored 25 times and must reproduce
@@ -989,7 +989,7 @@ def test_flag_driven_cholesky_is_race_free_under_repetition(bl, monkeypatch):
         P = _synth.trf_batch(170 + n, B, m, n) if kind == "trf" else _synth.dogbox_batch(170 + n, B, m, n)
         ref = None
         for rep, rl in enumerate(["0"] + ["1"] * 25):
-            monkeypatch.setenv("BLSQ_CHOL_RL", rl)
+            blsq_opt("BLSQ_CHOL_RL", rl)
             ctx = _abi.Context(0)
             if kind == "trf":
                 sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
@@ -1008,7 +1008,7 @@ def test_flag_driven_cholesky_is_race_free_under_repetition(bl, monkeypatch):
                 assert all(np.array_equal(a, b) for a, b in zip(ref, got)), (B, m, n, kind, rep)
 
 
-def test_open_jacobian_systems_go_to_the_third_stage_directly(bl, monkeypatch):
+def test_open_jacobian_systems_go_to_the_third_stage_directly(bl, monkeypatch, blsq_opt):
     """A problem stage 0 cannot settle whose system is J^T J itself (no Coleman-Li block) skips the explicit inverse
     of the norm stage and is decided by the shifted factorisation (GramCholArgs::cert_open; BLSQ_CERT_DIRECT = 0:
     everybody through the norm stage).  Both routes PROVE what they decide, so paths and steps agree wherever both
@@ -1026,7 +1026,7 @@ def test_open_jacobian_systems_go_to_the_third_stage_directly(bl, monkeypatch):
     P["J"][6][:, 7] = P["J"][6][:, 3] * (1 + 1e-9)                          # two columns nearly equal: a tiny pivot
     outs = []
     for flag in ("1", "0"):
-        monkeypatch.setenv("BLSQ_CERT_DIRECT", flag)
+        blsq_opt("BLSQ_CERT_DIRECT", flag)
         ctx = _abi.Context(0)
         sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
         ctx.gram_stats(reset=True)

@@ -39,21 +39,21 @@ TRF_CASES = (load_npz("trf_small.npz") + load_npz("trf_large.npz") +
 
 
 @pytest.fixture(params=["gram_front_end", "qr_tree_only"], autouse=True)
-def fact_path(request, monkeypatch):
+def fact_path(request, monkeypatch, blsq_opt):
     """Every test of this file runs twice: with the normal-equations front end of the
     factorisation (Gram + gated Cholesky; ill-conditioned problems still reach the Householder
     tree through its gate) and with the front end switched off, so the TSQR tree keeps its full
     coverage."""
-    monkeypatch.setenv("BLSQ_GRAM", "1" if request.param == "gram_front_end" else "0")
+    blsq_opt("BLSQ_GRAM", "1" if request.param == "gram_front_end" else "0")
     return request.param
 
 
 @pytest.fixture(params=["svd_free", "svd_only"])
-def tr_path(request, monkeypatch):
+def tr_path(request, monkeypatch, blsq_opt):
     """Both trust-region paths: the SVD-free one (QR of [R; sqrt(alpha) I], taken when the
     full-rank gate passes) and the Jacobi-SVD one forced for every problem."""
-    monkeypatch.setenv("BLSQ_NO_SVDFREE", "1" if request.param == "svd_only" else "0")
-    monkeypatch.setenv("BLSQ_SVDFREE_MIN_N", "0")      # let small fixtures take the SVD-free path too
+    blsq_opt("BLSQ_NO_SVDFREE", "1" if request.param == "svd_only" else "0")
+    blsq_opt("BLSQ_SVDFREE_MIN_N", "0")      # let small fixtures take the SVD-free path too
     return request.param
 
 
@@ -298,15 +298,14 @@ def test_tall_problem_factor_through_the_librarys_own_collective(bl, m, n, fact_
     ctx.close()
 
 
-def test_mixed_rank_batch_takes_both_paths(bl):
+def test_mixed_rank_batch_takes_both_paths(bl, blsq_opt):
     """A batch mixing well-conditioned, rank-deficient and badly conditioned problems:
     the gate must send only the clearly full-rank ones down the SVD-free path, and
     every problem must still match the oracle."""
     from oracle import blsq_oracle as orc
     from bounded_lsq import _synth
-    import os
-    os.environ["BLSQ_SVDFREE_MIN_N"] = "0"
-    os.environ["BLSQ_NO_SVDFREE"] = "0"
+    blsq_opt("BLSQ_SVDFREE_MIN_N", "0")
+    blsq_opt("BLSQ_NO_SVDFREE", "0")
     B, m, n = 6, 120, 12
     P = _synth.trf_batch(31337, B, m, n, unbounded=True)
     P["J"][1, :, 5] = P["J"][1, :, 2]                      # exactly rank deficient
@@ -329,8 +328,6 @@ def test_mixed_rank_batch_takes_both_paths(bl):
         assert int(S.n_iter[b]) == So.n_iter, b
         assert rel(S.step[b], So.step) < RTOL, (b, rel(S.step[b], So.step))
     sol.close()
-    os.environ.pop("BLSQ_SVDFREE_MIN_N", None)
-    os.environ.pop("BLSQ_NO_SVDFREE", None)
 
 
 # ---- size-independent properties at BASELINE.json's full size (4096 x 256) -----------------

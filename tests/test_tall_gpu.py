@@ -64,10 +64,10 @@ def test_config5_row_blocks_of_250000_rows(tall):
 
 
 @pytest.mark.parametrize("gram", ["1", "0"])
-def test_config5_single_rank_collective_route(tall, gram, monkeypatch):
+def test_config5_single_rank_collective_route(tall, gram, monkeypatch, blsq_opt):
     """The same 500 000 rows as ONE rank through blsq_tsqr_factor_dev (real communicator): Gram
     all-reduce route with the front end on, triangle all-gather route with it off."""
-    monkeypatch.setenv("BLSQ_GRAM", gram)
+    blsq_opt("BLSQ_GRAM", gram)
     from bounded_lsq import _abi
     from bounded_lsq._multi import TsqrTrfSolver
     P, ref = tall
