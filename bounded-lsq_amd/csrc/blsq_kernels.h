@@ -260,6 +260,7 @@ struct CsneState {
   int rows_per_wg, nchunk, NE;   // set by the host (csne_geometry: functions of m and of the batch's deepest recording)
 };
 void csne_geometry(int m, int* rows_per_wg, int* nchunk);
+int csne_launch_evals(int NE);            // evaluations the pass launch carries for a recording depth of NE (>= NE)
 bool csne_supported(int m, int n);
 struct LmState;
 struct TrfState;

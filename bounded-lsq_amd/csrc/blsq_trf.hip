@@ -615,7 +615,7 @@ int trf_csne_correct(blsq_trf_plan* p, const double* dDelta, const double* dalph
   blsq_ctx* ctx = p->ctx;
   CsneState& cs = p->cs;
   const int ne_max = std::min(CSNE_MAXE, 1 + std::max(0, p->lm_rounds_done));
-  const int NE = ne_max;
+  const int NE = csne_launch_evals(ne_max);               // (the launch's split over the waves: NEH x G >= ne_max)
   cs.NE = NE;
   const size_t need = (size_t)p->ncsne * cs.nchunk * ((size_t)NE * p->ld + 16);
   if (need > p->cs_part_cap) {                            // (grows geometrically; hipFree waits for the stream)

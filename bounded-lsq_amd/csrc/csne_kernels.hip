@@ -60,21 +60,33 @@ __device__ __forceinline__ constexpr int cs_bitrev4(int i) {
 }
 
 // ---- the pass over J -------------------------------------------------------------------------------
-// grid (row chunks, listed problems) x 256 threads.  Lane l owns columns l + 64 cb; a wave takes four rows per
-// batch: per row and recorded evaluation e the two dot products  u = J_h[r] . p~_e + f_r,  t = J_h[r] . w~_e
-// (J_h = J D: the vectors are pre-multiplied by d), their 64-lane totals by transposed butterflies (wave_sum16),
-// then  y_e += u J[r]  (per lane: its columns) and  b_e += t^2.  J is read exactly once, straight into registers
-// (the next batch is requested before the current one is consumed); no LDS on the way.
-template <int NCB, int NE>
+// grid (row chunks, listed problems) x 256 threads.  Lane l owns columns l + 64 cb.  The rows of a chunk go in batches
+// of four; batch bi belongs to row class bi mod 4, and a problem's sums are DEFINED as
+//     ((S_0 + S_1) + S_2) + S_3,   S_c = the batches of class c in increasing order, rows 0 .. 3 of a batch in order
+// — whatever the launch looks like.  The launch splits the NE recorded evaluations over G groups of waves (G = 1, 2, 4;
+// NEH evaluations each): the four waves are G groups of 4 / G members, a member takes the classes c = j mod (4 / G) —
+// G of them, each in its own accumulators — for its group's evaluations.  So the deeper the batch's recordings the
+// fewer evaluations a wave carries (vectors, accumulators and the butterflies of its totals scale with NEH, not NE: the
+// kernel is VALU-issue-bound, not memory-bound, at NEH = 6), each row is then loaded by G waves (the second to fourth
+// from L1 / L2), and a problem's bits do not depend on the depth its batch forces on the launch.
+// Per row and evaluation e: the two dot products  u = J_h[r] . p~_e + f_r,  t = J_h[r] . w~_e  (J_h = J D: the vectors
+// are pre-multiplied by d), their 64-lane totals by transposed butterflies (wave_sum16), then  y_e += u J[r]  (per lane:
+// its columns) and  b_e += t^2  (uniform: broadcast first, so that its order is the rows' order).  J streams straight
+// into registers (the next batch is requested before the current one is consumed); no LDS on the way.
+template <int NCB, int NEH, int G, int NS>
 __global__ __launch_bounds__(CS_NT, 1) void csne_pass_kernel(CsneState cs, const double* __restrict__ dvec) {
-  constexpr int NV = 2 * NE;                              // totals per row
-  constexpr int NTOT = CS_RB * NV;                        // totals per batch
+  static_assert(NS >= 2, "register slots of the row batches: one consumed, NS - 1 in flight");
+  static_assert(G == 1 || G == 2 || G == 4, "groups of waves");
+  constexpr int MEM = CS_NW / G;                          // members (waves) per group
+  constexpr int NV = 2 * NEH;                             // totals per row and wave
+  constexpr int NTOT = CS_RB * NV;                        // ... per batch
   constexpr int NBF = (NTOT + 15) / 16;                   // butterflies per batch
-  __shared__ double ysh[(CS_NW - 1) * NE * NCB * WAVE];
-  __shared__ double bsh[CS_NW * NBF * 16];
+  constexpr int NE = NEH * G;                             // evaluations the launch carries (the partial sums' stride)
+  extern __shared__ double ysh[];                         // [group][class][NEH][NCB][64] + [group][class][NEH]
   const int li = blockIdx.y, chunk = blockIdx.x;
   const int b = cs.list[li];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = w / MEM, mem = w % MEM;                 // (wave-uniform)
   const int n = cs.n, ld = cs.ld;
   const int r0 = chunk * cs.rows_per_wg;
   const int r1 = (r0 + cs.rows_per_wg < cs.m) ? r0 + cs.rows_per_wg : cs.m;
@@ -83,34 +95,37 @@ __global__ __launch_bounds__(CS_NT, 1) void csne_pass_kernel(CsneState cs, const
   int ne = cs.ne[b];
   if (ne > NE) ne = NE;                                   // (deeper recordings are declined by csne_fix_kernel)
   const int vidx = wave_sum16_index(lane);                // the total this lane receives from a butterfly
+  const int e0 = grp * NEH;                               // this wave's evaluations: e0 .. e0 + NEH - 1
 
   // the recorded vectors of the lane's columns, pre-multiplied by d (J_h = J D); zero beyond n and beyond the
   // problem's recording: columns n .. 64 NCB of J are loaded clamped and count for nothing
-  double V[NE][2][NCB];
+  double V[NEH][2][NCB];
 #pragma unroll
-  for (int e = 0; e < NE; ++e)
+  for (int e = 0; e < NEH; ++e)
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
         const int col = lane + 64 * cb;
         double v = 0.0;
-        if (e < ne && col < n)
-          v = dvec[(long)b * ld + col] * cs.rvec[(((long)b * CSNE_MAXE + e) * 3 + c) * ld + col];
+        if (e0 + e < ne && col < n)
+          v = dvec[(long)b * ld + col] * cs.rvec[(((long)b * CSNE_MAXE + e0 + e) * 3 + c) * ld + col];
         V[e][c][cb] = v;
       }
-  double y[NE][NCB];
+  double y[G][NEH][NCB], accB[G][NEH];                    // per class of this wave
 #pragma unroll
-  for (int e = 0; e < NE; ++e)
+  for (int ci = 0; ci < G; ++ci)
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) y[e][cb] = 0.0;
-  double accB[NBF];
+    for (int e = 0; e < NEH; ++e) {
+      accB[ci][e] = 0.0;
 #pragma unroll
-  for (int g = 0; g < NBF; ++g) accB[g] = 0.0;
+      for (int cb = 0; cb < NCB; ++cb) y[ci][e][cb] = 0.0;
+    }
 
   const int nbatch = (r1 - r0 + CS_RB - 1) / CS_RB;
-  double jr[2][CS_RB][NCB], fr[2][NBF];
-  auto issue = [&](int bi, int slot) {
+  double jr[NS][CS_RB][NCB], fr[NS][NBF];
+  auto issue = [&](int bi, auto slotc) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slotc)::value;
     const int rb = r0 + bi * CS_RB;
 #pragma unroll
     for (int r = 0; r < CS_RB; ++r) {
@@ -128,7 +143,9 @@ __global__ __launch_bounds__(CS_NT, 1) void csne_pass_kernel(CsneState cs, const
       fr[slot][g] = Fb[row < r1 ? row : r1 - 1];
     }
   };
-  auto consume = [&](int bi, int slot) {
+  auto consume = [&](int bi, auto slotc, auto cic) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slotc)::value;
+    constexpr int ci = decltype(cic)::value;
     const int rb = r0 + bi * CS_RB;
     if (rb + CS_RB > r1) {                                 // (uniform; the last batch of a chunk only) rows beyond it: zero
 #pragma unroll
@@ -141,104 +158,141 @@ __global__ __launch_bounds__(CS_NT, 1) void csne_pass_kernel(CsneState cs, const
         if (rb + (16 * g + vidx) / NV >= r1) fr[slot][g] = 0.0;
     }
     // one butterfly's sixteen totals at a time: their dot products, the butterfly, what the totals feed
-#pragma unroll
-    for (int g = 0; g < NBF; ++g) {
+    // (compile-time recursion instead of unrolled loops: every register-array index must be a constant)
+    static_for<0, NBF>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(gc)::value;
       double v[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int idx = 16 * g + i;
+      static_for<0, 16>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int idx = 16 * g + i;
         double acc = 0.0;
-        if (idx < NTOT) {
-          const int r = idx / NV, e = (idx % NV) / 2, c = idx % 2;
+        if constexpr (idx < NTOT) {
+          constexpr int r = idx / NV, e = (idx % NV) / 2, c = idx % 2;
 #pragma unroll
           for (int cb = 0; cb < NCB; ++cb) acc = fma(jr[slot][r][cb], V[e][c][cb], acc);
         }
         v[i] = acc;
-      }
+      });
       wave_sum16(v);
       const double tot = v[0];
       const double uu = tot + fr[slot][g];                // (meaningful on the lanes of the u totals: bit 3 clear)
-      const double tt = dpp_mov<0x108>(tot);              // row_shl:8 — the t total of the same (row, evaluation)
-      accB[g] = fma(tt, tt, accB[g]);                     // (read from the lanes with bit 3 clear only)
-#pragma unroll
-      for (int i = 0; i < 16; i += 2) {                   // the u totals of this butterfly: broadcast and axpy
-        const int idx = 16 * g + i;
-        if (idx < NTOT) {
-          const int r = idx / NV, e = (idx % NV) / 2;
+      static_for<0, 8>([&](auto hc) __attribute__((always_inline)) {   // the (row, evaluation) pairs of this butterfly, in row order
+        constexpr int i = 2 * decltype(hc)::value;
+        constexpr int idx = 16 * g + i;
+        if constexpr (idx < NTOT) {
+          constexpr int r = idx / NV, e = (idx % NV) / 2;
           const double us = read_lane(uu, cs_bitrev4(i));
+          const double ts = read_lane(tot, cs_bitrev4(i + 1));
+          accB[ci][e] = fma(ts, ts, accB[ci][e]);
 #pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) y[e][cb] = fma(us, jr[slot][r][cb], y[e][cb]);
+          for (int cb = 0; cb < NCB; ++cb) y[ci][e][cb] = fma(us, jr[slot][r][cb], y[ci][e][cb]);
         }
-      }
-    }
+      });
+    });
   };
-  // wave w takes batches w, w + 4, ...; one batch in flight behind the one being consumed
-  int bi = w;
-  if (bi < nbatch) issue(bi, 0);
-  int slot = 0;
-  for (; bi < nbatch; bi += CS_NW) {
-    const int nxt = bi + CS_NW;
-    if (slot == 0) {
-      if (nxt < nbatch) issue(nxt, 1);
-      consume(bi, 0);
-    } else {
-      if (nxt < nbatch) issue(nxt, 0);
-      consume(bi, 1);
+  // member `mem` takes batches mem, mem + MEM, ...: batch mem + MEM k is of class mem + MEM (k mod G), its local class
+  // k mod G.  NS G batches per trip (every register slot and every local class at a compile-time index); NS - 1
+  // batches in flight behind the one being consumed — the bytes a CU keeps in flight are what bounds this kernel.
+  {
+    int k = 0;
+    auto bat = [&](int kk) { return mem + MEM * kk; };
+    static_for<0, NS - 1>([&](auto qc) __attribute__((always_inline)) {
+      constexpr int q = decltype(qc)::value;
+      if (bat(q) < nbatch) issue(bat(q), std::integral_constant<int, q>{});
+    });
+    for (; bat(k) < nbatch; k += NS * G) {
+      static_for<0, NS * G>([&](auto qc) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value;
+        const int bi = bat(k + q);
+        if (bi < nbatch) {                                 // (uniform)
+          if (bat(k + q + NS - 1) < nbatch) issue(bat(k + q + NS - 1), std::integral_constant<int, ((q + NS - 1) % NS)>{});
+          consume(bi, std::integral_constant<int, (q % NS)>{}, std::integral_constant<int, q % G>{});
+        }
+      });
     }
-    slot ^= 1;
   }
-  // the four waves' partial sums, added in wave order
-  if (w > 0) {
+  // every wave's class sums to LDS; the problem's sums in class order
+  double* bsh = ysh + (size_t)G * 4 * NEH * NCB * WAVE;
 #pragma unroll
-    for (int e = 0; e < NE; ++e)
+  for (int ci = 0; ci < G; ++ci) {
+    const int cls = mem + MEM * ci;
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) ysh[(((w - 1) * NE + e) * NCB + cb) * WAVE + lane] = y[e][cb];
-  }
-  if (lane < 16) {
+    for (int e = 0; e < NEH; ++e) {
 #pragma unroll
-    for (int g = 0; g < NBF; ++g) bsh[(w * NBF + g) * 16 + lane] = accB[g];
+      for (int cb = 0; cb < NCB; ++cb) ysh[((((size_t)grp * 4 + cls) * NEH + e) * NCB + cb) * WAVE + lane] = y[ci][e][cb];
+      if (lane == 0) bsh[((size_t)grp * 4 + cls) * NEH + e] = accB[ci][e];
+    }
   }
   __syncthreads();
   double* out = cs.part + ((long)li * cs.nchunk + chunk) * csne_part_stride(NE, ld);
-  if (w == 0) {
-#pragma unroll
-    for (int e = 0; e < NE; ++e)
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        double t = y[e][cb];
-#pragma unroll
-        for (int q = 0; q < CS_NW - 1; ++q) t += ysh[((q * NE + e) * NCB + cb) * WAVE + lane];
-        const int col = lane + 64 * cb;
-        if (col < n) out[(long)e * ld + col] = t;
-      }
+  for (int idx = tid; idx < NE * NCB * WAVE; idx += CS_NT) {
+    const int l = idx % WAVE, cb = (idx / WAVE) % NCB, eg = idx / (WAVE * NCB);
+    const int g = eg / NEH, e = eg % NEH;
+    const double* src = ysh + ((((size_t)g * 4) * NEH + e) * NCB + cb) * WAVE + l;
+    const size_t cs_ = (size_t)NEH * NCB * WAVE;           // class stride
+    const double t = ((src[0] + src[cs_]) + src[2 * cs_]) + src[3 * cs_];
+    const int col = l + 64 * cb;
+    if (col < n) out[(long)eg * ld + col] = t;
   }
-  if (tid < NE) {                                         // b_e: the lanes of its t^2 sums, in a fixed order
-    double t = 0.0;
-    for (int q = 0; q < CS_NW; ++q)
-      for (int g = 0; g < NBF; ++g)
-        for (int l = 0; l < 8; ++l) {                     // lanes 0 .. 7 of a wave (bit 3 clear: the u totals' lanes)
-          const int idx = 16 * g + cs_bitrev4(l);
-          if (idx < NTOT && (idx % NV) / 2 == tid) t += bsh[(q * NBF + g) * 16 + l];
-        }
-    out[(long)NE * ld + tid] = t;
+  if (tid < NE) {
+    const int g = tid / NEH, e = tid % NEH;
+    const double* src = bsh + ((size_t)g * 4) * NEH + e;
+    out[(long)NE * ld + tid] = ((src[0] + src[NEH]) + src[2 * NEH]) + src[3 * NEH];
   }
 }
 
+// the split of a launch that carries NE evaluations: (NEH, G) with NEH G >= NE.  Measured (512 problems of 4096 x 256,
+// six evaluations): one group 1.51 ms, two groups of three evaluations 1.66 ms — the kernel is bound by the bytes a CU
+// keeps in flight (four waves x one batch of 8 KB: what the loaded latency lets through), and a row requested by two
+// waves halves the UNIQUE bytes in flight; the split stays in the kernel (G > 1 compiles and is tested through
+// BLSQ_CS_GROUPS builds) but the launch takes G = 1.
+#ifndef BLSQ_CS_GROUPS
+#define BLSQ_CS_GROUPS 1
+#endif
+static void csne_split(int NE, int* neh, int* g) {
+  if (BLSQ_CS_GROUPS == 1 || NE <= 3) { *neh = NE < 1 ? 1 : NE; *g = 1; }
+  else if (NE == 4) { *neh = 2; *g = 2; }
+  else if (NE <= 6) { *neh = 3; *g = 2; }
+  else { *neh = 2; *g = 4; }
+}
+int csne_launch_evals(int NE) { int a, b; csne_split(NE, &a, &b); return a * b; }
+
+#ifndef BLSQ_CS_SLOTS_DEEP
+#define BLSQ_CS_SLOTS_DEEP 4           // evaluations up to which THREE register slots (two batches in flight) fit the registers
+#endif
+template <int NCB, int NEH, int G>
+static hipError_t csne_pass_launch1(const CsneState& cs, const double* dvec, int count, hipStream_t s) {
+  constexpr int NS = (NEH <= BLSQ_CS_SLOTS_DEEP) ? 3 : 2;
+  const size_t lds = sizeof(double) * ((size_t)G * 4 * NEH * NCB * WAVE + (size_t)G * 4 * NEH);
+  static std::atomic<size_t> granted[64];
+  hipError_t ge = gram_grant_lds(csne_pass_kernel<NCB, NEH, G, NS>, lds, granted);
+  if (ge != hipSuccess) return ge;
+  hipLaunchKernelGGL((csne_pass_kernel<NCB, NEH, G, NS>), dim3(cs.nchunk, count), dim3(CS_NT), lds, s, cs, dvec);
+  return hipGetLastError();
+}
 template <int NCB>
 static hipError_t csne_pass_launch(const CsneState& cs, const double* dvec, int count, hipStream_t s) {
-  const dim3 grid(cs.nchunk, count), block(CS_NT);
-  switch (cs.NE) {
-    case 1: hipLaunchKernelGGL((csne_pass_kernel<NCB, 1>), grid, block, 0, s, cs, dvec); break;
-    case 2: hipLaunchKernelGGL((csne_pass_kernel<NCB, 2>), grid, block, 0, s, cs, dvec); break;
-    case 3: hipLaunchKernelGGL((csne_pass_kernel<NCB, 3>), grid, block, 0, s, cs, dvec); break;
-    case 4: hipLaunchKernelGGL((csne_pass_kernel<NCB, 4>), grid, block, 0, s, cs, dvec); break;
-    case 5: hipLaunchKernelGGL((csne_pass_kernel<NCB, 5>), grid, block, 0, s, cs, dvec); break;
-    case 6: hipLaunchKernelGGL((csne_pass_kernel<NCB, 6>), grid, block, 0, s, cs, dvec); break;
-    case 7: hipLaunchKernelGGL((csne_pass_kernel<NCB, 7>), grid, block, 0, s, cs, dvec); break;
-    case 8: hipLaunchKernelGGL((csne_pass_kernel<NCB, 8>), grid, block, 0, s, cs, dvec); break;
-    default: return hipErrorInvalidValue;
+  int neh = 1, g = 1;
+  csne_split(cs.NE, &neh, &g);
+  if (neh * g != cs.NE) return hipErrorInvalidValue;       // (the host sizes the partial sums with csne_launch_evals)
+  if (g == 1) {
+    switch (neh) {
+      case 1: return csne_pass_launch1<NCB, 1, 1>(cs, dvec, count, s);
+      case 2: return csne_pass_launch1<NCB, 2, 1>(cs, dvec, count, s);
+      case 3: return csne_pass_launch1<NCB, 3, 1>(cs, dvec, count, s);
+      case 4: return csne_pass_launch1<NCB, 4, 1>(cs, dvec, count, s);
+      case 5: return csne_pass_launch1<NCB, 5, 1>(cs, dvec, count, s);
+      case 6: return csne_pass_launch1<NCB, 6, 1>(cs, dvec, count, s);
+      case 7: return csne_pass_launch1<NCB, 7, 1>(cs, dvec, count, s);
+      case 8: return csne_pass_launch1<NCB, 8, 1>(cs, dvec, count, s);
+    }
   }
-  return hipGetLastError();
+#if BLSQ_CS_GROUPS != 1
+  if (g == 2 && neh == 2) return csne_pass_launch1<NCB, 2, 2>(cs, dvec, count, s);
+  if (g == 2 && neh == 3) return csne_pass_launch1<NCB, 3, 2>(cs, dvec, count, s);
+  if (g == 4 && neh == 2) return csne_pass_launch1<NCB, 2, 4>(cs, dvec, count, s);
+#endif
+  return hipErrorInvalidValue;
 }
 hipError_t launch_csne_pass(const CsneState& cs, const double* dvec, int count, hipStream_t s) {
   if (count <= 0) return hipSuccess;
