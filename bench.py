@@ -57,6 +57,9 @@ CONFIGS = {
                label="C3: dogbox dogleg step-solve, m=512 n=64"),
     "c4": dict(kind="trf", m=512, n=64, batch=1024,
                label="C4 (per-GPU share of 8192): TRF exact step-solve, m=512 n=64"),
+    # (the headline shape through dogbox: a side leg only — `certificate_rejected_dogbox`)
+    "c2-dogbox": dict(kind="dogbox", m=4096, n=256, batch=512,
+                      label="C2 shape through dogbox: dogleg step-solve, m=4096 n=256"),
     "c5": dict(kind="tsqr", m=250_000, n=128, batch=1,
                label="C5: one tall TRF problem split by rows, 250000 x 128 per rank"),
 }
@@ -281,7 +284,7 @@ def conditioning_leg(key, mut, ctx, name, batch, steps, check):
             "parity": bm.parity(min(16, B)) if check > 0 else None,
             "kernels_ms_per_step": {k: round(v, 4) for k, v in profile_table(bm).items() if v > 0},
             "note": ("kappa(J) = 3e3 for every problem, no bounds: all of them beyond the gate"
-                     if key == "certificate_rejected" else
+                     if key.startswith("certificate_rejected") else
                      "kappa(J) log-uniform over [1, 1e4]; each problem on the path its certificate allows. "
                      + ("Bounds as in the headline workload: the Coleman-Li block E^2 of the augmented "
                         "system [J D; E] (trf.py:264-270) keeps the SOLVED system well conditioned."
@@ -325,6 +328,10 @@ class Bench:
             self.Delta = np.array([0.5])
         elif kind == "dogbox":
             self.P = _synth.dogbox_batch(20_000 + rank * B, B, m, n)
+            if mutate is not None:
+                mutate(self.P)
+                if not np.isfinite(self.P["lb"]).any() and not np.isfinite(self.P["ub"]).any():
+                    self.P["on_bound"][:] = 0                   # (no bounds: nothing to sit on)
             self.sol = DogboxStepSolver(B, m, n, ctx=ctx)
         else:
             self.P = _synth.trf_batch(10_000 + rank * B, B, m, n)   # each rank its own problems
@@ -577,7 +584,7 @@ def with_timeout(fn, seconds, what):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="c2", choices=sorted(k for k in CONFIGS if k != "c2-dogbox"))
     ap.add_argument("--steps", type=int, default=None,
                     help="timed steps (default: enough for a timed region of about a second)")
     ap.add_argument("--warmup", type=int, default=None)
@@ -755,6 +762,9 @@ def main():
             for key, mut in (("mixed_conditioning", mut_mixed), ("mixed_conditioning_unbounded", mut_mixed_unbounded),
                              ("certificate_rejected", mut_all_rejected)):
                 extras[key] = conditioning_leg(key, mut, ctx, name, args.batch, steps_requested, args.check)
+            # ... and the all-rejected batch through dogbox (its Newton step corrected at factor time: CSNE)
+            extras["certificate_rejected_dogbox"] = conditioning_leg("certificate_rejected_dogbox", mut_all_rejected, ctx,
+                                                                     "c2-dogbox", args.batch, steps_requested, args.check)
             # The headline's inputs repeat: what the optimistic device API guesses from the last call always holds.
             # Here two input sets ALTERNATE on one plan — the headline batch and the unbounded mixed-conditioning one —
             # so the guess "every problem on the fast path" fails every other call (repair + the step once more).
@@ -928,8 +938,8 @@ def main():
                 digest[k] = [round(v["value"], 1), round(v["ms_per_step"], 4), round(v["roofline"]["frac"], 3)]
             else:
                 digest[k] = v
-        for k in ("householder_only", "certificate_rejected", "mixed_conditioning", "mixed_conditioning_unbounded",
-                  "alternating_conditioning", "h2d_inclusive"):
+        for k in ("householder_only", "certificate_rejected", "certificate_rejected_dogbox", "mixed_conditioning",
+                  "mixed_conditioning_unbounded", "alternating_conditioning", "h2d_inclusive"):
             if k in extras:
                 digest[k] = [round(extras[k]["value"], 1), round(extras[k]["ms_per_step"], 4), None]
         if "c5_tsqr" in extras and isinstance(extras["c5_tsqr"], dict) and "value" in extras["c5_tsqr"]:

@@ -30,6 +30,26 @@ int dog_alloc_state(blsq_dogbox_plan* p) {
   ALLOC(p->gate_ints, sizeof(int) * 3 * (size_t)B);
   ALLOC(p->colinfo, sizeof(double) * 2 * (size_t)B);
   p->svdfree_enable = ctx->opt.i(OPT_NO_SVDFREE) == 1 ? 0 : 1;
+  p->csne_on = p->tree.gram && csne_supported(p->m, p->n) && ctx->opt.on(OPT_CSNE) && p->svdfree_enable;
+  if (p->csne_on) {
+    ALLOC(p->cs_ints, sizeof(int) * (5 * (size_t)B + 8));
+    ALLOC(p->cs_pmin, sizeof(double) * (size_t)B);
+    ALLOC(p->cs_eta, sizeof(double) * (size_t)B);
+    ALLOC(p->cs_k2, sizeof(double) * (size_t)B);
+    ALLOC(p->cs_alpha, sizeof(double) * (size_t)B * CSNE_MAXE);
+    HIPCHK(ctx, hipMemsetAsync(p->cs_ints.p, 0, p->cs_ints.bytes, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(p->cs_pmin.p, 0, p->cs_pmin.bytes, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(p->cs_eta.p, 0, p->cs_eta.bytes, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(p->cs_k2.p, 0, p->cs_k2.bytes, ctx->stream));
+    CsneState& cs = p->cs;
+    cs.B = B; cs.m = p->m; cs.n = p->n; cs.ld = ld;
+    int* ii = p->cs_ints.as<int>();
+    cs.flag = ii; cs.list = ii + B; cs.fail_list = ii + 2 * (size_t)B; cs.ne = ii + 3 * (size_t)B;
+    cs.counts = ii + 5 * (size_t)B;
+    cs.ralpha = p->cs_alpha.as<double>(); cs.eta = p->cs_eta.as<double>();
+    csne_geometry(p->m, &cs.rows_per_wg, &cs.nchunk);
+    cs.NE = 1;
+  }
   HIPCHK(ctx, hipMemsetAsync(p->gate_ints.p, 0, p->gate_ints.bytes, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(p->S.p, 0, p->S.bytes, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(p->X.p, 0, p->X.bytes, ctx->stream));
@@ -45,6 +65,7 @@ int dog_alloc_state(blsq_dogbox_plan* p) {
   st.free_idx = p->ivecs.as<int>(); st.ncols = p->ivecs.as<int>() + vs;
   st.srange = p->scal2.as<double>(); st.g_norm = p->scal2.as<double>() + 2 * (size_t)B;
   st.active = p->active.as<unsigned char>();
+  if (p->csne_on) { st.csne = p->cs.flag; st.csne_k2 = p->cs_k2.as<double>(); }
   p->out.step = p->o_vec.as<double>(); p->out.x_new = p->o_vec.as<double>() + vs;
   p->out.on_bound_new = p->o_onb.as<long long>();
   p->out.scal = p->o_scal.as<double>(); p->out.info = p->o_info.as<int>();
@@ -81,7 +102,7 @@ int dog_put(blsq_dogbox_plan* p, const double* x, const double* lb, const double
 }
 
 // the free-column QR (Householder-path problems), rank gate + Newton step, SVD for the rest
-int dog_finish(blsq_dogbox_plan* p, const int* path, bool any_qr, bool any_gram) {
+int dog_finish(blsq_dogbox_plan* p, const int* path, bool any_qr, bool any_gram, const int* done = nullptr) {
   blsq_ctx* ctx = p->ctx;
   hipError_t e;
   if (any_qr) {
@@ -101,8 +122,9 @@ int dog_finish(blsq_dogbox_plan* p, const int* path, bool any_qr, bool any_gram)
   p->st.fast = gfast;
   if (!p->gate_done) {
     ctx->begin(K_LM_GATE);
+    // (done: problems whose steps stand already — the CSNE tier's corrected ones when the finish runs a second time)
     e = launch_dog_gate_solve(p->st, gfast, gmask, p->svdfree_enable, path,
-                              (path && any_gram) ? p->colinfo.as<double>() : nullptr, nullptr, nullptr, ctx->stream);
+                              (path && any_gram) ? p->colinfo.as<double>() : nullptr, nullptr, done, ctx->stream);
     ctx->end();
     if (e != hipSuccess) return ctx->fail(e, "launch_dog_gate_solve");
     p->njac = -1;
@@ -152,6 +174,7 @@ GramCholArgs dog_chol_args(blsq_dogbox_plan* p, const int* mask) {
   c.k2_max = t.k2_max; c.pivot_floor = 1.0 / t.k2_max;
   c.cert_flag = t.gram_cflag.as<int>(); c.cert_tau = t.gram_ctau.as<double>();
   c.colinfo = p->colinfo.as<double>();
+  if (p->csne_on) c.pmin_out = p->cs_pmin.as<double>();
   if (p->ld <= 80) {                        // (the register-resident kernel also finishes the gate / Newton / Cauchy work)
     int* gf_ = p->gate_ints.as<int>();
     c.dog.g = p->st.g; c.dog.newton = p->st.newton; c.dog.cauchy = p->st.cauchy;
@@ -179,6 +202,129 @@ int dog_gate_tail(blsq_dogbox_plan* p, const GramCholArgs& c) {
                             p->colinfo.as<double>(), t.fb_count() + 1, c.dog.g ? c.dog.done : nullptr, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_dog_gate_solve");
+  return 0;
+}
+
+// CSNE tier, dogbox (csne_kernels.hip).  Of the nfb problems the certificate has just rejected
+// (tree.fb_list()) those whose free-block factor qualifies keep it as a preconditioner; *ntree = the others.
+int dog_csne_select(blsq_dogbox_plan* p, int nfb, int* ntree, bool masked) {
+  blsq_ctx* ctx = p->ctx;
+  QrTree& t = p->tree;
+  const int B = p->B;
+  *ntree = nfb;
+  if (!p->csne_on) return 0;
+  hipError_t e = hipSuccess;
+  if (!p->cs_vec.p) {                                     // first use: the recording (one evaluation: the Newton step)
+    e = p->cs_vec.alloc(sizeof(double) * (size_t)B * CSNE_MAXE * 3 * p->ld);
+    if (e != hipSuccess) { (void)hipGetLastError(); p->csne_on = false; p->st.csne = nullptr; return 0; }
+    p->cs.rvec = p->cs_vec.as<double>();
+  }
+  int* sel = p->cs_ints.as<int>() + 4 * (size_t)B;
+  int* scratch = p->cs.counts + 4;
+  HIPCHK(ctx, hipMemsetAsync(sel, 0, sizeof(int) * (size_t)B, ctx->stream));
+  GramCholArgs cy = dog_chol_args(p, t.fb_mask());        // (mask: the rejected problems only; same gather)
+  cy.fb_mask = sel; cy.fail_count = scratch; cy.fail_list = nullptr; cy.path_out = nullptr;
+  cy.cert_done = nullptr; cy.cert_flag = nullptr; cy.cert_tau = nullptr; cy.cert_open = nullptr;
+  cy.unsettled = nullptr; cy.dog = GramCholArgs::DogFinish{};
+  cy.colinfo = nullptr; cy.pmin_out = nullptr;
+  cy.k2_max = CSNE_K2_MAX; cy.k2_out = p->cs_k2.as<double>();
+  ctx->begin(K_GRAM_GATE);
+  e = launch_gram_gate(cy, B, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_gram_gate(csne bound, dogbox)");
+  int* gfast = p->gate_ints.as<int>();
+  e = launch_csne_select_dog(p->cs, p->m, p->st.ncols, gfast, gfast + B, nfb, t.fb_list(), t.fb_mask(), t.fb_count(),
+                             t.path_rw(), sel, p->cs_k2.as<double>(), p->cs_pmin.as<double>(), p->colinfo.as<double>(),
+                             ctx->stream);
+  if (e != hipSuccess) return ctx->fail(e, "launch_csne_select_dog");
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 8, t.fb_count(), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 9, p->cs.counts, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  *ntree = ctx->pinned[8];
+  p->ncsne = ctx->pinned[9];
+  ctx->csne_routed += (unsigned long long)(nfb - *ntree);
+  if (!masked) t.any_qr = *ntree > 0;
+  t.any_gram = t.any_gram || *ntree < nfb;
+  return 0;
+}
+
+// ... and the correction itself, at FACTOR time (the Newton step of dogbox.py:197 does not depend on Delta): the cheap
+// steps of the problems on the tier scattered to full length, ONE pass over J, one corrected solve each.  Problems
+// whose measured correction is too large leave the tier: *nfail of them, listed in tree.fb_list() / fb_mask().
+int dog_csne_correct(blsq_dogbox_plan* p, const double* dJ, const double* df, int ldJ, int* nfail) {
+  blsq_ctx* ctx = p->ctx;
+  CsneState& cs = p->cs;
+  QrTree& t = p->tree;
+  *nfail = 0;
+  if (p->ncsne <= 0) return 0;
+  cs.J = dJ; cs.strideJ = (long)p->m * ldJ; cs.ldJ = ldJ; cs.F = df; cs.strideF = p->m;
+  cs.NE = 1;
+  const size_t need = (size_t)p->ncsne * cs.nchunk * ((size_t)p->ld + 16);
+  if (need > p->cs_part_cap) {
+    p->cs_part.release();
+    const size_t cap = std::max(need, 2 * p->cs_part_cap);
+    hipError_t ae = p->cs_part.alloc(sizeof(double) * cap);
+    if (ae != hipSuccess) { p->cs_part_cap = 0; return ctx->fail(ae, "hipMalloc(CSNE partial sums)"); }
+    p->cs_part_cap = cap;
+    cs.part = p->cs_part.as<double>();
+  }
+  HIPCHK(ctx, hipMemsetAsync(cs.counts + 1, 0, sizeof(int), ctx->stream));
+  ctx->begin(K_CSNE_PASS);
+  hipError_t e = launch_dog_csne_scatter(cs, p->st, p->ncsne, ctx->stream);
+  if (e == hipSuccess) e = launch_csne_pass(cs, nullptr, p->ncsne, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_csne_pass(dogbox)");
+  ctx->begin(K_CSNE_FIX);
+  e = launch_dog_csne_fix(cs, p->st, p->ncsne, ctx->stream);
+  ctx->end();
+  if (e != hipSuccess) return ctx->fail(e, "launch_dog_csne_fix");
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 12, cs.counts + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  *nfail = ctx->pinned[12];
+  ctx->csne_steps += (unsigned long long)(p->ncsne - *nfail);
+  ctx->csne_declined += (unsigned long long)*nfail;
+  if (*nfail > 0) {
+    e = launch_csne_reroute(cs, *nfail, t.fb_list(), t.fb_mask(), t.path_rw(), ctx->stream);
+    if (e != hipSuccess) return ctx->fail(e, "launch_csne_reroute(dogbox)");
+    p->ncsne -= *nfail;
+    t.any_qr = true;
+  }
+  return 0;
+}
+
+// what follows the certificate's verdict "nfb problems leave the normal-equations path": the tier's selection, the
+// next tiers' factorisation of the rest (CholeskyQR2 / tree) + their prep from the triangle, the plan's finish, the
+// tier's correction — and once more for the problems the correction declined
+int dog_repair(blsq_dogbox_plan* p, const double* dJ, const double* df, int ldJ, int scale_mode, int nfb, bool masked) {
+  blsq_ctx* ctx = p->ctx;
+  QrTree& t = p->tree;
+  int rc;
+  if (nfb > 0) {
+    int ntree = nfb;
+    if ((rc = dog_csne_select(p, nfb, &ntree, masked))) return rc;
+    nfb = ntree;
+  } else if (masked && p->ncsne > 0) {                     // (refreshed problems have left the tier: the list from the flags)
+    hipError_t e = launch_csne_reroute(p->cs, -1, nullptr, nullptr, nullptr, ctx->stream);
+    if (e != hipSuccess) return ctx->fail(e, "launch_csne_reroute(relist)");
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pinned + 9, p->cs.counts, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    p->ncsne = ctx->pinned[9];
+  }
+  for (int pass = 0; pass < 2; ++pass) {
+    if (nfb > 0) {
+      if ((rc = t.run_fallback(ctx, dJ, df, ldJ, nfb))) return rc;
+      ctx->begin(K_PREP);
+      hipError_t e = launch_dog_prep(p->st, scale_mode, 0, t.fb_mask(), 1, ctx->stream);
+      ctx->end();
+      if (e != hipSuccess) return ctx->fail(e, "launch_dog_prep(redo)");
+    }
+    if ((rc = dog_finish(p, t.path_rw(), t.any_qr, t.any_gram, pass > 0 && p->csne_on ? p->cs.flag : nullptr))) return rc;
+    int nfail = 0;
+    if (pass == 0 && (rc = dog_csne_correct(p, dJ, df, ldJ, &nfail))) return rc;
+    if (nfail == 0) break;
+    nfb = nfail;                                           // (declined: the next tier, then the finish once more)
+    p->gate_done = false; p->njac = -1;
+  }
   return 0;
 }
 
@@ -232,34 +378,16 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
     if (!mask) { p->guess_ok = (nfb == 0 && p->njac == 0); p->guess_settled = (c.unsettled && ctx->pinned[3] == 0); }
   }
   t.note_paths(ctx, nfb, mask != nullptr);
+  if (!mask) p->ncsne = 0;                                // (the prep launch cleared every flag; dog_csne_select sets them anew)
   if (skip_tail) { p->gate_done = false; return 0; }
-  if (nfb > 0) {
-    if ((rc = t.run_fallback(ctx, dJ, df, ldJ, nfb))) return rc;
-    ctx->begin(K_PREP);
-    e = launch_dog_prep(p->st, scale_mode, 0, t.fb_mask(), 1, ctx->stream);
-    ctx->end();
-    if (e != hipSuccess) return ctx->fail(e, "launch_dog_prep(redo)");
-  }
-  return dog_finish(p, t.path_rw(), t.any_qr, t.any_gram);
+  return dog_repair(p, dJ, df, ldJ, scale_mode, nfb, mask != nullptr);
 }
 
 // the verdict of an optimistic dogbox factor call (as trf_resolve)
 int dog_resolve(blsq_dogbox_plan* p, bool* redo) {
   return verdict_resolve(
       p, redo, [&]() { return dog_gate_tail(p, dog_chol_args(p, nullptr)); },
-      [&](int nfb) {
-        blsq_ctx* ctx = p->ctx;
-        QrTree& t = p->tree;
-        if (nfb > 0) {
-          int rc = t.run_fallback(ctx, p->pend_dJ, p->pend_df, p->pend_ldJ, nfb);
-          if (rc) return rc;
-          ctx->begin(K_PREP);
-          hipError_t e = launch_dog_prep(p->st, p->pend_scale_mode, 0, t.fb_mask(), 1, ctx->stream);
-          ctx->end();
-          if (e != hipSuccess) return ctx->fail(e, "launch_dog_prep(redo)");
-        }
-        return dog_finish(p, t.path_rw(), t.any_qr, t.any_gram);
-      });
+      [&](int nfb) { return dog_repair(p, p->pend_dJ, p->pend_df, p->pend_ldJ, p->pend_scale_mode, nfb, false); });
 }
 
 }  // namespace blsq_host
@@ -292,6 +420,7 @@ extern "C" int blsq_dogbox_plan_create(blsq_ctx* ctx, int B, int m, int n,
 }
 
 extern "C" int blsq_dogbox_plan_destroy(blsq_dogbox_plan* p) {
+  if (p) { p->cs_ints.release(); p->cs_pmin.release(); p->cs_eta.release(); p->cs_alpha.release(); p->cs_k2.release(); p->cs_vec.release(); p->cs_part.release(); }
   if (!p) return -1;
   hipStreamSynchronize(p->ctx->stream);
   { auto& v = p->ctx->dog_plans; v.erase(std::remove(v.begin(), v.end(), p), v.end()); }

@@ -710,6 +710,12 @@ struct blsq_dogbox_plan : VerdictState {
   DevBuf gate_ints;                 // [3B] fast flags, Jacobi launch mask, finished-in-the-Cholesky-kernel flags
   DevBuf colinfo;                   // [B][2] column-norm summary of the free block (Gram-path problems)
   int svdfree_enable = 1;
+  // CSNE tier (csne_kernels.hip): the Newton step of a rejected problem's free block corrected against J at factor time
+  bool csne_on = false;
+  int ncsne = 0;
+  DevBuf cs_ints, cs_pmin, cs_eta, cs_alpha, cs_k2, cs_vec, cs_part;
+  size_t cs_part_cap = 0;
+  CsneState cs{};
   DogState st{};
   DogStepOut out{};
 };

@@ -270,7 +270,19 @@ struct TrfState;
 hipError_t launch_csne_select(const CsneState& cs, const LmState& lm, int nfb, int* tree_list, int* tree_mask,
                               int* tree_count, int* path, const int* sel_mask, const double* k2, const double* pmin,
                               const double* colinfo, hipStream_t s);
+// ... the same for a dogbox plan (the free block of problem b has ncols[b] - 1 columns; gelsd's rank test,
+// dogbox.py:197, by the proven bound; the rank-gate outputs are the plan's fast / Jacobi-mask arrays)
+hipError_t launch_csne_select_dog(const CsneState& cs, int m, const int* ncols, int* fast, int* ncols_jac, int nfb,
+                                  int* tree_list, int* tree_mask, int* tree_count, int* path, const int* sel_mask,
+                                  const double* k2, const double* pmin, const double* colinfo, hipStream_t s);
+// (dvec == nullptr: J_h = J, no column scaling — dogbox)
 hipError_t launch_csne_pass(const CsneState& cs, const double* dvec, int count, hipStream_t s);
+// dogbox on the tier: the Gauss-Newton step of the free block, lstsq(J_free, -f) (dogbox.py:197), is ONE
+// solve — corrected at FACTOR time: scatter the cheap step into a full-length vector (the recording of the pass), the
+// pass, then  newton += -(X^T X)^-1 J_free^T (J_free newton + f)  with the free block's factor X
+struct DogState;
+hipError_t launch_dog_csne_scatter(const CsneState& cs, const DogState& st, int count, hipStream_t s);
+hipError_t launch_dog_csne_fix(const CsneState& cs, const DogState& st, int count, hipStream_t s);
 hipError_t launch_csne_fix(const CsneState& cs, const TrfState& st, const LmState& lm, const double* Delta,
                            const double* alpha_in, int count, hipStream_t s);
 // the problems of fail_list leave the tier: flag 0, path n + 1, tree_mask n + 1, tree_list = fail_list
@@ -452,6 +464,10 @@ struct DogState {
   double *newton, *cauchy;                // [B][ld], compact (free order)
   double *g_norm;                         // [B]
   unsigned char* active;                  // [B][ld]
+  // CSNE tier: flag[b] = 1 — the Newton step was corrected against J at factor time, the step kernel takes its
+  // products with it from the normal equations  J_free^T J_free newton = -g_free  (nullptr: off)
+  int* csne;                              // [B]
+  const double* csne_k2;                  // [B] the proven bound of the computed free-block system (rank gate of such a problem)
 };
 // from_gram / sel / redo: as launch_trf_prep (a Gram-path problem gets neither the compacted
 // columns S nor — yet — its Cauchy step: that comes from X in dog_gate_solve)

@@ -73,8 +73,11 @@ __device__ __forceinline__ constexpr int cs_bitrev4(int i) {
 // are pre-multiplied by d), their 64-lane totals by transposed butterflies (wave_sum16), then  y_e += u J[r]  (per lane:
 // its columns) and  b_e += t^2  (uniform: broadcast first, so that its order is the rows' order).  J streams straight
 // into registers (the next batch is requested before the current one is consumed); no LDS on the way.
+#ifndef BLSQ_CS_WGS_PER_CU
+#define BLSQ_CS_WGS_PER_CU 1
+#endif
 template <int NCB, int NEH, int G, int NS>
-__global__ __launch_bounds__(CS_NT, 1) void csne_pass_kernel(CsneState cs, const double* __restrict__ dvec) {
+__global__ __launch_bounds__(CS_NT, BLSQ_CS_WGS_PER_CU) void csne_pass_kernel(CsneState cs, const double* __restrict__ dvec) {
   static_assert(NS >= 2, "register slots of the row batches: one consumed, NS - 1 in flight");
   static_assert(G == 1 || G == 2 || G == 4, "groups of waves");
   constexpr int MEM = CS_NW / G;                          // members (waves) per group
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(CS_NT, 1) void csne_pass_kernel(CsneState cs, const
         const int col = lane + 64 * cb;
         double v = 0.0;
         if (e0 + e < ne && col < n)
-          v = dvec[(long)b * ld + col] * cs.rvec[(((long)b * CSNE_MAXE + e0 + e) * 3 + c) * ld + col];
+          v = (dvec ? dvec[(long)b * ld + col] : 1.0) * cs.rvec[(((long)b * CSNE_MAXE + e0 + e) * 3 + c) * ld + col];
         V[e][c][cb] = v;
       }
   double y[G][NEH][NCB], accB[G][NEH];                    // per class of this wave
@@ -512,25 +515,38 @@ __device__ __forceinline__ int cs_compact(int count, int* out, Get get, Keep kee
   return base;
 }
 
-__global__ __launch_bounds__(256) void csne_select_kernel(CsneState cs, LmState lm, int nfb, int* tree_list, int* tree_mask,
+// rank-gate outputs of a selected problem: TRF (LmState) or dogbox (fast / Jacobi-mask arrays); mrank = the row count
+// of the reference's rank test, ncols (optional): per-problem column count + 1 of the system factored (dogbox's free block)
+struct CsneGateOut {
+  LmState lm; int use_lm;
+  int* fast; int* ncols_jac;
+  const int* ncols; int mrank;
+};
+__global__ __launch_bounds__(256) void csne_select_kernel(CsneState cs, CsneGateOut go, int nfb, int* tree_list, int* tree_mask,
                                                           int* tree_count, int* path, const int* sel_mask,
                                                           const double* k2, const double* pmin, const double* colinfo) {
   __shared__ int scr[4];
   const int tid = threadIdx.x;
-  const int n = cs.n;
   for (int i = tid; i < nfb; i += 256) {
     const int b = tree_list[i];
+    const int n = go.ncols ? go.ncols[b] - 1 : cs.n;
     const double kb = k2[b], mn = colinfo[2 * (long)b], sm = colinfo[2 * (long)b + 1];
-    bool ok = sel_mask[b] == 0 && kb > 0.0 && kb <= CSNE_K2_MAX && pmin[b] >= CSNE_PIVOT_FLOOR && lm.m >= n;
-    // the reference's rank test (trust_region.py:108-110) by the proven bound: s_min(R_aug)^2 >= min_j h_jj / K2
+    bool ok = sel_mask[b] == 0 && kb > 0.0 && kb <= CSNE_K2_MAX && pmin[b] >= CSNE_PIVOT_FLOOR && go.mrank >= n && n >= 1;
+    // the reference's rank test (trust_region.py:108-110; gelsd's rcond = eps max(m, n), dogbox.py:197) by the proven
+    // bound: s_min(R)^2 >= min_j h_jj / K2
+    const int mx = go.mrank > n ? go.mrank : n;
     const double smin_lb = mn / sqrt(kb), smax_ub = sqrt(sm);
-    ok = ok && is_finite(sm) && sm > 0.0 && smin_lb > LM_GATE_MARGIN * LM_EPS * lm.m * smax_ub;
+    ok = ok && is_finite(sm) && sm > 0.0 && smin_lb > LM_GATE_MARGIN * LM_EPS * mx * smax_ub;
     if (ok) {
       cs.flag[b] = 1; path[b] = 0; tree_mask[b] = 0;
-      lm.fast[b] = 1; lm.ncols_jac[b] = 0;
-      lm.sc[(long)b * 16 + SC_SMAX] = smax_ub;
-      lm.sc[(long)b * 16 + SC_SMIN] = smin_lb;
-      lm.st[(long)b * 4 + ST_PHASE] = LM_IDLE;
+      if (go.use_lm) {
+        go.lm.fast[b] = 1; go.lm.ncols_jac[b] = 0;
+        go.lm.sc[(long)b * 16 + SC_SMAX] = smax_ub;
+        go.lm.sc[(long)b * 16 + SC_SMIN] = smin_lb;
+        go.lm.st[(long)b * 4 + ST_PHASE] = LM_IDLE;
+      } else {
+        go.fast[b] = 1; go.ncols_jac[b] = 0;
+      }
     }
   }
   __threadfence_block();
@@ -544,8 +560,89 @@ __global__ __launch_bounds__(256) void csne_select_kernel(CsneState cs, LmState 
 hipError_t launch_csne_select(const CsneState& cs, const LmState& lm, int nfb, int* tree_list, int* tree_mask,
                               int* tree_count, int* path, const int* sel_mask, const double* k2, const double* pmin,
                               const double* colinfo, hipStream_t s) {
-  hipLaunchKernelGGL(csne_select_kernel, dim3(1), dim3(256), 0, s, cs, lm, nfb, tree_list, tree_mask, tree_count, path,
+  CsneGateOut go{lm, 1, nullptr, nullptr, nullptr, lm.m};
+  hipLaunchKernelGGL(csne_select_kernel, dim3(1), dim3(256), 0, s, cs, go, nfb, tree_list, tree_mask, tree_count, path,
                      sel_mask, k2, pmin, colinfo);
+  return hipGetLastError();
+}
+hipError_t launch_csne_select_dog(const CsneState& cs, int m, const int* ncols, int* fast, int* ncols_jac, int nfb,
+                                  int* tree_list, int* tree_mask, int* tree_count, int* path, const int* sel_mask,
+                                  const double* k2, const double* pmin, const double* colinfo, hipStream_t s) {
+  CsneGateOut go{LmState{}, 0, fast, ncols_jac, ncols, m};
+  hipLaunchKernelGGL(csne_select_kernel, dim3(1), dim3(256), 0, s, cs, go, nfb, tree_list, tree_mask, tree_count, path,
+                     sel_mask, k2, pmin, colinfo);
+  return hipGetLastError();
+}
+
+// ---- dogbox on the tier ------------------------------------------------------------------------------
+// the cheap Newton step of the free block (free order) -> the full-length vector the pass multiplies J with (zeros at
+// the active variables): recording 0 of the problem, depth 1
+__global__ __launch_bounds__(256) void dog_csne_scatter_kernel(CsneState cs, DogState st) {
+  const int b = cs.list[blockIdx.x];
+  const int tid = threadIdx.x, n = cs.n, ld = cs.ld;
+  const long vo = (long)b * ld;
+  double* rec = cs.rvec + ((long)b * CSNE_MAXE) * 3 * ld;
+  const int nf = st.ncols[b] - 1;
+  for (int j = tid; j < n; j += 256) { rec[j] = 0.0; rec[ld + j] = 0.0; }
+  __syncthreads();
+  for (int q = tid; q < nf; q += 256) rec[st.free_idx[vo + q]] = st.newton[vo + q];
+  if (tid == 0) { cs.ne[b] = 1; cs.ralpha[(long)b * CSNE_MAXE] = 0.0; }
+}
+hipError_t launch_dog_csne_scatter(const CsneState& cs, const DogState& st, int count, hipStream_t s) {
+  if (count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(dog_csne_scatter_kernel, dim3(count), dim3(256), 0, s, cs, st);
+  return hipGetLastError();
+}
+
+// newton += -(X^T X)^-1 J_free^T (J_free newton + f): the residual of the cheap solve against J itself, one corrected
+// solve with the free block's factor; eta = |correction| / |newton| must stay below CSNE_ETA_MAX
+__global__ __launch_bounds__(TRI_NT) void dog_csne_fix_kernel(CsneState cs, DogState st) {
+  extern __shared__ double sh[];
+  __shared__ double scr[TRI_NW * 16];
+  const int li = blockIdx.x;
+  const int b = cs.list[li];
+  const int tid = threadIdx.x, ld = cs.ld;
+  const long vo = (long)b * ld;
+  const int nf = st.ncols[b] - 1;
+  double* q = sh;
+  double* invd = q + ld;
+  double* pfbuf = invd + ld;                              // 2 x 16 x ld doubles: DMA staging of the solves
+  const long PS = csne_part_stride(cs.NE, ld);
+  const double* part = cs.part + (long)li * cs.nchunk * PS;
+  const int* fidx = st.free_idx + vo;
+  const double* R = st.X + (long)b * ld * ld;
+  for (int k = tid; k < nf; k += TRI_NT) {
+    const int j = fidx[k];
+    double yj = 0.0;
+    for (int c = 0; c < cs.nchunk; ++c) yj += part[(long)c * PS + j];
+    q[k] = -yj;
+  }
+  tri_invdiag<TRI_NT>(R, nf, ld, invd);
+  __syncthreads();
+  tri_solve_upper_t_pf<TRI_NT>(R, nf, ld, invd, q, pfbuf);
+  tri_solve_upper_pf<TRI_NT>(R, nf, ld, invd, q, pfbuf);
+  double s2[2] = {0.0, 0.0};
+  for (int k = tid; k < nf; k += TRI_NT) {
+    const double dk = q[k], pk = st.newton[vo + k];
+    s2[0] = fma(pk, pk, s2[0]); s2[1] = fma(dk, dk, s2[1]);
+  }
+  cs_block_sums<2>(s2, scr);
+  const double eta = sqrt(s2[1] / s2[0]);
+  const bool fail = !(eta <= CSNE_ETA_MAX) || !is_finite(s2[0]) || !(s2[0] > 0.0);
+  if (!fail)
+    for (int k = tid; k < nf; k += TRI_NT) st.newton[vo + k] += q[k];
+  if (tid == 0) {
+    cs.eta[b] = fail ? -1.0 : eta;
+    if (fail) cs.fail_list[atomicAdd(cs.counts + 1, 1)] = b;
+  }
+}
+hipError_t launch_dog_csne_fix(const CsneState& cs, const DogState& st, int count, hipStream_t s) {
+  if (count <= 0) return hipSuccess;
+  const size_t lds = sizeof(double) * (2 + 32) * (size_t)cs.ld;
+  static std::atomic<size_t> granted[64];
+  hipError_t ge = gram_grant_lds(dog_csne_fix_kernel, lds, granted);
+  if (ge != hipSuccess) return ge;
+  hipLaunchKernelGGL(dog_csne_fix_kernel, dim3(count), dim3(TRI_NT), lds, s, cs, st);
   return hipGetLastError();
 }
 

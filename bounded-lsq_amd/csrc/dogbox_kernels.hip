@@ -77,6 +77,7 @@ __global__ __launch_bounds__(DG_NT) void dog_prep_kernel(DogState st, int jac_sc
   const int b = blockIdx.x, tid = threadIdx.x;
   if (b == 0 && pk.zero && tid < pk.nzero) pk.zero[tid] = 0;
   if (sel && sel[b] <= 1) return;
+  if (st.csne && tid == 0) st.csne[b] = 0;               // (a problem prepared afresh is on the CSNE tier only if selected again)
   const int n = st.n, ld = st.ld;
   const long vo = (long)b * ld;
   const double* Rt = st.Rt + (long)b * ld * ld;
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(DG_NT) void dog_step_kernel(DogState st, const doub
   int tr_hit = 0;
   bool newton_inside = in_box(cx, newton);
   // per-element face code kept in registers by owner threads: recomputed below
+  double cs_a = 0.0, cs_t = 1.0;                             // (CSNE: the step is cs_a cauchy + cs_t newton)
   if (newton_inside) {
     for (int q = tid; q < nf; q += DG_NT) { stp[q] = newton[q]; stepsv[q] = __builtin_inf(); dif[q] = 0.0; }
     __syncthreads();
@@ -321,6 +323,7 @@ __global__ __launch_bounds__(DG_NT) void dog_step_kernel(DogState st, const doub
     }
     __syncthreads();
     const double t = to_box(cx, cau, dif, stepsv);
+    cs_a = (c_in ? 1.0 : beta) * (1.0 - t); cs_t = t;
     int th = 0;
     for (int q = tid; q < nf; q += DG_NT) {
       const double sgn = (stepsv[q] == t) ? sign_of(dif[q]) : 0.0;
@@ -344,7 +347,21 @@ __global__ __launch_bounds__(DG_NT) void dog_step_kernel(DogState st, const doub
   // predicted reduction (dogbox.py:208-209):  Js.Js and Js.f
   const bool gp = st.path && st.path[b] == 0;
   double uu = 0.0, uc = 0.0;
-  if (gp) {
+  if (gp && st.csne && st.csne[b] && st.fast && st.fast[b]) {
+    // CSNE tier: X is a preconditioner only — its products with the Newton step would carry the Gram's error.  The
+    // corrected Newton step satisfies J_free^T J_free newton = -g_free, so with s = a c + t p (c the Cauchy step, a
+    // multiple of g: not in the small singular subspace)
+    //     |J s|^2 = a^2 |X c|^2 - 2 a t c.g_free - t^2 p.g_free
+    const double* Xf = st.X + (long)b * ld * ld;
+    tri_matvec_d(Xf, nf, ld, cauchy, u);
+    double cc = 0.0, cg = 0.0, pg = 0.0;
+    for (int q = tid; q < nf; q += DG_NT) {
+      const double gq = st.g[vo + fidx[q]];
+      cc += u[q] * u[q]; cg += cauchy[q] * gq; pg += newton[q] * gq; uc += stp[q] * gq;
+    }
+    cc = block_sum(cc, red); cg = block_sum(cg, red); pg = block_sum(pg, red);
+    if (tid == 0) uu = ((cs_a * cs_a) * cc - 2.0 * (cs_a * cs_t) * cg) - (cs_t * cs_t) * pg;   // (block_sum below adds the lanes' shares)
+  } else if (gp) {
     // normal-equations path: |J_free s|^2 = |X s|^2 (X: triangle of the free columns, or its Jacobi
     // rows), Js.f = s.g
     const double* Xf = st.X + (long)b * ld * ld;

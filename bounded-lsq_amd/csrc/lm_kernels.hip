@@ -244,7 +244,10 @@ __global__ __launch_bounds__(TRI_NT) void dog_gate_solve_kernel(DogState st, int
     bool sure = false;
     if (path && colinfo && path[b] == 0) {
       const double mn = colinfo[2 * (long)b], sm = colinfo[2 * (long)b + 1];
-      sure = is_finite(sm) && sm > 0.0 && (GRAM_SMIN_PROVEN * mn > LM_GATE_MARGIN * LM_EPS * mx * sqrt(sm));
+      // (a problem on the CSNE tier: the proven bound of ITS computed system instead of the gate's)
+      const double sminp = (st.csne && st.csne[b] && st.csne_k2 && st.csne_k2[b] > 0.0) ? 1.0 / sqrt(st.csne_k2[b])
+                                                                                       : GRAM_SMIN_PROVEN;
+      sure = is_finite(sm) && sm > 0.0 && (sminp * mn > LM_GATE_MARGIN * LM_EPS * mx * sqrt(sm));
     }
     if (!sure) {
     for (int i = tid; i < nf; i += TRI_NT) v[i] = (i & 1) ? -s0 : s0;

@@ -200,3 +200,44 @@ def test_inner_iterations_carry_alpha_and_need_no_new_factorisation():
         Delta = Dn
     assert ctx.csne_stats() == (B, 4 * B, 0)
     sol.close(); ctx.close()
+
+
+@pytest.mark.parametrize("m,n,kappa,bounded", [(1800, 144, 2e4, False), (4096, 256, 3e3, False), (1500, 100, 5e4, True),
+                                               (900, 81, 1e3, True)])
+def test_dogbox_newton_step_is_corrected_at_factor_time(m, n, kappa, bounded):
+    """dogbox on the tier: lstsq(J_free, -f) (dogbox.py:197) of a rejected free block is ONE solve — the cheap one
+    corrected against J at factor time; the dogleg's predicted reduction (dogbox.py:208-209) from the normal equations
+    the corrected step satisfies.  Newton / Cauchy steps, step, masks, tr_hit and predicted reduction as the oracle's."""
+    import bounded_lsq as bl
+    from bounded_lsq import _synth, _abi
+    from oracle import blsq_oracle as orc
+    rng = np.random.default_rng(21 + n)
+    B = 4
+    P = _synth.dogbox_batch(31, B, m, n)
+    P["J"] = logspaced(rng, B, m, n, kappa)
+    if not bounded:
+        P["lb"][:] = -np.inf; P["ub"][:] = np.inf; P["on_bound"][:] = 0
+    else:                                                       # wide bounds, a tenth of the variables sitting on one
+        P["lb"] = P["x"] - rng.uniform(50.0, 500.0, (B, n)); P["ub"] = P["x"] + rng.uniform(50.0, 500.0, (B, n))
+        P["on_bound"][:] = 0
+        for b in range(B):
+            idx = rng.choice(n, n // 10, replace=False)
+            P["x"][b, idx] = P["lb"][b, idx]; P["on_bound"][b, idx] = -1
+    ctx = _abi.Context(0)
+    sol = bl.DogboxStepSolver(B, m, n, ctx=ctx)
+    ctx.gram_stats(reset=True); ctx.cqr2_stats(reset=True); ctx.csne_stats(reset=True)
+    sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"], P["on_bound"])
+    stats = (ctx.gram_stats(), ctx.cqr2_stats(), ctx.csne_stats())
+    F = sol.fetch_factor(want_steps=True)
+    Delta = np.array([0.02, 1.0, 50.0, 1e6])
+    S = sol.step(Delta)
+    sol.close(); ctx.close()
+    print(stats)
+    assert stats[0] == (0, B) and stats[1] == 0 and stats[2] == (B, B, 0), stats
+    for b in range(B):
+        Fo, So = orc.dogbox_step_solve(P["J"][b], P["f"][b], P["x"][b], P["lb"][b], P["ub"][b], P["scale"][b],
+                                       P["on_bound"][b], float(Delta[b]))
+        assert rel(S.step[b], So.step) < RTOL, (b, rel(S.step[b], So.step))
+        np.testing.assert_array_equal(S.on_bound_new[b], So.on_bound_new)
+        assert bool(S.tr_hit[b]) == bool(So.tr_hit)
+        assert abs(S.predicted_reduction[b] - So.predicted_reduction) <= 1e-9 * abs(So.predicted_reduction), b

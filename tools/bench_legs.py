@@ -15,6 +15,7 @@ a = ap.parse_args()
 ctx = _abi.Context(0)
 muts = {"certificate_rejected": bench.mut_all_rejected, "mixed_conditioning_unbounded": bench.mut_mixed_unbounded,
         "mixed_conditioning": bench.mut_mixed}
+muts["certificate_rejected_dogbox"] = bench.mut_all_rejected
 for leg in a.legs:
-    r = bench.conditioning_leg(leg, muts[leg], ctx, "c2", a.batch, a.steps, a.check)
+    r = bench.conditioning_leg(leg, muts[leg], ctx, "c2-dogbox" if leg.endswith("dogbox") else "c2", a.batch, a.steps, a.check)
     print(leg, json.dumps({k: r[k] for k in ("value", "ms_per_step", "factorisation_paths", "parity", "kernels_ms_per_step")}), flush=True)
