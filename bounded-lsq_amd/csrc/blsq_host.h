@@ -252,6 +252,7 @@ struct QrTree {
   // CholeskyQR2 middle tier (cqr2_kernels.hip): buffers allocated on first use
   bool cqr2 = false;
   DevBuf cq_W, cq_Wf, cq_G2, cq_R1, cq_R2, cq_z, cq_ints;
+  size_t cq_cap = 0;                       // listed problems cq_W / cq_Wf hold (high-water mark of the rejected list)
   bool fb_zeroed = false;                  // the gate counters were cleared by pack_vecs_kernel of this factor call
   // per-problem path of the CURRENT triangles: gram_path()[b] = n + 1 (Householder tree) or 0 (Gram).
   // any_gram / any_qr: whether a problem of either kind can exist (host-side upper bounds)
@@ -456,10 +457,22 @@ struct QrTree {
   int run_fallback(blsq_ctx* ctx, const double* dJ, const double* df, int ldJ, int nfb) {
     if (!cqr2 || !gram) return run_levels(ctx, dJ, df, ldJ, fb_mask(), fb_list(), nfb);
     hipError_t e = hipSuccess;
-    if (!cq_W.p) {
-      e = cq_W.alloc(sizeof(double) * (size_t)B * m * n);
-      if (e == hipSuccess) e = cq_Wf.alloc(sizeof(double) * (size_t)B * m);
-      if (e == hipSuccess) e = cq_G2.alloc(sizeof(double) * (size_t)B * NPAD * NPAD);
+    // W = J R1^-1 and w_f for the LISTED problems only (list position, not problem index): sized by the high-water mark
+    // of the list, grown geometrically — a single rejected problem of a 512-problem batch costs 8 MB, not 4.3 GB.
+    if ((size_t)nfb > cq_cap) {
+      const size_t cap = std::min<size_t>((size_t)B, std::max<size_t>((size_t)nfb, 2 * cq_cap));
+      cq_W.release(); cq_Wf.release();
+      e = cq_W.alloc(sizeof(double) * cap * m * n);
+      if (e == hipSuccess) e = cq_Wf.alloc(sizeof(double) * cap * m);
+      if (e != hipSuccess) {                              // no room for the second pass: the tree does it all
+        cq_W.release(); cq_Wf.release(); cq_cap = 0;
+        (void)hipGetLastError();
+        return run_levels(ctx, dJ, df, ldJ, fb_mask(), fb_list(), nfb);
+      }
+      cq_cap = cap;
+    }
+    if (!cq_G2.p) {
+      e = cq_G2.alloc(sizeof(double) * (size_t)B * NPAD * NPAD);
       if (e == hipSuccess) e = cq_R2.alloc(sizeof(double) * (size_t)B * NPAD * NPAD);
       if (e == hipSuccess) e = cq_R1.alloc(sizeof(double) * (size_t)B * NPAD * NPAD);
       if (e == hipSuccess) e = hipMemsetAsync(cq_R1.p, 0, cq_R1.bytes, ctx->stream);
@@ -469,7 +482,7 @@ struct QrTree {
       if (e == hipSuccess) e = hipMemsetAsync(cq_R2.p, 0, cq_R2.bytes, ctx->stream);
       if (e == hipSuccess) e = hipMemsetAsync(cq_ints.p, 0, cq_ints.bytes, ctx->stream);
       if (e != hipSuccess) {                              // no room for the second pass: the tree does it all
-        cq_W.release(); cq_Wf.release(); cq_G2.release(); cq_R1.release(); cq_R2.release(); cq_z.release(); cq_ints.release();
+        cq_G2.release(); cq_R1.release(); cq_R2.release(); cq_z.release(); cq_ints.release();
         cqr2 = false;
         (void)hipGetLastError();
         return run_levels(ctx, dJ, df, ldJ, fb_mask(), fb_list(), nfb);
@@ -522,6 +535,7 @@ struct QrTree {
     g.opt = opt;
     g.J = q.Wj; g.strideJ = q.strideW; g.ldJ = n; g.F = q.Wf; g.strideF = m;
     g.m = m; g.n = n; g.NPAD = NPAD; g.mask = runm; g.list = fb_list();   // (compacted: all XCDs)
+    g.src_by_pos = 1;                                   // (W holds the listed problems only)
     double* G2 = cq_G2.as<double>();
     g.G = gram_nchunk > 1 ? gram_part.as<double>() : G2;
     ctx->begin(K_GRAM);

@@ -72,6 +72,8 @@ struct GramArgs {
   int rhs_valu;           // set by launch_gram: J^T f / f^T f accumulated by the vector ALUs
   double* Gscr;           // set by launch_gram (pair mode): the chunk-partials buffer, used as scratch
   const Options* opt;     // host only: the ctx's switches (nullptr: the table's defaults)
+  int src_by_pos;         // 1 (with `list`): J / F are indexed by the LIST POSITION of the workgroup's problem, not by the
+                          // problem — the source holds the listed problems only (CholeskyQR2's W, sized by the list)
 };
 struct GramCholArgs {
   const double* Gsrc;     // [B][NPAD*NPAD] Gram (upper tile blocks); may alias G (in place)
@@ -212,8 +214,8 @@ struct Cqr2Args {
   const double* dsc;      // [B][NPAD] the equilibration of the first Cholesky: R1' = R1 diag(dsc)
   const double* R1;       // [B][NPAD*NPAD] R1 | c as stored by the first Cholesky
   double* z;              // [B][NPAD] R1^-1 c
-  double* Wj; long strideW;   // [B][m][n]  W = J R1^-1
-  double* Wf; long strideWf;  // [B][m]     f - J R1^-1 c
+  double* Wj; long strideW;   // [list position][m][n]  W = J R1^-1  (sized by the list of rejected problems, not by B)
+  double* Wf; long strideWf;  // [list position][m]     f - J R1^-1 c
   int rows_per_wg;        // set by launch_cqr2_apply
 };
 constexpr double CQR2_K2_MAX = 1.0e12;   // largest proven kappa_2 of the equilibrated J^T J the tier accepts

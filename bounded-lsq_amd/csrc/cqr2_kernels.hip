@@ -150,8 +150,8 @@ __device__ __forceinline__ void cqr2_wave(const Cqr2Args& a, double* lds, int b)
     for (int h = 0; h < 2; ++h) { issue(r_lo, h); commit(r_lo, h, X0); }
   }
   __syncthreads();
-  double* Wjb = a.Wj + (long)b * a.strideW;
-  double* Wfb = a.Wf + (long)b * a.strideWf;
+  double* Wjb = a.Wj + (long)blockIdx.y * a.strideW;    // (by list position: the buffers hold the listed problems only)
+  double* Wfb = a.Wf + (long)blockIdx.y * a.strideWf;
   constexpr bool LATE = W >= 4;
   v4d acc[2][2];
   // lane holds W[row0 + 16 rt + lr + 4 g][16 j + lc]

@@ -55,8 +55,9 @@ __global__ __launch_bounds__(GR_NT, (SLOTS <= 8 ? 4 : 2)) void gram_kernel(GramA
   int r_hi = r_lo + a.rows_per_chunk;
   if (r_hi > a.m) r_hi = a.m;
   const int m = r_hi;                                   // exclusive row limit
-  const double* Jb = a.J + (long)b * a.strideJ;
-  const double* Fb = a.F + (long)b * a.strideF;
+  const long bsrc = a.src_by_pos ? (long)blockIdx.y : (long)b;   // (the source indexed by list position: CholeskyQR2's W)
+  const double* Jb = a.J + bsrc * a.strideJ;
+  const double* Fb = a.F + bsrc * a.strideF;
 
   // tile table (wave-uniform): slot t -> (ti, tj); idle slots recompute tile (0, 0) and are
   // not stored (no branch inside the MFMA loop)
@@ -250,8 +251,9 @@ __device__ __forceinline__ void gram16_wave(const GramArgs& a, double* lds) {
   if (r_hi > a.m) r_hi = a.m;
   const int m = r_hi;
   const int boundary = a.rows_per_chunk;                // (PAIR) first row of the second chunk
-  const double* Jb = a.J + (long)b * a.strideJ;
-  const double* Fb = a.F + (long)b * a.strideF;
+  const long bsrc = a.src_by_pos ? (long)blockIdx.y : (long)b;   // (the source indexed by list position: CholeskyQR2's W)
+  const double* Jb = a.J + bsrc * a.strideJ;
+  const double* Fb = a.F + bsrc * a.strideF;
 
   constexpr int HR = GR_RC / GR_NW / 2;                 // rows per wave per half chunk
   double pre[HR][NCB], fpre[HR];
@@ -510,8 +512,9 @@ __device__ __forceinline__ void gram8_wave(const GramArgs& a, double* lds) {
   int r_hi = r_lo + a.rows_per_chunk;
   if (r_hi > a.m) r_hi = a.m;
   const int m = r_hi;
-  const double* Jb = a.J + (long)b * a.strideJ;
-  const double* Fb = a.F + (long)b * a.strideF;
+  const long bsrc = a.src_by_pos ? (long)blockIdx.y : (long)b;   // (the source indexed by list position: CholeskyQR2's W)
+  const double* Jb = a.J + bsrc * a.strideJ;
+  const double* Fb = a.F + bsrc * a.strideF;
 
   constexpr int HR = GR_RC / GR_NW / 2;                 // rows per wave per half chunk
   double pre[HR][NCB], fpre[HR];
@@ -704,8 +707,9 @@ __global__ __launch_bounds__(64 * NWD, (NTT <= 2 ? 4 : 2)) void gram_direct_kern
   const int r_lo = blockIdx.x * a.rows_per_chunk;
   int r_hi = r_lo + a.rows_per_chunk;
   if (r_hi > a.m) r_hi = a.m;
-  const double* Jb = a.J + (long)b * a.strideJ;
-  const double* Fb = a.F + (long)b * a.strideF;
+  const long bsrc = a.src_by_pos ? (long)blockIdx.y : (long)b;   // (the source indexed by list position: CholeskyQR2's W)
+  const double* Jb = a.J + bsrc * a.strideJ;
+  const double* Fb = a.F + bsrc * a.strideF;
   v4d acc[NTILE];
 #pragma unroll
   for (int t = 0; t < NTILE; ++t) acc[t] = v4d{0.0, 0.0, 0.0, 0.0};
