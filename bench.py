@@ -710,17 +710,25 @@ def main():
 
     comm_ready = False
     comm_error = None
-    if world > 1:
-        # every N > 1 run brings up the library's own RCCL communicator (the tall problem needs it; the batch configs
-        # do not — no data-path collective — but the line then shows which librccl the ranks resolved and that it
-        # spans them all)
-        try:
+    comm_hung = False
+
+    def bring_up_comm():
+        """the library's own RCCL communicator over all ranks, guarded: an exception is reported, a bring-up that does
+        not return within two minutes is reported and left alone (its helper thread may still sit in librccl)"""
+        nonlocal comm_ready, comm_error, comm_hung
+        def go():
             ctx.comm_init(world, rank, bcast_comm_id())
+            return {"ok": True}
+        res, hung = with_timeout(go, 120, "blsq_comm_init over %d ranks" % world)
+        comm_hung = hung
+        if isinstance(res, dict) and res.get("ok"):
             comm_ready = True
-        except Exception as exc:                               # noqa: BLE001
-            if name == "c5":
-                raise
-            comm_error = "%s: %s" % (type(exc).__name__, str(exc)[:200])
+        else:
+            comm_error = (res or {}).get("error", "unknown") if isinstance(res, dict) else str(res)
+    if world > 1 and name == "c5":
+        bring_up_comm()                                        # (the tall problem needs it before its first factor call)
+        if not comm_ready:
+            raise RuntimeError("c5 at N > 1 needs the RCCL communicator: %s" % comm_error)
     bench = Bench(name, ctx, rank, world, batch=args.batch, m=args.m, n=args.n, comm_ready=comm_ready)
     steps_requested = steps
     own_elapsed, steps = time_steps(bench, steps, warmup, fence, args.min_time, max_over_ranks)
@@ -732,7 +740,13 @@ def main():
         units_rank = (1 if bench.kind == "tsqr" else bench.B) * steps
         out["per_rank"] = {"elapsed_s": per_rank, "step_solves_per_s": [units_rank / e for e in per_rank],
                            "note": "each rank's own clock over the same fenced region; `value` uses the max"}
-        if bench.kind == "tsqr" or comm_ready:
+    if world > 1 and not comm_ready:
+        # The batch configs have no data-path collective and their `value` is in hand; NOW — never in front of the
+        # timed region — every N > 1 run also brings up the library's RCCL communicator, so that the line shows which
+        # librccl the ranks resolved and that it spans them all (the `c5_tsqr` leg below then reuses it).
+        bring_up_comm()
+    if out is not None:
+        if comm_ready:
             out["rccl"] = ctx.comm_info()
         elif comm_error:
             out["rccl"] = {"error": comm_error}
@@ -862,7 +876,7 @@ def main():
                     side_hung = True
                     break
             extras["side_configs"] = side
-    if world > 1 and main_line and not args.no_side:
+    if world > 1 and main_line and not args.no_side and not comm_hung:
         # the tall problem of config 5 over ALL ranks (250 000 rows each): the library's own RCCL
         # communicator, Gram all-reduce inside blsq_tsqr_factor_dev.  A side figure: guarded, timed out.
         def c5_leg():
@@ -946,6 +960,11 @@ def main():
             digest["c5_tsqr"] = [round(extras["c5_tsqr"]["value"], 1), round(extras["c5_tsqr"]["ms_per_step"], 4), None]
         out["side_summary"] = digest
         print(json.dumps(out), flush=True)
+    if comm_hung:
+        # the communicator's bring-up never came back (its helper thread still sits in librccl): the line is out and
+        # says so (`rccl.error`); the measurement itself needed no collective — leave without teardown
+        sys.stdout.flush()
+        os._exit(0)
     if side_hung:
         # a side leg never came back: its helper thread still drives this ctx and stream, so nothing more
         # is enqueued behind it (close() would wait on the stuck work) — the line is out, leave, non-zero
