@@ -241,3 +241,58 @@ def test_dogbox_newton_step_is_corrected_at_factor_time(m, n, kappa, bounded):
         np.testing.assert_array_equal(S.on_bound_new[b], So.on_bound_new)
         assert bool(S.tr_hit[b]) == bool(So.tr_hit)
         assert abs(S.predicted_reduction[b] - So.predicted_reduction) <= 1e-9 * abs(So.predicted_reduction), b
+
+
+def _illcond_fit(B, m, n, kappa, seed):
+    """B nonlinear fits  r(x) = tanh(A_b x - y_b)  with ill-conditioned A_b (kappa(A) = kappa): the Jacobian
+    diag(1 - r^2) A_b inherits the conditioning, so the certificate rejects it at every outer iteration."""
+    rng = np.random.default_rng(seed)
+    A = logspaced(rng, B, m, n, kappa) / np.sqrt(m)
+    xs = rng.standard_normal((B, n))
+    Y = np.einsum("bmn,bn->bm", A, xs) + 0.05 * rng.standard_normal((B, m))
+
+    def fun(X):
+        X = np.atleast_2d(X)
+        return np.tanh(np.einsum("bmn,bn->bm", A[:X.shape[0]], X) - Y[:X.shape[0]])
+
+    def jac(X):
+        X = np.atleast_2d(X)
+        r = np.tanh(np.einsum("bmn,bn->bm", A[:X.shape[0]], X) - Y[:X.shape[0]])
+        return (1.0 - r * r)[:, :, None] * A[:X.shape[0]]
+    return fun, jac, A, Y, xs
+
+
+@pytest.mark.parametrize("method", ["trf", "dogbox"])
+def test_end_to_end_solves_on_the_tier_sequential_batched_and_device_resident(method):
+    """Whole solves whose every outer iteration is on the tier: the sequential host driver (inner iterations re-solve on
+    the same factor with the carried alpha: the pass reads the staged J again), the batched host driver, and the
+    device-resident outer driver (masked re-factorisation: problems leave and re-enter the tier as their Jacobians are
+    refreshed while the others keep their flags, recordings and J) — the same nfev / njev / status and the same x."""
+    from bounded_lsq import least_squares, least_squares_batch, _abi, _hip_step
+    B, m, n = 5, 600, 96
+    fun, jac, A, Y, xs = _illcond_fit(B, m, n, 2e3, 17)
+    X0 = xs + 0.3 * np.random.default_rng(3).standard_normal((B, n))
+    kw = dict(method=method, max_nfev=25)
+    ctx = _hip_step.default_context()
+    ctx.csne_stats(reset=True)
+    seq = []
+    for b in range(B):
+        def fun_b(p, b=b):
+            return np.tanh(A[b] @ p - Y[b])
+
+        def jac_b(p, b=b):
+            r = np.tanh(A[b] @ p - Y[b])
+            return (1.0 - r * r)[:, None] * A[b]
+        seq.append(least_squares(fun_b, X0[b], jac_b, **kw))
+    routed, delivered, declined = ctx.csne_stats(reset=True)
+    assert routed >= sum(r.njev for r in seq) - B and delivered > 0, (routed, delivered, declined)
+    host = least_squares_batch(fun, X0, jac, **kw)
+    dev = least_squares_batch(fun, X0, jac, driver='device', **kw)
+    r2 = ctx.csne_stats(reset=True)
+    assert r2[0] > 0 and r2[1] > 0, r2
+    assert len({r.nfev for r in seq}) > 1                   # (different iteration counts: masked factor calls happen)
+    for b in range(B):
+        for name, res in (("host", host[b]), ("device", dev[b])):
+            assert (res.nfev, res.njev, res.status) == (seq[b].nfev, seq[b].njev, seq[b].status), (name, b)
+            np.testing.assert_allclose(res.x, seq[b].x, rtol=1e-8, atol=1e-10)
+            np.testing.assert_allclose(res.obj_value, seq[b].obj_value, rtol=1e-9)
