@@ -759,15 +759,19 @@ def main():
         if not args.no_householder:
             # the same workload with the normal-equations front end off: every problem through the
             # Householder TSQR tree — what a batch gets whose problems fail the conditioning gate
-            os.environ["BLSQ_GRAM"] = "0"                      # read when a plan is created
-            bh = Bench(name, ctx, 0, 1, batch=args.batch)
-            os.environ.pop("BLSQ_GRAM", None)
+            gram_was = ctx.get_option("gram")
+            ctx.set_option("gram", 0)                          # (a route switch: read when a plan is created)
+            try:
+                bh = Bench(name, ctx, 0, 1, batch=args.batch)
+            finally:
+                ctx.set_option("gram", gram_was)
             kh = max(2, min(steps_requested, 20))
             eh, kh = time_steps(bh, kh, 1, ctx.sync)
             extras["householder_only"] = {
                 "value": B * kh / eh, "unit": "step-solves/s", "ms_per_step": 1e3 * eh / kh, "steps": kh,
                 "kernels_ms_per_step": {k: round(v, 4) for k, v in profile_table(bh).items() if v > 0},
-                "note": "BLSQ_GRAM=0: Householder TSQR tree for every problem"}
+                "factorisation_paths": dict(zip(("normal_equations", "householder_tree"), ctx.gram_stats())),
+                "note": "option gram = 0: Householder TSQR tree for every problem"}
             bh.close()
         if not args.no_householder:
             # A batch of mixed conditioning: kappa(J) log-uniform over [1, 1e4] (J = Z V diag(s) V^T, Z
@@ -917,6 +921,12 @@ def main():
             # this ctx (a helper thread may still sit in the stuck collective), no teardown, no re-exec.
             os._exit(3)
 
+    if world == 1 and main_line and not args.no_h2d and not side_hung:
+        # (the last GPU leg: its numpy callbacks wake the BLAS thread pool, whose workers then spin for tens of
+        #  milliseconds on the box's CPU share — measured: a latency-bound side leg that followed at once ran at HALF
+        #  speed; the CPU leg below waits a moment for them to go back to sleep)
+        front_end_leg()
+        time.sleep(1.0)
     if rank == 0 and world == 1 and not args.no_cpu and main_line and not side_hung:
         # The CPU leg LAST, after every GPU leg (so that the GPU work of this run is contiguous), and in a child
         # process of its own: this one has initialised the GPU and must not fork worker pools.
@@ -932,11 +942,6 @@ def main():
         except Exception as exc:                               # noqa: BLE001
             extras["cpu_baseline_error"] = str(exc)[:300]
             cpu = None
-    if world == 1 and main_line and not args.no_h2d and not side_hung:
-        # (the very last leg: its numpy callbacks wake the BLAS thread pool, whose workers then spin for tens of
-        #  milliseconds on the box's CPU share — measured: a latency-bound side leg that followed at once ran at HALF
-        #  speed, and the CPU leg's sixteen workers lost a fifth of theirs)
-        front_end_leg()
     if rank == 0:
         out.update(extras)
         out["cpu_baseline"] = cpu
