@@ -358,7 +358,7 @@ int dog_factor_core(blsq_dogbox_plan* p, const double* dJ, const double* df, int
   e = launch_gram_chol(c, p->B, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_gram_chol(free block)");
-  const bool defer = may_defer && p->optimistic && p->guess_ok && p->svdfree_enable && !mask && p->pend_pin &&
+  const bool defer = may_defer && !mask && verdict_may_guess(p) && p->svdfree_enable && p->pend_pin &&
                      p->pend_ev;
   // second guess (N <= 80): the Cholesky kernel settles EVERY problem itself, as it did in the last call —
   // then the certificate, gate and solve launches would all be empty and are not enqueued at all

@@ -639,6 +639,11 @@ using namespace blsq_host;
 struct VerdictState {
   bool optimistic = true;           // option `optimistic` = 0 switches it off
   bool guess_ok = true;             // the last verdict of this plan was "all fast": only then is the next one guessed
+  // Back-off: a plan whose guess keeps failing (inputs that change their conditioning class from call to call) stops
+  // guessing for 2, 4, ... 32 factor calls after each wrong guess — a wrong guess costs the Newton rounds and the step
+  // once more (about half a step-solve), a synchronous verdict ten microseconds of idle stream; a right guess takes
+  // one level off again.
+  int guess_streak = 0, guess_pause = 0;
   bool pending = false;
   // Second guess: every problem is settled inside the factor kernel / stage 0 of the certificate, so the certificate
   // and gate launches are not even enqueued; checked with the same read-back.
@@ -780,6 +785,18 @@ PublishArgs verdict_rides(Plan* p) {
 
 // prep from the Gram, Cholesky of H with the pivot gate, conditioning gate; *nfb = problems of this
 
+// the back-off of a plan's guessing (VerdictState::guess_pause)
+inline void verdict_wrong(VerdictState* p) {
+  if (p->guess_streak < 5) ++p->guess_streak;
+  p->guess_pause = 1 << p->guess_streak;
+}
+inline void verdict_right(VerdictState* p) { if (p->guess_streak > 0) --p->guess_streak; }
+// may this factor call guess?  (consumes one call of a pause)
+inline bool verdict_may_guess(VerdictState* p) {
+  if (p->guess_pause > 0) { --p->guess_pause; return false; }
+  return p->optimistic && p->guess_ok;
+}
+
 // has the factor kernel (N <= 80) / stage 0 of the certificate (TRF, N > 80) settled every problem of the call?
 inline bool verdict_settled(const blsq_trf_plan* p) { return p->pend_pin[2] == 0; }
 inline bool verdict_settled(const blsq_dogbox_plan* p) { return p->ld <= 80 && p->pend_pin[2] == 0; }
@@ -797,8 +814,9 @@ int verdict_drop(Plan* p) {
   if (p->pend_tail) { if (!verdict_settled(p)) p->guess_settled = false; }
   else if (nfb_ > 0 || njac_ > 0) {
     p->guess_ok = false;
+    verdict_wrong(p);
     ctx->gram_fast -= nfb_; ctx->gram_fallback += nfb_;
-  }
+  } else verdict_right(p);
   return 0;
 }
 
@@ -840,11 +858,12 @@ int verdict_resolve(Plan* p, bool* redo, GateTail gate_tail, Repair repair) {
     HIPCHK(ctx, hipMemcpyAsync(p->pend_pin, t.fb_count(), 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     nfb = p->pend_pin[0]; njac = p->pend_pin[1];
-    if (nfb > 0 || njac > 0) p->guess_ok = false;
+    if (nfb > 0 || njac > 0) { p->guess_ok = false; verdict_wrong(p); }
   } else {
     p->guess_settled = settled;
-    if (nfb == 0 && njac == 0) return 0;
+    if (nfb == 0 && njac == 0) { verdict_right(p); return 0; }
     p->guess_ok = false;
+    verdict_wrong(p);
     if (redo) *redo = true;
   }
   ctx->gram_fast -= nfb; ctx->gram_fallback += nfb;      // (note_paths counted everybody as fast)

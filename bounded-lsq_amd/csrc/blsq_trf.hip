@@ -413,7 +413,7 @@ int trf_factor_core(blsq_trf_plan* p, const double* dJ, const double* df, int ld
   if (!mask) p->ncsne = 0;                                // (the prep launch clears every flag; trf_csne_select sets them anew)
   int nfb = 0;
   // (never in the n-band that always takes the SVD, nor right after a wrong guess)
-  const bool defer = may_defer && p->optimistic && p->guess_ok && p->lm_enable && !mask && p->pend_pin &&
+  const bool defer = may_defer && !mask && verdict_may_guess(p) && p->lm_enable && p->pend_pin &&
                      p->pend_ev;
   if ((rc = trf_gram_stage(p, scale_mode, mask, &nfb, defer))) return rc;
   if (defer) { p->pend_dJ = dJ; p->pend_df = df; p->pend_ldJ = ldJ; p->pend_scale_mode = scale_mode; }

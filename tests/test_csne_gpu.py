@@ -296,3 +296,45 @@ def test_end_to_end_solves_on_the_tier_sequential_batched_and_device_resident(me
             assert (res.nfev, res.njev, res.status) == (seq[b].nfev, seq[b].njev, seq[b].status), (name, b)
             np.testing.assert_allclose(res.x, seq[b].x, rtol=1e-8, atol=1e-10)
             np.testing.assert_allclose(res.obj_value, seq[b].obj_value, rtol=1e-9)
+
+
+def test_alternating_conditioning_classes_on_one_plan(blsq_opt):
+    """Two input sets alternate on ONE plan through the device API — a well-conditioned bounded batch and one whose
+    problems are rejected (CSNE tier) — so the optimistic guess of blsq_trf_factor_dev fails again and again: the plan
+    backs off (2, 4, ... factor calls without guessing after each wrong guess).  Whatever it guesses and however often:
+    the bits of the synchronous mode at every call, and the same path statistics."""
+    import bounded_lsq as bl
+    from bounded_lsq import _synth, _abi
+    rng = np.random.default_rng(41)
+    B, m, n = 6, 1024, 128
+    good = _synth.trf_batch(900, B, m, n)
+    bad = _synth.trf_batch(901, B, m, n, unbounded=True)
+    bad["J"] = logspaced(rng, B, m, n, 5e3)
+    Delta = np.array([0.5, 0.05, 5.0, 0.2, 0.3, 1.0])
+    runs = []
+    for opt in (1, 0):
+        blsq_opt("optimistic", opt)
+        ctx = _abi.Context(0)
+        sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
+        dev = [{k: ctx.to_device(P[k]) for k in ("J", "f", "x", "lb", "ub", "scale")} for P in (good, bad)]
+        dD, dA = ctx.to_device(Delta), ctx.to_device(np.zeros(B))
+        ctx.gram_stats(reset=True); ctx.csne_stats(reset=True)
+        outs = []
+        for call in range(14):
+            d = dev[call & 1]
+            sol.factor_dev(d["J"], d["f"], d["x"], d["lb"], d["ub"], d["scale"])
+            sol.step_dev(dD, dA)
+            S = sol.fetch_step()
+            outs.append((S.step.copy(), np.asarray(S.alpha).copy(), np.asarray(S.n_iter).copy(), S.hits.copy()))
+        stats = (ctx.gram_stats(), ctx.csne_stats())
+        assert stats == ((7 * B, 7 * B), (7 * B, 7 * B, 0)), (opt, stats)
+        runs.append(outs)
+        sol.close()
+        for d in dev:
+            for v in d.values():
+                ctx.free(v)
+        ctx.free(dD); ctx.free(dA)
+        ctx.close()
+    for call, (a, b) in enumerate(zip(*runs)):
+        for x1, x0 in zip(a, b):
+            assert np.array_equal(x1, x0), call
