@@ -16,6 +16,11 @@ ctx = _abi.Context(0)
 muts = {"certificate_rejected": bench.mut_all_rejected, "mixed_conditioning_unbounded": bench.mut_mixed_unbounded,
         "mixed_conditioning": bench.mut_mixed}
 muts["certificate_rejected_dogbox"] = bench.mut_all_rejected
+muts["householder_only"] = None                        # the headline batch with option gram = 0: the Householder tree for all
 for leg in a.legs:
+    if leg == "householder_only":
+        ctx.set_option("gram", 0)
     r = bench.conditioning_leg(leg, muts[leg], ctx, "c2-dogbox" if leg.endswith("dogbox") else "c2", a.batch, a.steps, a.check)
     print(leg, json.dumps({k: r[k] for k in ("value", "ms_per_step", "factorisation_paths", "parity", "kernels_ms_per_step")}), flush=True)
+    if leg == "householder_only":
+        ctx.set_option("gram", 1)

@@ -4,6 +4,7 @@
 #   bench's `certificate_rejected` leg (512 problems of 4096 x 256, kappa(J) = 3e3, no bounds: all on the tier)
 set -o pipefail
 TAG=$1; LEG=${2:-certificate_rejected}
+# (BLSQ_CSNE=0 in the environment profiles the CholeskyQR2 tier on the same leg; leg householder_only: the tree)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out
 RUN="python3 tools/bench_legs.py $LEG --steps 4 --check 0"
