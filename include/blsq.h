@@ -116,7 +116,10 @@ int blsq_trf_step(blsq_trf_plan* plan, const double* Delta /*B*/, double* alpha_
  * unmodified until the verdict has been read — by the next blsq_*_step_dev / blsq_*_fetch_* call on the
  * plan, or by blsq_sync(ctx), which resolves every pending verdict of the ctx (so does blsq_dev_free and
  * blsq_memcpy_h2d: memory handed back to, or overwritten through, the library is never read afterwards).
- * After blsq_sync nothing of the caller's J / f is read again.  A second *_factor_dev on the plan drops
+ * After blsq_sync nothing of the caller's J / f is read again — EXCEPT by blsq_trf_step_dev while the plan holds problems
+ * on the CSNE tier (ill-conditioned TRF problems of 80 <= n <= 256; blsq_debug_csne_stats below): their steps are
+ * corrected against J itself, so dJ / df must then stay valid and unmodified until the next factor call on the plan
+ * (option `csne` = 0 restores the unconditional rule).  A second *_factor_dev on the plan drops
  * the first one's verdict (it is still read for the path statistics).  Option `optimistic` = 0 (environment
  * BLSQ_OPTIMISTIC=0 at blsq_ctx_create): the factor call waits itself and the rule is void. */
 int blsq_trf_factor_dev(blsq_trf_plan* plan, const double* dJ, const double* df,
