@@ -11,8 +11,9 @@ for seed, lk in ((11, (0.0, 4.0)), (12, (2.0, 6.0)), (13, (4.0, 8.0)), (14, (0.0
     recs, bad, paths = fz.run_sweep(count, seed, ctx, budget_s=150, verbose=False, log_kappa=lk)
     exc = sum(r[7] for r in recs)
     worst = max([r[0] for r in recs if not r[7]] + [0.0])
-    print("seed %d log10 kappa %s: %d problems, paths (Gram, rejected) %s, cqr2 so far %d, violations %d, excused %d, worst accepted %.2e"
-          % (seed, lk, len(recs), paths, ctx.cqr2_stats(), len(bad), exc, worst), flush=True)
+    print("seed %d log10 kappa %s: %d problems, paths (Gram, rejected) %s, cqr2 so far %d, csne (routed, delivered, declined) so far %s, "
+          "violations %d, excused %d, worst accepted %.2e"
+          % (seed, lk, len(recs), paths, ctx.cqr2_stats(), ctx.csne_stats(), len(bad), exc, worst), flush=True)
     for v in bad:
         print("  VIOLATION case %d %s %s b=%d err %.2e oracle-move %.2e mask_ok %s mask_stable %s" % v)
     tot_bad += len(bad)
