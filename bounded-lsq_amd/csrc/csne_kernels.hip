@@ -333,7 +333,7 @@ __global__ __launch_bounds__(TRI_NT) void csne_fix_kernel(CsneState cs, TrfState
   extern __shared__ double sh[];
   __shared__ double red[32];
   __shared__ double scr[TRI_NW * 16];
-  __shared__ double kphi[CSNE_MAXE], kdphi[CSNE_MAXE], kddphi[CSNE_MAXE], kalpha[CSNE_MAXE], keta[CSNE_MAXE];
+  __shared__ double kphi[CSNE_MAXE], kdphi[CSNE_MAXE], kddphi[CSNE_MAXE], keta[CSNE_MAXE];
   const int li = blockIdx.x;
   const int b = cs.list[li];
   const int tid = threadIdx.x;
@@ -392,7 +392,6 @@ __global__ __launch_bounds__(TRI_NT) void csne_fix_kernel(CsneState cs, TrfState
       const double pMp = (2.0 * pw - (bk + wdw)) - 2.0 * zr;   // p^T M^-1 p to first order
       const double e1 = fabs(2.0 * wr) / pp, e2 = fabs(pMp - pw) / fabs(pw);
       if (tid == 0) {
-        kalpha[k] = cs.ralpha[(long)b * CSNE_MAXE + k];
         kphi[k] = pn - Delta;
         kdphi[k] = -pMp / pn;
         // phi'' = (w.w + 2 p.z) / |p| - (p.w)^2 / |p|^3 with p.z = p^T M^-1 w = w.w (M symmetric): from the cheap vectors

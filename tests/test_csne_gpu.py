@@ -338,3 +338,35 @@ def test_alternating_conditioning_classes_on_one_plan(blsq_opt):
     for call, (a, b) in enumerate(zip(*runs)):
         for x1, x0 in zip(a, b):
             assert np.array_equal(x1, x0), call
+
+
+@pytest.mark.parametrize("scale_mode", [1, 2])
+def test_jac_scaling_on_the_tier(scale_mode):
+    """scaling='jac' (trf.py:216-219, 239-242): scale = 1 / ||J_j|| (mode 1) resp. min(scale, 1 / ||J_j||) (mode 2) from
+    the Gram's diagonal; the tier's pass multiplies J by d = sqrt(v) scale (J_h = J D).  Badly scaled columns on top of
+    an ill-conditioned J."""
+    import bounded_lsq as bl
+    from bounded_lsq import _abi, _synth
+    from oracle import blsq_oracle as orc
+    rng = np.random.default_rng(8)
+    B, m, n = 4, 1200, 110
+    P = _synth.trf_batch(19, B, m, n, unbounded=True)
+    P["J"] = logspaced(rng, B, m, n, 4e3) * 10.0 ** rng.uniform(-2, 2, size=(B, 1, n))
+    scale0 = np.full((B, n), 1.0) if scale_mode == 1 else rng.uniform(0.5, 2.0, (B, n)) / np.linalg.norm(P["J"], axis=1)
+    Delta = np.array([10.0, 0.5, 0.05, 1e9])
+    ctx = _abi.Context(0)
+    sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
+    ctx.csne_stats(reset=True)
+    F = sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], scale0.copy(), scale_mode=scale_mode)
+    scale = F.scale
+    S = sol.step(Delta, np.zeros(B))
+    stats = ctx.csne_stats()
+    sol.close(); ctx.close()
+    assert stats[0] >= B - 1 and stats[2] == 0, stats          # (column scaling changes nothing for the equilibrated system)
+    for b in range(B):
+        jn = np.linalg.norm(P["J"][b], axis=0)
+        sc = 1.0 / jn if scale_mode == 1 else np.minimum(scale0[b], 1.0 / jn)
+        _, So = orc.trf_step_solve(P["J"][b], P["f"][b], P["x"][b], P["lb"][b], P["ub"][b], sc, Delta[b], 0.0)
+        assert rel(S.step[b], So.step) < RTOL, (b, rel(S.step[b], So.step))
+        assert int(S.n_iter[b]) == So.n_iter
+        np.testing.assert_allclose(scale[b], sc, rtol=1e-12)
