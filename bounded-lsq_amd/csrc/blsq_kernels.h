@@ -279,6 +279,8 @@ hipError_t launch_csne_select_dog(const CsneState& cs, int m, const int* ncols, 
                                   const double* k2, const double* pmin, const double* colinfo, hipStream_t s);
 // (dvec == nullptr: J_h = J, no column scaling — dogbox)
 hipError_t launch_csne_pass(const CsneState& cs, const double* dvec, int count, hipStream_t s);
+// the same sums with the dot products on the FP64 MFMA pipe (TRF; cs.NE = CSNE_MAXE: all eight evaluation slots)
+hipError_t launch_csne_pass_mfma(const CsneState& cs, const double* dvec, int count, hipStream_t s);
 // dogbox on the tier: the Gauss-Newton step of the free block, lstsq(J_free, -f) (dogbox.py:197), is ONE
 // solve — corrected at FACTOR time: scatter the cheap step into a full-length vector (the recording of the pass), the
 // pass, then  newton += -(X^T X)^-1 J_free^T (J_free newton + f)  with the free block's factor X

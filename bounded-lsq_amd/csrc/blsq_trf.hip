@@ -615,7 +615,8 @@ int trf_csne_correct(blsq_trf_plan* p, const double* dDelta, const double* dalph
   blsq_ctx* ctx = p->ctx;
   CsneState& cs = p->cs;
   const int ne_max = std::min(CSNE_MAXE, 1 + std::max(0, p->lm_rounds_done));
-  const int NE = csne_launch_evals(ne_max);               // (the launch's split over the waves: NEH x G >= ne_max)
+  const bool mfma = ctx->opt.on(OPT_CSNE_MFMA);           // (all eight evaluation slots; the sums do not depend on the depth)
+  const int NE = mfma ? CSNE_MAXE : csne_launch_evals(ne_max);   // (else the launch's split over the waves: NEH x G >= ne_max)
   cs.NE = NE;
   const size_t need = (size_t)p->ncsne * cs.nchunk * ((size_t)NE * p->ld + 16);
   if (need > p->cs_part_cap) {                            // (grows geometrically; hipFree waits for the stream)
@@ -628,7 +629,8 @@ int trf_csne_correct(blsq_trf_plan* p, const double* dDelta, const double* dalph
   }
   HIPCHK(ctx, hipMemsetAsync(cs.counts + 1, 0, sizeof(int), ctx->stream));
   ctx->begin(K_CSNE_PASS);
-  hipError_t e = launch_csne_pass(cs, p->st.d, p->ncsne, ctx->stream);
+  hipError_t e = mfma ? launch_csne_pass_mfma(cs, p->st.d, p->ncsne, ctx->stream)
+                      : launch_csne_pass(cs, p->st.d, p->ncsne, ctx->stream);
   ctx->end();
   if (e != hipSuccess) return ctx->fail(e, "launch_csne_pass");
   ctx->begin(K_CSNE_FIX);

@@ -244,6 +244,205 @@ __global__ __launch_bounds__(CS_NT, BLSQ_CS_WGS_PER_CU) void csne_pass_kernel(Cs
   }
 }
 
+// ---- the pass over J on the matrix pipe (TRF) ------------------------------------------------------------
+// The kernel above spends most of its issue slots on the 64-lane totals of its dot products (VALU-issue-bound at six
+// evaluations: 1.37 ms against the 0.63 ms the same kernel needs with ONE vector, i.e. the streaming rate).  Here
+// both products of a 16-row tile are small GEMMs on the FP64 MFMA pipe (v_mfma_f64_16x16x4):
+//   T = J_tile V          V = [d p~_0, d w~_0, d p~_1, ...]: sixteen columns = eight evaluations; the reduction over
+//                         the columns happens inside the instruction;
+//   Y += U^T J_tile       U = T (+ f on the even columns): T lands in the accumulator layout (lane (lr, lc), element g:
+//                         row 4 g + lr, vector lc), which IS the A-operand layout of U^T for k-step g — no shuffle;
+//                         b_e += t^2 on the odd columns, lane-local.  (The rows of Y that belong to the w~ are computed
+//                         and dropped: the pipe has the room.)
+// The four waves of a workgroup work on the SAME tile, each on its own slice of 16 NST columns: a wave stages its slice
+// in its own LDS region (the next tile's rows already requested into registers), holds its part of V in registers as B operands, computes the
+// partial T of its columns, and the four partial sums meet in LDS — one barrier per tile, the exchange area double
+// buffered — before every wave multiplies the full U into its own columns of Y.  Small per-wave state (164 registers,
+// 8 KB of LDS), so three workgroups share a CU and one wave's waits hide under the others' products.
+// Sums are defined by the tiles: T = ((P_0 + P_1) + P_2) + P_3 over the waves' column slices (each: k-steps of even
+// index in one accumulator, odd in the other, a0 + a1), Y and b summed over a chunk's tiles in order — nothing depends
+// on how many evaluations the launch carries.
+static constexpr int CSM_TR = 16;                         // rows per tile
+// row stride of a wave's slice: = 18 mod 32 doubles, so that the A fragments J[row lc][4 s + lr] of the first product
+// hit disjoint banks and the B fragments J[row 4 g + lr][16 c + lc] of the second nearly so
+// Measured at 512 x (4096 x 256), six evaluations (the vector-ALU kernel: 1.37 ms): 2 workgroups per CU and 2 tiles
+// ahead 0.89 ms, 2 and 1: 0.91 ms, 3 and 1 (164 registers, 50 KB of LDS): 0.81 ms.
+#ifndef BLSQ_CSM_OCC
+#define BLSQ_CSM_OCC 3                                    // workgroups per CU the kernel is built for
+#endif
+#ifndef BLSQ_CSM_PF
+#define BLSQ_CSM_PF 1                                     // tiles requested ahead (register sets)
+#endif
+__host__ __device__ constexpr int csm_stride(int NST) { return NST <= 3 ? 50 : (BLSQ_CSM_OCC >= 3 ? 66 : 82); }
+template <int NST>
+__global__ __launch_bounds__(CS_NT, BLSQ_CSM_OCC) void csne_pass_mfma_kernel(CsneState cs, const double* __restrict__ dvec) {
+  constexpr int PF = BLSQ_CSM_PF;
+  constexpr int NK = 4 * NST;                             // k-steps of four columns in a wave's slice
+  constexpr int SW = 16 * NST;                            // columns of a slice
+  constexpr int S = csm_stride(NST);
+  constexpr int NE = CSNE_MAXE;                           // vector slots: 2 NE = 16 = the MFMA's columns
+  extern __shared__ double lds[];
+  const int li = blockIdx.y, chunk = blockIdx.x;
+  const int b = cs.list[li];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane >> 4, lc = lane & 15;
+  const int n = cs.n, ld = cs.ld;
+  const int r0 = chunk * cs.rows_per_wg;
+  const int r1 = (r0 + cs.rows_per_wg < cs.m) ? r0 + cs.rows_per_wg : cs.m;
+  const int c0 = w * SW;                                  // first column of this wave's slice
+  const double* __restrict__ Jb = cs.J + (long)b * cs.strideJ;
+  const double* __restrict__ Fb = cs.F + (long)b * cs.strideF;
+  int ne = cs.ne[b];
+  if (ne > NE) ne = NE;                                   // (deeper recordings are declined by csne_fix_kernel)
+  double* X = lds + (size_t)w * (CSM_TR * S);             // this wave's slice of the tile [16][S]
+  double* E = lds + (size_t)CS_NW * (CSM_TR * S);         // partial T: [parity][wave][g][lane]
+  // B operands of the first product: V[col = c0 + 4 s + lr][vec = lc]; vec 2 e = d p~_e, vec 2 e + 1 = d w~_e (the
+  // LAST evaluation recorded p~ only); zero beyond column n
+  double Vb[NK];
+  {
+    const int e = lc >> 1, c = lc & 1;
+    const bool have = e < ne && !(c == 1 && e == ne - 1);
+    const double* rv = cs.rvec + (((long)b * CSNE_MAXE + e) * 3 + c) * ld;
+    const double* dv = dvec + (long)b * ld;
+#pragma unroll
+    for (int s_ = 0; s_ < NK; ++s_) {
+      const int col = c0 + 4 * s_ + lr;
+      const int cc = col < n ? col : n - 1;
+      const double v = dv[cc] * rv[cc];
+      Vb[s_] = (have && col < n) ? v : 0.0;
+    }
+  }
+  for (int i = lane; i < CSM_TR * S; i += WAVE) X[i] = 0.0;   // (the padding columns are read by nobody; keep them finite)
+  v4d yacc[NST];
+#pragma unroll
+  for (int c = 0; c < NST; ++c) yacc[c] = v4d{0.0, 0.0, 0.0, 0.0};
+  double accB = 0.0;
+  const int ntile = (r1 - r0 + CSM_TR - 1) / CSM_TR;
+  // staging: lane l < SW owns column c0 + l; PF tiles ahead
+  const int mycol = c0 + lane;
+  const bool colin = lane < SW && mycol < n;
+  const bool allin = c0 + SW <= n;                        // (uniform: the whole slice lies inside the matrix)
+  const double* __restrict__ Jc = Jb + (colin ? mycol : (n - 1));
+  const long ldj = cs.ldJ;
+  double jr[PF][CSM_TR], fr[PF][4];
+  auto request = [&](int tl, auto setc) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value;
+    const int rb = r0 + tl * CSM_TR;
+    if (rb + CSM_TR <= r1) {                              // (uniform) a full tile: no clamping
+      const double* rp = Jc + (long)rb * ldj;
+#pragma unroll
+      for (int r = 0; r < CSM_TR; ++r) jr[set][r] = __builtin_nontemporal_load(rp + r * ldj);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) fr[set][g] = Fb[rb + 4 * g + lr];
+    } else {
+#pragma unroll
+      for (int r = 0; r < CSM_TR; ++r) {
+        const int row = rb + r;
+        jr[set][r] = __builtin_nontemporal_load(Jc + (long)(row < r1 ? row : r1 - 1) * ldj);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int row = rb + 4 * g + lr;
+        fr[set][g] = Fb[row < r1 ? row : r1 - 1];
+      }
+    }
+  };
+  auto tile = [&](int ti, auto setc) __attribute__((always_inline)) {
+    constexpr int set = decltype(setc)::value;
+    const int rb = r0 + ti * CSM_TR;
+    // commit the slice (rows beyond the chunk and columns beyond n: zero), request the tile PF ahead
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (this wave's reads of the last tile are done)
+    double fv[4];
+    if (allin && rb + CSM_TR <= r1) {                     // (uniform)
+      if (SW == WAVE || lane < SW) {
+#pragma unroll
+        for (int r = 0; r < CSM_TR; ++r) X[r * S + lane] = jr[set][r];
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) fv[g] = fr[set][g];
+    } else {
+      if (lane < SW) {
+#pragma unroll
+        for (int r = 0; r < CSM_TR; ++r) X[r * S + lane] = (colin && rb + r < r1) ? jr[set][r] : 0.0;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) fv[g] = (rb + 4 * g + lr < r1) ? fr[set][g] : 0.0;
+    }
+    if (ti + PF < ntile) request(ti + PF, setc);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // partial T of this wave's columns
+    v4d acc[2] = {v4d{0.0, 0.0, 0.0, 0.0}, v4d{0.0, 0.0, 0.0, 0.0}};
+    const double* Xa = X + lc * S + lr;                   // A[row = lc][k = lr] of k-step 0
+#pragma unroll
+    for (int s_ = 0; s_ < NK; ++s_) acc[s_ & 1] = gmfma(Xa[4 * s_], Vb[s_], acc[s_ & 1]);
+    double* Ew = E + ((size_t)(ti & 1) * CS_NW + w) * (4 * WAVE);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) Ew[g * WAVE + lane] = acc[0][g] + acc[1][g];
+    __syncthreads();
+    // u = T + f on the even vectors, b += t^2 on the odd ones (wave 0 keeps b)
+    const double* Er = E + (size_t)(ti & 1) * CS_NW * (4 * WAVE) + lane;
+    double u[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const double t = ((Er[g * WAVE] + Er[(4 + g) * WAVE]) + Er[(8 + g) * WAVE]) + Er[(12 + g) * WAVE];
+      u[g] = (lc & 1) ? t : t + fv[g];
+      accB = (lc & 1) ? fma(t, t, accB) : accB;
+    }
+    // Y += U^T J_tile for this wave's columns: k-step g covers rows 4 g .. 4 g + 3
+    const double* Xb = X + lr * S + lc;                   // B[k = lr][j = lc] of k-step 0, column tile 0
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int c = 0; c < NST; ++c) yacc[c] = gmfma(u[g], Xb[4 * g * S + 16 * c], yacc[c]);
+  };
+  static_for<0, PF>([&](auto pc) __attribute__((always_inline)) {
+    if (decltype(pc)::value < ntile) request(decltype(pc)::value, pc);
+  });
+  for (int ti = 0; ti < ntile; ti += PF) {                // (every wave runs every tile: the barriers match)
+    static_for<0, PF>([&](auto pc) __attribute__((always_inline)) {
+      if (ti + decltype(pc)::value < ntile) tile(ti + decltype(pc)::value, pc);
+    });
+  }
+  // yacc[c], lane (lr, lc), element g: Y[vec 4 g + lr][col c0 + 16 c + lc]; vec 2 e: lr in {0, 2}, e = 2 g + lr / 2
+  double* out = cs.part + ((long)li * cs.nchunk + chunk) * csne_part_stride(NE, ld);
+  if ((lr & 1) == 0) {
+#pragma unroll
+    for (int c = 0; c < NST; ++c) {
+      const int col = c0 + 16 * c + lc;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (col < n) out[(long)(2 * g + (lr >> 1)) * ld + col] = yacc[c][g];
+    }
+  }
+  __syncthreads();                                        // (the exchange area is done with)
+  if (w == 0) E[lane] = accB;
+  __syncthreads();
+  if (tid < NE) {                                         // b_e: lanes (lr, lc = 2 e + 1) of wave 0, lr in order
+    const double* s4 = E + 2 * tid + 1;
+    out[(long)NE * ld + tid] = ((s4[0] + s4[16]) + s4[32]) + s4[48];
+  }
+}
+
+template <int NST>
+static hipError_t csne_pass_mfma_launch(const CsneState& cs, const double* dvec, int count, hipStream_t s) {
+  const size_t lds = sizeof(double) * ((size_t)CS_NW * CSM_TR * csm_stride(NST) + 2 * CS_NW * 4 * WAVE);
+  static std::atomic<size_t> granted[64];
+  hipError_t ge = gram_grant_lds(csne_pass_mfma_kernel<NST>, lds, granted);
+  if (ge != hipSuccess) return ge;
+  hipLaunchKernelGGL((csne_pass_mfma_kernel<NST>), dim3(cs.nchunk, count), dim3(CS_NT), lds, s, cs, dvec);
+  return hipGetLastError();
+}
+// cs.NE must be CSNE_MAXE (the partial sums carry all eight evaluation slots, whatever the batch's depth)
+hipError_t launch_csne_pass_mfma(const CsneState& cs, const double* dvec, int count, hipStream_t s) {
+  if (count <= 0) return hipSuccess;
+  if (cs.NE != CSNE_MAXE || !dvec) return hipErrorInvalidValue;
+  const int nst = (cs.n + 63) / 64;                       // column tiles of sixteen per wave
+  if (nst <= 2) return csne_pass_mfma_launch<2>(cs, dvec, count, s);
+  if (nst == 3) return csne_pass_mfma_launch<3>(cs, dvec, count, s);
+  if (nst == 4) return csne_pass_mfma_launch<4>(cs, dvec, count, s);
+  return hipErrorInvalidValue;
+}
+
 // the split of a launch that carries NE evaluations: (NEH, G) with NEH G >= NE.  Measured (512 problems of 4096 x 256,
 // six evaluations): one group 1.51 ms, two groups of three evaluations 1.66 ms — the kernel is bound by the bytes a CU
 // keeps in flight (four waves x one batch of 8 KB: what the loaded latency lets through), and a row requested by two

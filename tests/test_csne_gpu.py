@@ -72,6 +72,26 @@ def test_unbounded_ill_conditioned_problems_take_the_tier(m, n, kappa):
     print("worst step error", w)
 
 
+@pytest.mark.parametrize("mfma", [1, 0])
+@pytest.mark.parametrize("m,n", [(1000, 81), (1237, 130), (531, 193), (2050, 250), (4096, 256)])
+def test_both_pass_kernels_on_ragged_shapes(m, n, mfma, blsq_opt):
+    """The pass over J exists twice — the MFMA kernel (16-row tiles, four column slices) and the vector-ALU kernel
+    (option csne_mfma = 0) — and both handle a last tile of fewer than sixteen rows, column counts that are odd or no
+    multiple of the slice width, and chunks of unequal length.  The batch mixes depths of the recording."""
+    from bounded_lsq import _synth
+    blsq_opt("csne_mfma", mfma)
+    rng = np.random.default_rng(m + n)
+    B = 3
+    P = _synth.trf_batch(n, B, m, n, unbounded=True)
+    P["J"] = logspaced(rng, B, m, n, 4e3)
+    Delta = np.array([0.02, 1.0, 1e6])
+    stats, S = run_trf(P, Delta)
+    assert stats["csne"] == (B, B, 0) and stats["cqr2"] == 0, stats
+    w = check(P, Delta, S)
+    print("mfma", mfma, "worst step error", w, "iterations", S.n_iter)
+    assert len(set(int(k) for k in S.n_iter)) > 1             # (different depths in one launch)
+
+
 def test_problems_beyond_the_tiers_measured_bound_go_on_to_the_next_tier():
     """kappa(J) = 3e5 .. 1e6: the certificate's bound is above CSNE_K2_MAX or the measured first-order correction above
     CSNE_ETA_MAX — the problem is declined (at factor or at step time) and CholeskyQR2 / the tree deliver the step."""

@@ -12,7 +12,8 @@ pass() {
 }
 pass mix SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES || exit 1
 pass act SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_WAVE_CYCLES || exit 1
-python3 - $O/${TAG}_pc_mix $O/${TAG}_pc_act <<'PY' | tee $O/${TAG}_pmc_csne.txt
+pass mfma SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CYCLES || echo "(no mfma pass)"
+python3 - $O/${TAG}_pc_mix $O/${TAG}_pc_act $O/${TAG}_pc_mfma <<'PY' | tee $O/${TAG}_pmc_csne.txt
 import csv, glob, sys
 for d in sys.argv[1:]:
     acc = {}
