@@ -856,6 +856,13 @@ def main():
                     cb["t"] += time.perf_counter() - t_
                     return r_
                 kw1 = dict(jac=jac1, bounds=(P1["lb"][0] - 1.0, P1["ub"][0] + 1.0), method="trf", max_nfev=12)
+                # (the callbacks' BLAS on ONE thread: a 4096 x 256 matvec gains nothing from 64, and a pool of spinning
+                #  BLAS threads on the job's 16-CPU share delays the library's own host thread by milliseconds)
+                try:
+                    import threadpoolctl
+                    blas1 = threadpoolctl.threadpool_limits(limits=1)
+                except Exception:                              # noqa: BLE001
+                    blas1 = None
                 bounded_lsq.least_squares(fun1, x1 + 0.01, **kw1)          # (warm: code objects, allocator)
                 t0 = time.perf_counter()
                 sol1 = bounded_lsq.TrfStepSolver(1, m, n)                  # what every solve pays once: its plan
@@ -866,12 +873,26 @@ def main():
                 r1 = bounded_lsq.least_squares(fun1, x1 + 0.01, **kw1)
                 e1 = time.perf_counter() - t0
                 ecb = cb["t"]
+                best = (e1 - ecb, e1, ecb, r1)
+                for _ in range(4):                              # (best of five solves: the box's host share is noisy)
+                    cb["t"] = 0.0
+                    t0 = time.perf_counter()
+                    r1 = bounded_lsq.least_squares(fun1, x1 + 0.01, **kw1)
+                    e1 = time.perf_counter() - t0
+                    if e1 - cb["t"] < best[0]:
+                        best = (e1 - cb["t"], e1, cb["t"], r1)
+                _, e1, ecb, r1 = best
+                if blas1 is not None:
+                    blas1.restore_original_limits()
                 extras["least_squares_single_4096x256"] = {
                     "nfev": int(r1.nfev), "njev": int(r1.njev), "status": int(r1.status), "total_ms": 1e3 * e1,
                     "callbacks_ms": 1e3 * ecb, "plan_create_ms": 1e3 * eplan,
-                    "ms_per_iteration_excluding_callbacks_and_plan": 1e3 * (e1 - ecb - eplan) / max(1, int(r1.njev)),
+                    "plan_pooled": True, "solves": 5, "callbacks_blas_threads": 1 if blas1 is not None else None,
+                    "ms_per_iteration_excluding_callbacks_and_plan": 1e3 * (e1 - ecb) / max(1, int(r1.njev)),
                     "note": "bounded_lsq.least_squares (sequential host driver, numpy callbacks): wall time per outer "
-                            "iteration = H2D of the 8 MiB Jacobian + factor + inner steps + result fetches"}
+                            "iteration = H2D of the 8 MiB Jacobian + factor + inner steps + result fetches; the plan "
+                            "is leased from the context's pool (created by the warm call: plan_create_ms is what a "
+                            "first solve of a shape pays once, nothing is subtracted for it here)"}
             except Exception as exc:                           # noqa: BLE001
                 extras["least_squares_single_4096x256"] = {"error": str(exc)[:200]}
         if not args.no_side:

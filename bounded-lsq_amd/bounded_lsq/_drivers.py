@@ -12,7 +12,7 @@ from numpy.linalg import norm
 from scipy.optimize import OptimizeResult
 
 from ._hip_step import (TrfStepSolver, DogboxStepSolver, SCALE_GIVEN, SCALE_JAC_INIT,
-                        SCALE_JAC_UPDATE)
+                        SCALE_JAC_UPDATE, lease_solver, return_solver)
 from ._hostmath import shift_into_interior, active_mask, cl_vector
 
 EPS = np.finfo(float).eps
@@ -44,7 +44,7 @@ def trf(fun, jac, x0, lb, ub, ftol, xtol, gtol, max_nfev, scaling, ctx=None):
         raise RuntimeError("Inconsistent dimensions between the returns of "
                            "`fun` and `jac` on the first iteration.")
     m, n = J.shape
-    solver = TrfStepSolver(1, m, n, ctx=ctx)
+    solver = lease_solver(TrfStepSolver, 1, m, n, ctx=ctx)
     try:
         use_jac = _is_jac(scaling)
         scale = np.ones(n) if use_jac else 1 / np.asarray(scaling, dtype=float)
@@ -115,7 +115,7 @@ def trf(fun, jac, x0, lb, ub, ftol, xtol, gtol, max_nfev, scaling, ctx=None):
             active_mask=active_mask(x, lb, ub, rtol=xtol), nfev=nfev, njev=njev, status=0,
             x_covariance=None)
     finally:
-        solver.close()
+        return_solver(solver)
 
 
 def dogbox(fun, jac, x0, lb, ub, ftol, xtol, gtol, max_nfev, scaling, ctx=None):
@@ -128,7 +128,7 @@ def dogbox(fun, jac, x0, lb, ub, ftol, xtol, gtol, max_nfev, scaling, ctx=None):
         raise RuntimeError("Inconsistent dimensions between the returns of "
                            "`fun` and `jac` on the first iteration.")
     m, n = J.shape
-    solver = DogboxStepSolver(1, m, n, ctx=ctx)
+    solver = lease_solver(DogboxStepSolver, 1, m, n, ctx=ctx)
     try:
         use_jac = _is_jac(scaling)
         scale = np.ones(n) if use_jac else 1 / np.asarray(scaling, dtype=float)
@@ -200,4 +200,4 @@ def dogbox(fun, jac, x0, lb, ub, ftol, xtol, gtol, max_nfev, scaling, ctx=None):
             x=x, fun=f, jac=J, obj_value=obj_value, optimality=g_norm, active_mask=on_bound,
             nfev=nfev, njev=njev, status=0, x_covariance=None)
     finally:
-        solver.close()
+        return_solver(solver)

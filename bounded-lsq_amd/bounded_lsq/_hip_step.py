@@ -9,6 +9,7 @@ expose the two-call seam of the reference drivers:
 All arithmetic happens in libblsq_hip.so on the GPU.
 """
 import ctypes as C
+import threading
 from collections import namedtuple
 
 import numpy as np
@@ -36,6 +37,45 @@ def default_context(device_id=0):
     if c is None:
         c = _default_ctx[device_id] = _abi.Context(device_id)
     return c
+
+
+# ---- plans of the sequential drivers: leased, not created per solve ---------------------------------------
+# A plan (device buffers for one (B, m, n)) costs ~0.9 ms to create and ~0.3 ms to destroy — beside a 4096 x 256 solve
+# of five iterations that is a fifth of the library's own time.  The drop-in drivers (`_drivers.trf / dogbox`) lease
+# theirs from a small per-context pool: a solve of a shape seen before reuses the plan of the last one.  A plan's
+# history decides which launches a call enqueues, never a number it returns (tests/test_drivers_gpu.py).
+PLAN_POOL_KEEP = 4                     # plans a context keeps between solves (0: create / destroy per solve)
+PLAN_POOL_MAX_BYTES = 64 << 20         # ... of problems up to this size of [J] only
+_pool_lock = threading.Lock()
+
+
+def lease_solver(cls, B, m, n, ctx=None):
+    """A solver of class `cls` for (B, m, n) on `ctx`: one the pool holds, or a new one."""
+    ctx = ctx or default_context()
+    with _pool_lock:
+        pool = ctx.__dict__.setdefault("_solver_pool", [])
+        for i in range(len(pool) - 1, -1, -1):
+            s = pool[i]
+            if not s.h:                                        # (closed with its context, or by hand)
+                del pool[i]
+            elif type(s) is cls and (s.B, s.m, s.n) == (int(B), int(m), int(n)):
+                return pool.pop(i)
+    return cls(B, m, n, ctx=ctx)
+
+
+def return_solver(s):
+    """Back to its context's pool (the least recently returned plan leaves when the pool is full)."""
+    ctx = s.ctx
+    if (not s.h or not getattr(ctx, "h", None) or PLAN_POOL_KEEP <= 0
+            or 8 * s.B * s.m * s.n > PLAN_POOL_MAX_BYTES):
+        s.close()
+        return
+    with _pool_lock:
+        pool = ctx.__dict__.setdefault("_solver_pool", [])
+        pool.append(s)
+        out, pool[:] = pool[:-PLAN_POOL_KEEP], pool[-PLAN_POOL_KEEP:]
+    for o in out:
+        o.close()
 
 
 STATUS_MESSAGES = {1: "`s` is zero.",                            # trust_region.py:28-29

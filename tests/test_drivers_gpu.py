@@ -469,3 +469,60 @@ def test_suite58_family_through_the_device_driver():
             if rec.get("stable"):
                 assert (r.nfev, r.njev, r.status) == (rec["nfev"], rec["njev"], rec["status"]), p["name"]
                 np.testing.assert_allclose(r.x, unh(rec["x"]), rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.parametrize("method", ["trf", "dogbox"])
+def test_sequential_drivers_lease_their_plans_from_a_pool(method):
+    """The drop-in drivers do not create and destroy a plan per solve: a solve of a shape seen before reuses the plan
+    of the last one (`_hip_step.lease_solver / return_solver`).  A plan's history — other problems, other conditioning,
+    an exception in the middle of a solve — never changes a number: every result equals the one of a fresh context
+    bit for bit; the pool stays bounded and closes with its context."""
+    import bounded_lsq as bl
+    from bounded_lsq import _abi, _hip_step
+    f1, j1 = expfit_problem(E2E["expfit_seed"])
+    lo, hi = EXPFIT_BOX
+    kw = dict(bounds=(lo, hi), method=method)
+
+    def solve(ctx, fun, jac, x0):
+        return bl.least_squares(fun, x0, jac, options={"ctx": ctx}, **kw)
+
+    def solve_rosen(ctx):
+        return bl.least_squares(rosen, [-2.0, 1.0], rosen_jac, method=method, options={"ctx": ctx})
+
+    fresh = []
+    for which in (0, 1):
+        c = _abi.Context(0)
+        fresh.append(solve(c, f1, j1, EXPFIT_X0) if which == 0 else solve_rosen(c))
+        c.close()
+    ctx = _abi.Context(0)
+    r1 = solve(ctx, f1, j1, EXPFIT_X0)
+    pool = ctx.__dict__["_solver_pool"]
+    assert len(pool) == 1
+    h1 = pool[0].h.value
+    r2 = solve_rosen(ctx)                                                             # another shape: another plan
+    assert len(pool) == 2
+    with pytest.raises(ZeroDivisionError):                                            # a solve that dies half way
+        calls = {"n": 0}
+
+        def bad(x):
+            calls["n"] += 1
+            if calls["n"] > 2:
+                raise ZeroDivisionError
+            return f1(x)
+        solve(ctx, bad, j1, EXPFIT_X0)
+    assert len(pool) == 2
+    r3 = solve(ctx, f1, j1, EXPFIT_X0)                                                # the first plan again
+    assert len(pool) == 2 and any(s.h.value == h1 for s in pool)
+    for a, b in ((r1, fresh[0]), (r3, fresh[0]), (r2, fresh[1])):
+        assert np.array_equal(a.x, b.x) and a.nfev == b.nfev and a.status == b.status
+        assert a.obj_value == b.obj_value and a.optimality == b.optimality
+    keep = _hip_step.PLAN_POOL_KEEP
+    rng = np.random.default_rng(3)
+    for k in range(keep + 3):                                                         # more shapes than the pool keeps
+        A = rng.standard_normal((6 + k, 3)); y = rng.standard_normal(6 + k)
+        bl.least_squares(lambda x, A=A, y=y: A @ x - y, np.zeros(3), lambda x, A=A: A, method=method,
+                         options={"ctx": ctx})
+    assert len(pool) == keep
+    held = list(pool)
+    ctx.close()
+    assert all(not s.h for s in held)
