@@ -33,6 +33,7 @@ const OptInfo kOptTable[OPT_COUNT] = {
   {"gram_direct_nw", "BLSQ_GRAM_DIRECT_NW", 0, "narrow problems: 2 | 4 | 8 waves per workgroup of the direct Gram kernel; 0: by the row count"},
   {"gram_direct_max_nt", "BLSQ_GRAM_DIRECT_MAX_NT", 4, "narrow problems: the direct (no LDS) Gram kernel up to this many column tiles; 0: never"},
   {"qr_cqr", "BLSQ_QR_CQR", 1, "Householder tree: panels by Cholesky-QR + Householder reconstruction where the pivot test allows; 0: column loop"},
+  {"gram1", "BLSQ_GRAM1", 1, "at most four (row chunk, problem) pairs, n a multiple of 16 in 80 .. 256: Gram with one tile per wave, operands straight from global memory; 0: tile groups through LDS (bit-identical)"},
   {"csne_mfma", "BLSQ_CSNE_MFMA", 1, "CSNE tier, TRF: the pass over J computes its dot products as 16-row MFMA tiles; 0: the vector-ALU kernel (a different summation order)"},
 };
 

@@ -38,6 +38,7 @@ enum Opt {
   OPT_GRAM_DIRECT_NW,      // narrow problems: waves per workgroup of the direct kernel (0: by the row count)
   OPT_GRAM_DIRECT_MAX_NT,  // narrow problems: the direct kernel up to this many column tiles (0: never)
   OPT_QR_CQR,              // Householder panels by Cholesky-QR + reconstruction where the pivot test allows; 0: column loop
+  OPT_GRAM1,               // a handful of problems: one Gram tile per wave straight from global memory; 0: tile groups
   OPT_CSNE_MFMA,           // CSNE pass of TRF plans with its dot products on the FP64 MFMA pipe; 0: the vector-ALU kernel
   OPT_COUNT
 };

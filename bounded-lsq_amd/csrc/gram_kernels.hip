@@ -829,6 +829,145 @@ __global__ __launch_bounds__(64 * NWD, (NTT <= 2 ? 4 : 2)) void gram_direct_kern
   }
 }
 
+// ---- a handful of problems (chunks x B <= 4), n a multiple of 16: one tile per wave, no LDS staging ---------------
+// One 4096 x 256 problem gives gram_kernel two row chunks: even split over 32 tile groups that is 64 workgroups whose
+// waves each run a chain of 512 k-steps through the LDS staging loop at ~800 cycles a step (0.17 ms, whatever the number
+// of groups).  Here a wave owns ONE output tile (i, j) of one row chunk and takes its two operand fragments
+// X[4 s + lr][16 i + lc], X[4 s + lr][16 j + lc] straight from global memory (L2 / MALL: every fragment is read by 16
+// tile jobs), BLSQ_G1_DEPTH k-steps ahead in registers; the rhs column is the job of four more workgroups per chunk whose
+// waves reproduce the generic kernel's sums — "wave" v adds the rows v, v + 8, ... of the chunk in order, the eight
+// partials are added in wave order.  A tile sees the same k-steps in the same order with the same instruction: the
+// result equals gram_kernel's bit for bit (tests/test_gram_gpu.py).
+// Measured, ONE problem of 4096 x 256 (tile groups through LDS: 171 us): 146 us with a branch per k-step in the loop,
+// 75 without, 61 with the row chunks dealt to the XCDs; by the depth of the prefetch 4 / 6 / 8 / 10 / 12 / 16 / 24 / 30
+// k-steps: 62 / 50 / 49 / 45 / 43 / 42 / 61 / 68 us (more requests in flight than the fabric takes queue up).
+#ifndef BLSQ_G1_DEPTH
+#define BLSQ_G1_DEPTH 16
+#endif
+static constexpr int G1_NW = 4, G1_NT = 64 * G1_NW;
+__global__ __launch_bounds__(G1_NT) void gram1_kernel(GramArgs a, int chunks, int nprob, int tile_wgs) {
+  constexpr int D = BLSQ_G1_DEPTH;
+  __shared__ double red[2 * G1_NW * 64 + 2 * G1_NW];
+  // Workgroups go to the eight XCDs round robin: the (row chunk, problem) pairs are dealt to the XCDs, so that an XCD's
+  // L2 sees the rows of ONE chunk (its waves walk them at the same pace: every line is fetched once per XCD).
+  const int groups = chunks * nprob;
+  const int xcd = (int)blockIdx.x % 8, slot = (int)blockIdx.x / 8;
+  const int group = xcd % groups, mg = (8 - group + groups - 1) / groups;
+  const int job = slot * mg + xcd / groups;
+  if (job >= tile_wgs + (a.n + 63) / 64) return;
+  const int pz = group / chunks;
+  const int b = a.list ? a.list[pz] : pz;
+  if (a.mask && a.mask[b] <= 1) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane >> 4, lc = lane & 15;
+  const int n = a.n, NTJ = n / 16;
+  const int chunk = group % chunks;
+  const int r_lo = chunk * a.rows_per_chunk;
+  int r_hi = r_lo + a.rows_per_chunk;
+  if (r_hi > a.m) r_hi = a.m;
+  const long bsrc = a.src_by_pos ? (long)pz : (long)b;
+  const double* Jb = a.J + bsrc * a.strideJ;
+  const double* Fb = a.F + bsrc * a.strideF;
+  const long ldJ = a.ldJ;
+  double* G = a.G + ((long)b * chunks + chunk) * (long)a.NPAD * a.NPAD;
+  if (job < tile_wgs) {
+    // ---- tile job: workgroup `job` owns four consecutive tiles (i, j0 .. j0 + 3) of ONE tile row — the four waves share the
+    // fragment of column tile i (one of them fetches a line, the others find it in the L1) and their own four are
+    // neighbours: rows 4 s .. 4 s + 3 are read as 512 contiguous bytes each
+    int i = 0, rem = job;
+    while (i < NTJ && rem >= (NTJ - i + G1_NW - 1) / G1_NW) { rem -= (NTJ - i + G1_NW - 1) / G1_NW; ++i; }
+    const int j = i + G1_NW * rem + w;
+    if (i >= NTJ || j >= NTJ) return;
+    const int nk = (r_hi - r_lo + 3) / 4;
+    const double* pa = Jb + 16 * i + lc;
+    const double* pb = Jb + 16 * j + lc;
+    const int last = r_hi - 1;
+    auto rowof = [&](int s_) { const int r = r_lo + 4 * s_ + lr; return r < r_hi ? r : last; };
+    double fa[D], fb[D];
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      const long ro = (long)rowof(u < nk ? u : 0) * ldJ;
+      fa[u] = pa[ro];
+      fb[u] = pb[ro];
+    }
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    for (int s0 = 0; s0 < nk; s0 += D) {
+#pragma unroll
+      for (int u = 0; u < D; ++u) {
+        // (no branch in here: the compiler counts the outstanding loads only along straight-line code — with a branch
+        //  per k-step it waited for ALL of them at every join, one memory round trip per k-step: 0.146 ms.  A k-step
+        //  beyond the chunk multiplies zeros, its request repeats the last row.)
+        const int s_ = s0 + u;
+        const bool in = r_lo + 4 * s_ + lr < r_hi;        // (rows beyond the chunk count as zeros)
+        const double av = in ? fa[u] : 0.0;
+        const double bv = in ? fb[u] : 0.0;
+        const int sn = s_ + D < nk ? s_ + D : nk - 1;
+        const long ro = (long)rowof(sn) * ldJ;
+        fa[u] = pa[ro];
+        fb[u] = pb[ro];
+        acc = gmfma(av, bv, acc);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) G[(long)(16 * i + lr + 4 * g) * a.NPAD + 16 * j + lc] = acc[g];
+    return;
+  }
+  // ---- rhs job: columns 64 cb + lane; wave w plays the generic kernel's waves w and w + 4 (rows v, v + 8, ... in order)
+  const int cb = job - tile_wgs;
+  const int col = 64 * cb + lane;
+  const int cc = col < n ? col : n - 1;
+  double gf0 = 0.0, gf1 = 0.0, gff0 = 0.0, gff1 = 0.0;
+  {
+    const double* pc = Jb + cc;
+    constexpr int U = 8;                                  // rows of each of the two sums in flight
+    for (int r0 = r_lo; r0 < r_hi; r0 += 8 * U) {
+      double jv0[U], jv1[U], fv0[U], fv1[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int ra = r0 + 8 * u + w, rb = ra + G1_NW;
+        const int rac = ra < r_hi ? ra : r_hi - 1, rbc = rb < r_hi ? rb : r_hi - 1;
+        jv0[u] = pc[(long)rac * ldJ]; fv0[u] = Fb[rac];
+        jv1[u] = pc[(long)rbc * ldJ]; fv1[u] = Fb[rbc];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int ra = r0 + 8 * u + w, rb = ra + G1_NW;
+        // (the generic kernel stages whole 32-row blocks: a row beyond the chunk enters its sums with f = 0)
+        const double f0 = ra < r_hi ? fv0[u] : 0.0, f1 = rb < r_hi ? fv1[u] : 0.0;
+        const bool live0 = ra < r_lo + ((r_hi - r_lo + GR_RC - 1) / GR_RC) * GR_RC;
+        const bool live1 = rb < r_lo + ((r_hi - r_lo + GR_RC - 1) / GR_RC) * GR_RC;
+        if (live0) { gf0 = fma(jv0[u], f0, gf0); gff0 = fma(f0, f0, gff0); }
+        if (live1) { gf1 = fma(jv1[u], f1, gf1); gff1 = fma(f1, f1, gff1); }
+      }
+    }
+  }
+  red[w * 64 + lane] = gf0;
+  red[(w + G1_NW) * 64 + lane] = gf1;
+  if (lane == 0) { red[2 * G1_NW * 64 + w] = gff0; red[2 * G1_NW * 64 + G1_NW + w] = gff1; }
+  __syncthreads();
+  if (w == 0) {
+    double sum = 0.0;
+#pragma unroll
+    for (int ww = 0; ww < 2 * G1_NW; ++ww) sum += red[ww * 64 + lane];
+    if (col < n) G[(long)col * a.NPAD + n] = sum;
+  }
+  if (cb == 0) {
+    if (tid == 0) {
+      double sum = 0.0;
+#pragma unroll
+      for (int ww = 0; ww < 2 * G1_NW; ++ww) sum += red[2 * G1_NW * 64 + ww];
+      G[(long)n * a.NPAD + n] = sum;
+    }
+    // the rest of the rhs tile column of the slot: padding columns (n, 16 NT) stay zero
+    const int N = n + 1, NT = (N + 15) / 16;
+    for (int e = tid; e < a.NPAD * (16 * NT - N); e += G1_NT) {
+      const int r = e / (16 * NT - N), c = N + e % (16 * NT - N);
+      if ((r >> 4) <= (c >> 4)) G[(long)r * a.NPAD + c] = 0.0;
+    }
+  }
+}
+
 // partial Grams of the row chunks -> the triangle slot (fixed order: deterministic)
 __global__ void gram_reduce_kernel(const double* Gpart, int chunks, int NPAD, double* Gout,
                                    const int* mask) {
@@ -971,6 +1110,18 @@ hipError_t launch_gram(const GramArgs& a_in, int chunks, int B, hipStream_t s, d
       }
       return hipGetLastError();
     }
+  }
+  // a handful of problems, rhs column outside the tiles, widths whose sums the tile-table kernel defines: one tile per wave
+  // straight from global memory (bit-identical; option gram1 = 0: the tile groups below)
+  if (a.rhs_valu && (long)chunks * B <= 4 && NTJ > opt.i(OPT_GRAM_DIRECT_MAX_NT) && NTJ > 4 && !(NTJ == 8 && opt.on(OPT_GRAM8)) &&
+      NTJ <= 16 && opt.on(OPT_GRAM1)) {
+    int tile_wgs = 0;
+    for (int i = 0; i < NTJ; ++i) tile_wgs += (NTJ - i + G1_NW - 1) / G1_NW;
+    const int rhs_wgs = (a.n + 63) / 64;
+    const int groups = chunks * B, mg_min = 8 / groups;             // (XCDs per (row chunk, problem) pair, at least)
+    const int slots = (tile_wgs + rhs_wgs + mg_min - 1) / mg_min;
+    hipLaunchKernelGGL(gram1_kernel, dim3(8 * slots), dim3(G1_NT), 0, s, a, chunks, B, tile_wgs);
+    return hipGetLastError();
   }
   const int ncb = (a.n + 63) / 64;
   // tile groups: enough workgroups to occupy the CUs when the batch is small (results identical)

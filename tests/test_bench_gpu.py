@@ -43,6 +43,9 @@ def test_batch_configs_at_two_ranks_report_the_communicator_too():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak"
     assert line["rccl"]["ranks"] == 2
     assert len(line["per_rank"]["step_solves_per_s"]) == 2
-    assert line["roofline"]["scope"] == "whole_step"          # (latency-bound dominant slot: no kernel roofline claimed)
+    # (a latency-bound dominant slot claims no kernel roofline; with two ranks' launches interleaving on ONE card the
+    #  slot that dominates rank 0's five steps is the Gram in some runs, the Newton rounds' Cholesky in most)
+    roof = line["roofline"]
+    assert roof["scope"] == ("kernel" if roof["kernel"] in ("gram", "qr_leaf") else "whole_step")
     # whole-job rate = what both ranks did over the slowest rank's clock
     assert line["value"] == pytest.approx(2 * 1024 * 5 / max(line["per_rank"]["elapsed_s"]), rel=1e-6)

@@ -370,6 +370,48 @@ def test_tile_groups_do_not_change_a_single_bit(bl, monkeypatch, blsq_opt):
         assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
 
 
+def test_one_tile_per_wave_kernel_matches_the_generic_one_bit_for_bit(bl, monkeypatch, blsq_opt):
+    """At most four (row chunk, problem) pairs with n a multiple of 16 run gram1_kernel: a wave owns ONE output tile and
+    reads its operand fragments straight from global memory, four more workgroups per chunk reproduce the generic
+    kernel's sums of the rhs column.  Same k-steps in the same order with the same instruction: the whole step and
+    g = J^T f are bitwise those of the tile-group launch (option gram1 = 0) — so a problem solved alone, as the drop-in
+    front end does, has the bits it has inside a large batch.  Row counts: one chunk, two chunks, a last k-step of
+    fewer than four rows, a last 32-row block that is not full."""
+    from bounded_lsq import _synth, _abi
+    for (B, m, n) in [(1, 4096, 256), (2, 4096, 256), (1, 2048, 240), (1, 2311, 96), (2, 1001, 80), (1, 3000, 112),
+                      (1, 2050, 144), (1, 4096, 160), (3, 900, 256), (1, 700, 256)]:
+        P = _synth.trf_batch(61 + n + m, B, m, n)
+        Delta = np.full(B, 0.7)
+        outs = []
+        for g1 in ("1", "0"):
+            blsq_opt("BLSQ_GRAM1", g1)
+            ctx = _abi.Context(0)
+            sol = bl.TrfStepSolver(B, m, n, ctx=ctx)
+            ctx.gram_stats(reset=True)
+            sol.factor(P["J"], P["f"], P["x"], P["lb"], P["ub"], P["scale"])
+            assert ctx.gram_stats() == (B, 0)
+            S = sol.step(Delta, np.zeros(B))
+            outs.append((S.step.copy(), sol.fetch_factor().g.copy(), S.alpha.copy()))
+            sol.close(); ctx.close()
+        assert np.array_equal(outs[0][1], outs[1][1]), (B, m, n)     # g = J^T f: the rhs column
+        assert np.array_equal(outs[0][0], outs[1][0]), (B, m, n)
+        assert np.array_equal(outs[0][2], outs[1][2]), (B, m, n)
+    # ... and inside a batch large enough for the static-tile-row kernel: the same bits for problem 0
+    B, m, n = 300, 4096, 256
+    P = _synth.trf_batch(61 + n + m, 1, m, n)
+    Pb = _synth.trf_batch(7, B, m, n)
+    for k in P:
+        Pb[k][0] = P[k][0]
+    res = []
+    for Q, nb in ((P, 1), (Pb, B)):
+        ctx = _abi.Context(0)
+        sol = bl.TrfStepSolver(nb, m, n, ctx=ctx)
+        sol.factor(Q["J"], Q["f"], Q["x"], Q["lb"], Q["ub"], Q["scale"])
+        res.append(sol.step(np.full(nb, 0.7), np.zeros(nb)).step[0].copy())
+        sol.close(); ctx.close()
+    assert np.array_equal(res[0], res[1])
+
+
 def test_static_tile_row_kernel_matches_the_generic_one_bit_for_bit(bl, monkeypatch, blsq_opt):
     """n = 241 .. 256 (16 column tiles) with one workgroup per row chunk runs gram16_kernel (static
     tile rows per wave, shared operand fragments); every tile still accumulates the same k-steps in
