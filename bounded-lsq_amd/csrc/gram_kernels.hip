@@ -761,9 +761,68 @@ __global__ __launch_bounds__(64 * NWD, (NTT <= 2 ? 4 : 2)) void gram_direct_kern
     }
   };
   // two rounds in flight: the loads of round i + 1 are issued before round i is consumed
+  int r_start = r_lo + 4 * w;
+  if constexpr (RHS) {
+    // FULL rounds (every row inside the chunk; n = 16 NTT: every column inside the matrix) — no clamps, no masks, one
+    // pointer per k-step of the round advanced by a scalar, the column tiles and f as immediate offsets; and the next
+    // round's requests UNCONDITIONAL (after the last full round they repeat it: the step is zero): behind a branch the
+    // compiler's wait counts at the join assumed the path without new requests and the fourth k-step of every round
+    // drained the next round's loads with vmcnt(0) — one round in flight instead of two.  The same sums as below.
+    const int span = 4 * NWD * (KU - 1) + 4;              // rows from a round's first to its last, + 1
+    const int nfull = r_hi - span >= r_start ? (r_hi - span - r_start) / RSTEP + 1 : 0;
+    if (nfull > 0) {
+      const double* pj[KU];
+#pragma unroll
+      for (int u = 0; u < KU; ++u) pj[u] = Jb + (long)(r_start + 4 * NWD * u + lr) * a.ldJ + lc;
+      const double* pf = Fb + r_start + lr;
+      const long jstep = (long)RSTEP * a.ldJ;
+      auto load_full = [&](double (&fr)[KU][NTT], double (&fv)[KU]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+          fv[u] = pf[4 * NWD * u];
+#pragma unroll
+          for (int c = 0; c < NTT; ++c) fr[u][c] = __builtin_nontemporal_load(pj[u] + 16 * c);
+        }
+      };
+      auto advance = [&](bool more) __attribute__((always_inline)) {
+        const long dj = more ? jstep : 0;
+        const int df_ = more ? RSTEP : 0;
+#pragma unroll
+        for (int u = 0; u < KU; ++u) pj[u] += dj;
+        pf += df_;
+      };
+      auto use_full = [&](double (&fr)[KU][NTT], double (&fv)[KU]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+          int t = 0;
+#pragma unroll
+          for (int i = 0; i < NTT; ++i)
+#pragma unroll
+            for (int j = i; j < NTT; ++j, ++t) acc[t] = gmfma(fr[u][i], fr[u][j], acc[t]);
+#pragma unroll
+          for (int c = 0; c < NTT; ++c) gf[c] = fma(fr[u][c], fv[u], gf[c]);
+          gff = fma(fv[u], fv[u], gff);
+        }
+      };
+      double frA[KU][NTT], fvA[KU], frB[KU][NTT], fvB[KU];
+      load_full(frA, fvA);
+      for (int k = 0; k < nfull; k += 2) {
+        advance(k + 1 < nfull);
+        load_full(frB, fvB);
+        __builtin_amdgcn_sched_barrier(0);
+        use_full(frA, fvA);
+        if (k + 1 >= nfull) break;
+        advance(k + 2 < nfull);
+        load_full(frA, fvA);
+        __builtin_amdgcn_sched_barrier(0);
+        use_full(frB, fvB);
+      }
+      r_start += nfull * RSTEP;
+    }
+  }
   {
     double frA[KU][NTT], fvA[KU], frB[KU][NTT], fvB[KU];
-    int r0 = r_lo + 4 * w;
+    int r0 = r_start;
     if (r0 < r_hi) load_round(r0, frA, fvA);
     while (r0 < r_hi) {
       if (r0 + RSTEP < r_hi) load_round(r0 + RSTEP, frB, fvB);
