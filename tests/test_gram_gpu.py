@@ -457,6 +457,28 @@ def test_every_kernel_dispatch_boundary(bl, n):
         assert stats == (2, 0)
 
 
+@pytest.mark.parametrize("n", [16, 32, 48, 64])
+@pytest.mark.parametrize("m", [130, 257, 515, 1000, 1029, 2048, 2090])
+def test_narrow_gram_full_rounds_and_ragged_tails(bl, m, n, blsq_opt):
+    """gram_direct_kernel with the rhs column outside its tiles (n a multiple of 16): the FULL rounds of a row chunk run
+    a loop without clamps or masks (pointers advanced by a scalar, the next round's requests unconditional), the rest —
+    a last round that is not full, fewer rows than one round, a second chunk of a few rows — the masked loop; two, four
+    or eight waves per workgroup by the row count.  Whatever the split between the two loops and the number of waves:
+    within 1e-10 of the oracle, masks bit-exact, and the same bits for 2, 4 and 8 waves wherever the option applies
+    (the k-steps a wave takes depend on the wave count, so the sums differ — parity is the bar there)."""
+    from bounded_lsq import _synth
+    P = _synth.trf_batch(300 + m + n, 3, m, n)
+    stats, w1 = _check(bl, P, np.array([0.7, 0.05, 3.0]))
+    assert stats == (3, 0)
+    Pd = _synth.dogbox_batch(700 + m + n, 3, m, n)
+    stats, w2 = _check(bl, Pd, np.array([0.7, 0.05, 3.0]), kind="dogbox")
+    assert stats == (3, 0)
+    for nw in (2, 4, 8):
+        blsq_opt("gram_direct_nw", nw)
+        stats, _ = _check(bl, P, np.array([0.7, 0.05, 3.0]))
+        assert stats == (3, 0)
+
+
 @pytest.mark.parametrize("n", [6, 16, 48, 64, 79])
 def test_newton_rounds_in_one_launch(bl, monkeypatch, n, blsq_opt):
     """N <= 80: the Gauss-Newton step, the bracket and every Newton round of a normal-equations-path
