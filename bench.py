@@ -802,16 +802,28 @@ def main():
             # problem crosses PCIe inside the call ("including and excluding H2D of J")
             bench.step_host()
             kh = 3
+            # (a NEW array per call, as a `jac` callback returns one: the runtime's pin-on-the-fly path is fast only
+            #  for a buffer it has seen before — the copy of J is made outside the clock)
+            eh = 0.0
+            keepJ = bench.P["J"]
+            for _ in range(kh):
+                bench.P["J"] = keepJ.copy()
+                t0 = time.perf_counter()
+                bench.step_host()
+                eh += time.perf_counter() - t0
+                bench.P["J"] = keepJ
             t0 = time.perf_counter()
             for _ in range(kh):
                 bench.step_host()
-            eh = time.perf_counter() - t0
+            er = time.perf_counter() - t0
             extras["h2d_inclusive"] = {
                 "value": B * kh / eh, "unit": "step-solves/s", "ms_per_step": 1e3 * eh / kh, "steps": kh,
                 "host_to_device_GBps": 8.0 * B * m * (n + 1) * kh / eh / 1e9,
-                "note": "host-pointer API, pageable numpy buffers (one copy, the runtime pins on the fly); `pinned`: the "
-                        "same from page-locked buffers (blsq_host_alloc), copied in sub-batches under the Grams of the "
-                        "previous ones; the PCIe link bounds both, never `value`"}
+                "same_buffer_again": {"value": B * kh / er, "host_to_device_GBps": 8.0 * B * m * (n + 1) * kh / er / 1e9},
+                "note": "host-pointer API, pageable numpy buffers, a NEW array of J per call (one copy, the runtime "
+                        "pins on the fly; `same_buffer_again`: the same array in every call); `pinned`: the same from "
+                        "page-locked buffers (blsq_host_alloc), copied in sub-batches under the Grams of the previous "
+                        "ones; the PCIe link bounds all of them, never `value`"}
             try:
                 # the same with J / f in page-locked memory (Context.pinned_empty -> blsq_host_alloc): straight DMA
                 Jp = ctx.pinned_empty(bench.P["J"].shape)
